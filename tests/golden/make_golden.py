@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE classes (imported from /root/reference) on CPU.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz (small-channel full-tensor fixtures) and tests/golden/kat_c1024.json
+(known-answer checksums for seed-initialised C=1024 models).  The fixtures pin
+oracle/temporal_oracle.py (tests/test_oracle_golden.py) and, on the GPU, the HIP path
+(tests/test_gpu_*.py).  Nothing here is copied from the reference: it is only *executed*.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("VP3D_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+from common.model import TemporalModel, TemporalModelOptimized1f  # noqa: E402  (reference, executed only)
+from common.loss import mpjpe  # noqa: E402
+from common.camera import project_to_2d, project_to_2d_linear  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def randomise_bn(model, gen):
+    """Non-trivial BN affine + running stats so that BN folding / eval is really exercised."""
+    for name, buf in model.state_dict().items():
+        if name.endswith("running_mean"):
+            buf.copy_(torch.randn(buf.shape, generator=gen) * 0.1)
+        elif name.endswith("running_var"):
+            buf.copy_(torch.rand(buf.shape, generator=gen) * 1.5 + 0.5)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "bn" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif "bn" in name and name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+def sd_numpy(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def make_case(name, kind, fw, causal, channels, j_in=17, feat=2, j_out=17, dense=False, seed=0,
+              batch=3, extra_t=0, dropout=0.0, momentum=0.1):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(1000 + seed)
+    if kind == "dilated":
+        model = TemporalModel(j_in, feat, j_out, fw, causal=causal, dropout=dropout, channels=channels, dense=dense)
+    else:
+        model = TemporalModelOptimized1f(j_in, feat, j_out, fw, causal=causal, dropout=dropout, channels=channels)
+    randomise_bn(model, gen)
+    model.set_bn_momentum(momentum)
+    rf = model.receptive_field()
+    t_in = rf + (extra_t if kind == "dilated" else 0)
+    x = (torch.randn(batch, t_in, j_in, feat, generator=gen) * 0.5).clamp(-1, 1)
+    out = {"meta": json.dumps(dict(name=name, kind=kind, filter_widths=list(fw), causal=bool(causal),
+                                   channels=channels, j_in=j_in, feat=feat, j_out=j_out, dense=bool(dense),
+                                   seed=seed, dropout=dropout, momentum=momentum, rf=rf,
+                                   total_causal_shift=int(model.total_causal_shift()))),
+           "x": x.numpy()}
+    for k, v in sd_numpy(model).items():
+        out["sd0/" + k] = v
+
+    # eval forward
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x)
+    out["y_eval"] = y_eval.numpy().copy()
+
+    # train forward + backward (capture dropout masks through a hook on the shared Dropout module)
+    model.train()
+    masks = []
+
+    def hook(mod, inp, outp):
+        i, o = inp[0].detach(), outp.detach()
+        mk = torch.where(i > 0, o / torch.where(i > 0, i, torch.ones_like(i)), torch.full_like(i, float("nan")))
+        masks.append(mk.permute(0, 2, 1).contiguous().numpy())   # NCL -> NLC
+
+    hnd = model.drop.register_forward_hook(hook)
+    y_train = model(x)
+    hnd.remove()
+    target = torch.randn(y_train.shape, generator=gen) * 0.3
+    target[:, :, 0] = 0
+    loss = mpjpe(y_train, target)
+    loss.backward()
+    out["y_train"] = y_train.detach().numpy().copy()
+    out["target"] = target.numpy()
+    out["loss"] = np.float64(loss.item())
+    for k, v in sd_numpy(model).items():
+        if "running" in k or "num_batches" in k:
+            out["sd1/" + k] = v
+    for k, p in model.named_parameters():
+        out["grad/" + k] = p.grad.numpy().copy()
+    if dropout > 0:
+        for i, mk in enumerate(masks):
+            # where relu output was 0 the mask is unobservable (and irrelevant): store keep=1 scale there
+            scale = 1.0 / (1.0 - dropout)
+            mk = np.where(np.isnan(mk), scale, mk)
+            out["mask/%d" % i] = (mk > 0).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "rf", rf, "loss %.6f" % loss.item())
+
+
+def make_kat():
+    """Seed-only known answers at C=1024 (weights are not stored: they follow from torch.manual_seed)."""
+    kats = []
+    for kind, fw, causal, b in (("dilated", [3, 3, 3], False, 4), ("strided", [3, 3, 3], False, 4),
+                                ("dilated", [3, 3, 3, 3, 3], False, 2), ("strided", [3, 3, 3, 3, 3], True, 2)):
+        torch.manual_seed(0)
+        if kind == "dilated":
+            model = TemporalModel(17, 2, 17, fw, causal=causal, channels=1024)
+        else:
+            model = TemporalModelOptimized1f(17, 2, 17, fw, causal=causal, channels=1024)
+        model.eval()
+        rf = model.receptive_field()
+        x = torch.randn(b, rf, 17, 2)
+        with torch.no_grad():
+            y = model(x)
+        n_params = sum(p.numel() for p in model.parameters())
+        kats.append(dict(kind=kind, filter_widths=fw, causal=causal, batch=b, rf=rf, n_params=n_params,
+                         x_sum=float(x.double().sum()), y_sum=float(y.double().sum()),
+                         y_abs_sum=float(y.double().abs().sum()),
+                         y_first=[float(v) for v in y.flatten()[:6]],
+                         expand_w_sum=float(model.expand_conv.weight.double().sum()),
+                         shrink_w_sum=float(model.shrink.weight.double().sum())))
+        print("kat", kind, fw, "y_sum", kats[-1]["y_sum"], "params", n_params)
+    with open(os.path.join(HERE, "kat_c1024.json"), "w") as f:
+        json.dump(kats, f, indent=1)
+
+
+def make_camera():
+    gen = torch.Generator().manual_seed(7)
+    n = 6
+    X = torch.randn(n, 2, 17, 3, generator=gen)
+    X[..., 2] = X[..., 2].abs() + 0.6     # mostly in front of the camera, some |x/z| > 1 to hit the clamp
+    X[0, 0, 0, 2] = 0.2
+    cam = torch.cat((torch.rand(n, 2, generator=gen) + 1.0, torch.randn(n, 2, generator=gen) * 0.05,
+                     torch.randn(n, 3, generator=gen) * 0.2, torch.randn(n, 2, generator=gen) * 0.01), dim=1)
+    out = {"X": X.numpy(), "cam": cam.numpy()}
+    for nm, fn in (("full", project_to_2d), ("linear", project_to_2d_linear)):
+        Xr = X.clone().requires_grad_(True)
+        y = fn(Xr, cam)
+        g = torch.randn(y.shape, generator=gen)
+        (y * g).sum().backward()
+        out["y_" + nm] = y.detach().numpy()
+        out["g_" + nm] = g.numpy()
+        out["dX_" + nm] = Xr.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), **out)
+    print("wrote camera")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    make_case("dil_333_c32", "dilated", [3, 3, 3], False, 32, extra_t=11)
+    make_case("dil_333_c32_causal", "dilated", [3, 3, 3], True, 32, extra_t=5, seed=1)
+    make_case("dil_33333_c32", "dilated", [3, 3, 3, 3, 3], False, 32, batch=2, extra_t=7, seed=2)
+    make_case("dil_353_c48_dense", "dilated", [3, 5, 3], False, 48, dense=True, extra_t=4, seed=3)
+    make_case("dil_333_c32_traj", "dilated", [3, 3, 3], False, 32, j_out=1, seed=4, extra_t=2)
+    make_case("dil_333_c32_drop", "dilated", [3, 3, 3], False, 32, dropout=0.25, extra_t=3, seed=5)
+    make_case("str_333_c32", "strided", [3, 3, 3], False, 32, batch=5)
+    make_case("str_333_c32_causal", "strided", [3, 3, 3], True, 32, batch=4, seed=1)
+    make_case("str_33333_c32", "strided", [3, 3, 3, 3, 3], False, 32, batch=4, seed=2, momentum=0.03)
+    make_case("str_353_c48_j15", "strided", [3, 5, 3], False, 48, j_in=15, batch=6, seed=3)
+    make_case("str_333_c32_drop", "strided", [3, 3, 3], False, 32, dropout=0.25, batch=8, seed=5)
+    make_case("str_333_c128", "strided", [3, 3, 3], False, 128, batch=16, seed=6)
+    make_case("dil_333_c128", "dilated", [3, 3, 3], False, 128, batch=2, extra_t=30, seed=6)
+    make_kat()
+    make_camera()

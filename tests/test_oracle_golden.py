@@ -1,0 +1,60 @@
+"""Pin oracle/temporal_oracle.py against fixtures produced by the reference classes
+(tests/golden/make_golden.py, which imports /root/reference/common/model.py)."""
+import numpy as np
+import pytest
+
+from oracle import temporal_oracle as O
+from tests.util import golden_names, load_golden, mpjpe_np, rel_err, GOLDEN
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_eval_forward(name):
+    g = load_golden(name)
+    m = g["meta"]
+    y, _, _ = O.forward(g["sd0"], g["x"], m["filter_widths"], causal=m["causal"], kind=m["kind"],
+                        dense=m["dense"], training=False)
+    assert y.shape == g["y_eval"].shape
+    assert mpjpe_np(y, g["y_eval"]) < 1e-5          # north_star bar is 1e-3; oracle is pinned 100x tighter
+    assert np.abs(y - g["y_eval"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_train_forward_backward(name):
+    g = load_golden(name)
+    m = g["meta"]
+    y, cache, new_running = O.forward(g["sd0"], g["x"], m["filter_widths"], causal=m["causal"], kind=m["kind"],
+                                      dense=m["dense"], training=True, dropout_masks=g["masks"],
+                                      momentum=m["momentum"])
+    assert mpjpe_np(y, g["y_train"]) < 1e-5
+    assert abs(O.mpjpe(y, g["target"]) - float(g["loss"])) < 1e-5
+    for k, v in new_running.items():
+        assert rel_err(v, g["sd1"][k]) < 1e-5, k
+    grads = O.backward(cache, O.mpjpe_grad(y, g["target"]))
+    assert set(grads) == set(g["grad"])
+    for k, v in g["grad"].items():
+        assert grads[k].shape == v.shape, k
+        assert rel_err(grads[k], v) < 2e-4, (k, rel_err(grads[k], v))     # BASELINE.md parity bar: 1e-4..1e-3 rel
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_scalars(name):
+    m = load_golden(name)["meta"]
+    assert O.receptive_field(m["filter_widths"]) == m["rf"]
+    assert O.total_causal_shift(m["filter_widths"], m["causal"], m["kind"]) == m["total_causal_shift"]
+
+
+def test_oracle_float64_agrees():
+    g = load_golden("str_333_c32")
+    m = g["meta"]
+    y64, _, _ = O.forward(g["sd0"], g["x"], m["filter_widths"], kind=m["kind"], training=False, dtype=np.float64)
+    assert np.abs(y64 - g["y_eval"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("linear", [False, True])
+def test_oracle_camera(linear):
+    z = np.load(GOLDEN + "/camera.npz")
+    nm = "linear" if linear else "full"
+    y = O.project_to_2d(z["X"], z["cam"], linear=linear)
+    assert np.abs(y - z["y_" + nm]).max() < 1e-5
+    dX = O.project_to_2d_grad(z["X"], z["cam"], z["g_" + nm], linear=linear)
+    assert rel_err(dX, z["dX_" + nm]) < 1e-5

@@ -1,0 +1,46 @@
+"""Shared helpers for the tests: golden-fixture loading and error metrics."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+                  if not p.endswith("camera.npz"))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = dict(meta=json.loads(str(z["meta"])), sd0={}, sd1={}, grad={}, mask={})
+    for k in z.files:
+        if "/" in k:
+            grp, key = k.split("/", 1)
+            g[grp][key] = z[k]
+        elif k != "meta":
+            g[k] = z[k]
+    if g["mask"]:
+        p = g["meta"]["dropout"]
+        g["masks"] = [g["mask"][str(i)].astype(np.float32) / (1.0 - p) for i in range(len(g["mask"]))]
+    else:
+        g["masks"] = None
+    return g
+
+
+def load_kats():
+    with open(os.path.join(GOLDEN, "kat_c1024.json")) as f:
+        return json.load(f)
+
+
+def mpjpe_np(a, b):
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    return float(np.mean(np.sqrt((d ** 2).sum(-1))))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
