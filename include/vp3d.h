@@ -1,0 +1,177 @@
+/*
+ * vp3d.h -- C ABI of libvp3d.so: the MI355X (gfx950) implementation of the VideoPose3D
+ * temporal-model hot path (reference common/model.py).  Plain C: raw device pointers, sizes and a
+ * hipStream_t passed as void*.  No torch types, no C++ types.
+ *
+ * What each entry point replaces in the reference (all arithmetic there is delegated to torch.nn):
+ *   vp3d_tconv_fwd        nn.Conv1d forward         model.py:102,113-118,167,178-180,33 (+ folded BN/ReLU/residual
+ *                                                   of model.py:127,134-135 in eval mode)
+ *   vp3d_tconv_dgrad      nn.Conv1d backward-data   autograd of model.py:134-135,193-194 (+ residual scatter of :132/:191)
+ *   vp3d_tconv_wgrad      nn.Conv1d backward-weight autograd of the same calls
+ *   vp3d_bn_finalize      nn.BatchNorm1d (train)    model.py:32,117,119,179,181: batch stats, running update
+ *   vp3d_bn_act_fwd       bn -> ReLU -> Dropout (+ residual add)          model.py:127,134-135 / 188,193-194
+ *   vp3d_bn_bwd_reduce / vp3d_bn_bwd_finalize / vp3d_bn_bwd_apply         autograd of the above
+ *   vp3d_pack_weight / vp3d_bn_fold                                       eval-mode BN folding (model.eval(), run.py:427)
+ *   vp3d_project_to_2d_fwd / _bwd                                         common/camera.py:37-67, 69-90
+ *
+ * Conventions
+ *   - Layout: activations are channels-last rows, x[b][t][c] ("NLC"); this IS the reference's module boundary
+ *     layout ([B,T,J*F] in, [B,T_out,J_out*3] out, model.py:68-75), so no transposes exist anywhere.
+ *   - Ownership: the library never allocates, frees or retains user-visible memory.  Every buffer (inputs,
+ *     outputs, workspaces) is a device pointer owned by the caller and must stay alive until the stream has
+ *     passed the call.
+ *   - Ordering: every call only enqueues kernels on `stream`; no implicit synchronisation, no allocation,
+ *     hipGraph-capture safe.
+ *   - Errors: every function returns 0 on success or a negative VP3D_E_* code; vp3d_last_error() returns a
+ *     thread-local message.  Arguments are validated before anything is launched.  Nothing throws.
+ *   - Threading: stateless; concurrent calls on distinct streams are safe.
+ */
+#ifndef VP3D_H_
+#define VP3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP3D_VERSION 100
+
+#define VP3D_OK 0
+#define VP3D_E_INVALID (-1)   /* bad argument (null pointer, size, alignment) */
+#define VP3D_E_LAUNCH (-2)    /* HIP reported a launch error */
+#define VP3D_E_UNSUPPORTED (-3)
+
+typedef void* vp3d_stream_t; /* hipStream_t */
+
+/* Row gather of a temporal convolution.  Output row m = b*t_dst + t reads, for tap k, the source row
+ *   b*t_src + (t*t_stride + k*tap_step + t_off)
+ * and contributes zero when that time index falls outside [0, t_src).
+ *   forward conv (taps,dil,stride):    t_stride=stride, tap_step=dil,  t_off=0
+ *   dgrad, gather form (dilated):      t_stride=1,      tap_step=-dil, t_off=0   (rows of dx gather rows of dy)
+ *   dgrad, strided (stride==taps):     plain GEMM: taps=1, output written with ldc = taps*C_in
+ */
+typedef struct vp3d_rowmap {
+  int32_t batch;     /* B */
+  int32_t t_dst;     /* rows per sample on the output side; M = batch*t_dst */
+  int32_t t_src;     /* rows per sample of the gathered tensor */
+  int32_t t_stride;
+  int32_t tap_step;  /* signed */
+  int32_t t_off;
+  int32_t taps;
+} vp3d_rowmap;
+
+/* Fused epilogue of the GEMM kernels (all parts optional; NULL / 0 = off).
+ *   v = acc (+ bias[n]) ; if relu: v = max(v,0) ; v += residual ; C[b*c_bpitch + t*ldc + n] = v
+ * residual row for output row (b,t): tr = t*r_stride + r_off, used iff 0 <= tr < r_t and
+ *   r_col0 <= n < r_col0 + r_cols, read from R[b*r_bpitch + tr*r_ld + (n - r_col0)].
+ * stats (training-mode BatchNorm): per 64-row slab s and column n, over the valid rows of the slab of the RAW
+ *   accumulator: stat_sum[s*N + n] = sum, stat_m2[s*N + n] = sum (v - slab_mean)^2.  Deterministic (no atomics). */
+typedef struct vp3d_epilogue {
+  const float* bias;
+  int32_t relu;
+  const float* residual;
+  int64_t r_bpitch;
+  int32_t r_ld;
+  int32_t r_t;
+  int32_t r_stride;
+  int32_t r_off;
+  int32_t r_col0;
+  int32_t r_cols;
+  float* stat_sum;
+  float* stat_m2;
+} vp3d_epilogue;
+
+/* Counter-based dropout (Philox4x32-10): element e of layer `layer` is kept iff
+ * uniform(Philox(key=seed, counter=(e>>2, layer, offset))[e&3]) >= p; kept values are scaled by 1/(1-p).
+ * The mask is never stored: backward regenerates it from the same (seed, offset, layer). */
+typedef struct vp3d_dropout {
+  float p;
+  uint64_t seed;
+  uint64_t offset;
+  uint32_t layer;
+} vp3d_dropout;
+
+int vp3d_version(void);
+const char* vp3d_last_error(void);
+
+/* number of 64-row statistic slabs a [M, *] output produces (size stat_sum / stat_m2 as slabs*N floats) */
+int64_t vp3d_stat_slabs(int64_t M);
+
+/* y[b,t,:] = sum_k x[b, map(t,k), :] @ W_k  (+ epilogue).   M = B*t_dst, N = c_out, K = taps*c_in.
+ *   x  : gathered activations, row pitch ldx floats, c_in channels used per tap
+ *   wt : packed weights  wt[n*ldw + k*c_in + ci] == W[n][ci][k]   (vp3d_pack_weight, mode 0)
+ *   y  : output rows at y[b*y_bpitch + t*ldy + n]
+ *   zeros: >= 1024 B of device zeros (source for out-of-range taps / ragged tiles) */
+int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
+                   const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
+                   const vp3d_epilogue* epi, const float* zeros);
+
+/* dx[b,s,:] = sum_k dy[b, map(s,k), :] @ W_k^T (+ epilogue: the residual-gradient scatter).
+ *   M = B*t_dst rows of dx, N = n_out columns, K = taps*c_out.
+ *   wt: the SAME forward-packed weights; column n of tap k is read at wt[co*ldw + k*w_tap_stride + n]. */
+int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
+                     const float* wt, int32_t ldw, int32_t w_tap_stride, int32_t n_out, float* dx,
+                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros);
+
+/* dWt[co][k*c_in + ci] = sum_m dy[m][co] * x[map(m,k)][ci].   Reduction over M = B*t_dst rows, split in
+ * `splits` slices whose partial [c_out, taps*c_in] matrices go to `partials` (splits*c_out*taps*c_in floats);
+ * vp3d_wgrad_reduce sums them.  With splits == 1 `partials` is the result itself. */
+int vp3d_tconv_wgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
+                     const float* x, int32_t ldx, int32_t c_in, float* partials, int32_t splits,
+                     const float* zeros);
+/* dW[co][ci][k] (reference Conv1d.weight layout) = sum_s partials[s][co][k*c_in + ci] */
+int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t splits, int32_t c_out, int32_t c_in,
+                      int32_t taps, float* dw);
+
+/* mode 0: out[co][k*c_in + ci] = w[co][ci][k] * (scale ? scale[co] : 1)      (reference layout -> packed) */
+int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
+                     const float* scale, float* out);
+/* eval-mode BN folding: scale[c] = gamma/sqrt(running_var+eps), shift[c] = beta - running_mean*scale */
+int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* scale, float* shift);
+
+/* Training BatchNorm statistics from the GEMM's slab partials (Chan merge in fp64):
+ * save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean/var updated in place
+ * (unbiased variance), num_batches_tracked += 1 (any of the running pointers may be NULL). */
+int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* stat_sum, const float* stat_m2,
+                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                     float* save_mean, float* save_invstd);
+
+/* out[m][c] = (res ? res[resrow(m)][c] : 0) + dropout(relu(y[m][c]*scale[c] + shift[c])).
+ * resrow(m = b*t_dst + t) = b*r_t + t*r_stride + r_off (row pitch r_ld).  drop may be NULL (p = 0). */
+int vp3d_bn_act_fwd(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
+                    const float* shift, const vp3d_dropout* drop, const float* res, int32_t t_dst, int32_t r_t,
+                    int32_t r_stride, int32_t r_off, int32_t r_ld, float* out);
+
+/* Backward of a = dropout(relu(bn(y))):  g = go*keep*[z>0];  partial sums of g and g*xhat per channel into
+ * partials[nparts][2][C]; returns the number of parts through *nparts (query with partials == NULL). */
+int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       const vp3d_dropout* drop, float* partials, int32_t* nparts);
+/* dgamma[c] = sum g*xhat, dbeta[c] = sum g   (fp64 accumulation over the parts) */
+int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials, int32_t nparts, float* dgamma,
+                         float* dbeta);
+/* dy = scale*(g - dbeta/M - xhat*dgamma/M) */
+int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      const vp3d_dropout* drop, const float* dgamma, const float* dbeta, float* dy);
+
+/* out[n] = sum_m g[m*ld + n]   (bias gradient of the shrink conv) */
+int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int32_t ld, float* out);
+
+/* materialise the dropout keep*scale mask of a layer as floats (tests / debugging only) */
+int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out);
+
+/* camera.py:37-67 / 69-90: X [n_cam, pts_per_cam, 3], cam [n_cam, 9] -> out [n_cam, pts_per_cam, 2] */
+int vp3d_project_to_2d_fwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
+                           const float* cam, int32_t linear, float* out);
+int vp3d_project_to_2d_bwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
+                           const float* cam, const float* gout, int32_t linear, float* dX);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP3D_H_ */

@@ -1,0 +1,118 @@
+"""Host-side (no GPU) checks: C-ABI exports, state_dict / init parity with the reference, plan arithmetic,
+loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import videopose3d_amd as V
+from videopose3d_amd import _lib, plan as P
+from tests.util import golden_names, load_golden, load_kats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(meta, dropout=None):
+    kw = dict(causal=meta["causal"], dropout=meta["dropout"] if dropout is None else dropout, channels=meta["channels"])
+    if meta["kind"] == "dilated":
+        return V.TemporalModel(meta["j_in"], meta["feat"], meta["j_out"], meta["filter_widths"], dense=meta["dense"], **kw)
+    return V.TemporalModelOptimized1f(meta["j_in"], meta["feat"], meta["j_out"], meta["filter_widths"], **kw)
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vp3d.h")).read()
+    declared = set(re.findall(r"\b(vp3d_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vp3d_stream_t"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    h = _lib.lib()                                   # loads libvp3d.so; raises if any symbol is missing
+    for name in declared:
+        assert hasattr(h, name)
+    assert h.vp3d_version() == 100
+    assert h.vp3d_stat_slabs(129) == 3
+
+
+def test_abi_rejects_bad_arguments_without_gpu():
+    h = _lib.lib()
+    rc = h.vp3d_colsum(None, 0, 4, None, 4, None)    # validation happens before any launch
+    assert rc == -1 and b"colsum" in h.vp3d_last_error()
+    with pytest.raises(_lib.Vp3dError):
+        _lib.check(rc, "vp3d_colsum")
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_state_dict_is_reference_compatible(name):
+    g = load_golden(name)
+    m = _make(g["meta"])
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["sd0"].keys())              # same names, same order as the reference emits
+    for k, v in sd.items():
+        assert tuple(v.shape) == g["sd0"][k].shape, k
+        assert str(v.dtype).replace("torch.", "") == str(g["sd0"][k].dtype), k
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["sd0"].items()}, strict=True)
+    assert m.receptive_field() == g["meta"]["rf"]
+    assert m.total_causal_shift() == g["meta"]["total_causal_shift"]
+    m.set_bn_momentum(0.03)
+    assert m.expand_bn.momentum == 0.03 and all(bn.momentum == 0.03 for bn in m.layers_bn)
+
+
+@pytest.mark.parametrize("kat", load_kats(), ids=lambda k: "%s-%d" % (k["kind"], len(k["filter_widths"])))
+def test_seeded_init_matches_reference(kat):
+    torch.manual_seed(0)
+    cls = V.TemporalModel if kat["kind"] == "dilated" else V.TemporalModelOptimized1f
+    m = cls(17, 2, 17, kat["filter_widths"], causal=kat["causal"], channels=1024)
+    assert sum(p.numel() for p in m.parameters()) == kat["n_params"]
+    assert abs(float(m.expand_conv.weight.double().sum()) - kat["expand_w_sum"]) < 1e-6
+    assert abs(float(m.shrink.weight.double().sum()) - kat["shrink_w_sum"]) < 1e-6
+    x = torch.randn(kat["batch"], kat["rf"], 17, 2)               # same RNG stream position as the reference run
+    assert abs(float(x.double().sum()) - kat["x_sum"]) < 1e-6
+
+
+def test_two_classes_share_state_dict():
+    a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=64)
+    b = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=64)
+    b.load_state_dict(a.state_dict())                             # run.py:426
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+
+
+def test_no_cpu_fallback():
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=32)
+    with pytest.raises(V.Vp3dError):
+        m(torch.zeros(2, 27, 17, 2))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(2, 27, 16, 2))
+    with pytest.raises(AssertionError):
+        V.TemporalModel(17, 2, 17, [3, 4, 3])
+
+
+def test_plan_shapes_cfg2_cfg3():
+    p2 = P.make_plan("dilated", 34, 1024, 51, [3, 3, 3, 3, 3])
+    assert p2.lengths(243) == [241, 235, 217, 163, 1] and p2.receptive_field() == 243
+    p3 = P.make_plan("strided", 34, 1024, 51, [3, 3, 3, 3, 3])
+    assert p3.lengths(243) == [81, 27, 9, 3, 1]
+    assert [r.start for r in p3.res] == [1, 1, 1, 1] and [r.step for r in p3.res] == [3, 3, 3, 3]
+    pc = P.make_plan("strided", 34, 1024, 51, [3, 3, 3], causal=True)
+    assert [r.start for r in pc.res] == [2, 2] and pc.total_causal_shift() == 13
+    pd = P.make_plan("dilated", 34, 1024, 51, [3, 3, 3], causal=True)
+    assert pd.total_causal_shift() == 91                           # the reference's double counting, kept
+    with pytest.raises(ValueError):
+        p2.lengths(100)
+    # algorithmic FLOPs of BASELINE.md section 2 follow from the plan
+    def flops(plan, t):
+        ls = [t] + plan.lengths(t)
+        f = 0
+        for i, c in enumerate(plan.convs):
+            t_out = ls[1 + (i + 1) // 2] if i else ls[1]
+            f += 2 * t_out * c.c_out * c.taps * c.c_in
+        return f + 2 * ls[-1] * plan.shrink.c_out * plan.shrink.c_in
+    assert flops(p2, 243) == 5217830912
+    assert flops(p3, 243) == 352569344
+
+
+def test_wgrad_splits_bounds():
+    for m in (2, 31, 1024, 27648, 82944):
+        s = P.wgrad_splits(m, 1024, 3072)
+        assert 1 <= s <= max(1, (m + 31) // 32)

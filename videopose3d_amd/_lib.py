@@ -1,0 +1,93 @@
+"""ctypes binding of libvp3d.so (C ABI declared in include/vp3d.h).
+
+The library is hand-written HIP for gfx950 and is built in-tree by ``__graft_entry__.build()`` /
+``python -m videopose3d_amd.build``.  There is NO fallback: if the shared object is missing or a call
+fails, an exception is raised -- the product path never silently routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvp3d.so")
+
+
+class Vp3dError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("t_dst", C.c_int32), ("t_src", C.c_int32), ("t_stride", C.c_int32),
+                ("tap_step", C.c_int32), ("t_off", C.c_int32), ("taps", C.c_int32)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("relu", C.c_int32), ("residual", C.c_void_p), ("r_bpitch", C.c_int64),
+                ("r_ld", C.c_int32), ("r_t", C.c_int32), ("r_stride", C.c_int32), ("r_off", C.c_int32),
+                ("r_col0", C.c_int32), ("r_cols", C.c_int32), ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p)]
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32)]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_P = C.POINTER
+
+# name -> (restype, argtypes); every symbol declared in include/vp3d.h must appear here
+SIGNATURES = {
+    "vp3d_version": (C.c_int, []),
+    "vp3d_last_error": (C.c_char_p, []),
+    "vp3d_stat_slabs": (_i64, [_i64]),
+    "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp]),
+    "vp3d_tconv_dgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32,
+                                   _P(Epilogue), _vp]),
+    "vp3d_tconv_wgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "vp3d_wgrad_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vp3d_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "vp3d_bn_fold": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "vp3d_bn_finalize": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_bn_act_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vp3d_bn_bwd_reduce": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _P(_i32)]),
+    "vp3d_bn_bwd_finalize": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
+    "vp3d_bn_bwd_apply": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp]),
+    "vp3d_colsum": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
+    "vp3d_dropout_mask": (C.c_int, [_vp, _i64, _P(Dropout), _vp]),
+    "vp3d_project_to_2d_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp]),
+    "vp3d_project_to_2d_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises Vp3dError when the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Vp3dError(
+            "libvp3d.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for this path." % LIB_PATH)
+    # torch must be imported first so that its bundled libamdhip64.so.7 (same SONAME as /opt/rocm's) is the one
+    # HIP runtime in the process: torch's stream handles are then valid inside our launches.
+    import torch  # noqa: F401
+    h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:  # pragma: no cover
+            raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if h.vp3d_version() != 100:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (100); rebuild" % h.vp3d_version())
+    _lib = h
+    return h
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().vp3d_last_error()
+        raise Vp3dError("%s failed (code %d): %s" % (what or "vp3d call", rc, msg.decode() if msg else "?"))

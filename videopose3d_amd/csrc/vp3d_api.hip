@@ -1,0 +1,174 @@
+// C ABI entry points for the temporal-convolution GEMMs + error plumbing (see include/vp3d.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vp3d_internal.h"
+
+namespace vp3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return VP3D_E_LAUNCH;
+  }
+  return VP3D_OK;
+}
+
+static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, int32_t ldc, int32_t n_cols) {
+  e->C = C;
+  e->c_bpitch = c_bpitch;
+  e->ldc = ldc;
+  e->bias = nullptr;
+  e->relu = 0;
+  e->R = nullptr;
+  e->r_bpitch = 0;
+  e->r_ld = e->r_t = e->r_stride = e->r_off = e->r_col0 = e->r_cols = 0;
+  e->stat_sum = e->stat_m2 = nullptr;
+  if (u == nullptr) return VP3D_OK;
+  e->bias = u->bias;
+  e->relu = u->relu;
+  if (u->residual != nullptr) {
+    VP3D_REQUIRE(u->r_t > 0 && u->r_ld > 0 && u->r_cols > 0 && u->r_col0 >= 0 && u->r_col0 + u->r_cols <= n_cols,
+                 "epilogue: bad residual map (r_t=%d r_ld=%d r_col0=%d r_cols=%d n=%d)", u->r_t, u->r_ld, u->r_col0,
+                 u->r_cols, n_cols);
+    e->R = u->residual;
+    e->r_bpitch = u->r_bpitch;
+    e->r_ld = u->r_ld;
+    e->r_t = u->r_t;
+    e->r_stride = u->r_stride;
+    e->r_off = u->r_off;
+    e->r_col0 = u->r_col0;
+    e->r_cols = u->r_cols;
+  }
+  VP3D_REQUIRE((u->stat_sum == nullptr) == (u->stat_m2 == nullptr), "epilogue: stat_sum and stat_m2 go together");
+  e->stat_sum = u->stat_sum;
+  e->stat_m2 = u->stat_m2;
+  return VP3D_OK;
+}
+
+static int check_map(const vp3d_rowmap* m, const char* who) {
+  VP3D_REQUIRE(m != nullptr, "%s: null rowmap", who);
+  VP3D_REQUIRE(m->batch > 0 && m->t_dst > 0 && m->t_src > 0 && m->taps > 0, "%s: bad rowmap (B=%d t_dst=%d t_src=%d taps=%d)",
+               who, m->batch, m->t_dst, m->t_src, m->taps);
+  VP3D_REQUIRE((int64_t)m->batch * m->t_dst < (int64_t)1 << 31 && (int64_t)m->batch * m->t_src < (int64_t)1 << 31,
+               "%s: more than 2^31 rows", who);
+  return VP3D_OK;
+}
+
+}  // namespace vp3d
+
+using namespace vp3d;
+
+extern "C" {
+
+int vp3d_version(void) { return VP3D_VERSION; }
+const char* vp3d_last_error(void) { return g_err; }
+int64_t vp3d_stat_slabs(int64_t M) { return (M + 63) / 64; }
+
+int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
+                   const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
+                   const vp3d_epilogue* epi, const float* zeros) {
+  int rc = check_map(map, "tconv_fwd");
+  if (rc) return rc;
+  VP3D_REQUIRE(x && wt && y && zeros, "tconv_fwd: null pointer");
+  VP3D_REQUIRE(c_in > 0 && c_out > 0 && ldx >= 1 && ldw >= map->taps * c_in && ldy >= c_out,
+               "tconv_fwd: bad sizes (c_in=%d c_out=%d ldx=%d ldw=%d ldy=%d)", c_in, c_out, ldx, ldw, ldy);
+  RowsGemmArgs a;
+  a.A = x;
+  a.B = wt;
+  a.zeros = zeros;
+  a.M = map->batch * map->t_dst;
+  a.N = c_out;
+  a.K = map->taps * c_in;
+  a.lda = ldx;
+  a.c_src = c_in;
+  a.ldb = ldw;
+  a.b_tap_stride = 0;
+  a.t_dst = map->t_dst;
+  a.t_src = map->t_src;
+  a.t_stride = map->t_stride;
+  a.tap_step = map->tap_step;
+  a.t_off = map->t_off;
+  a.taps = map->taps;
+  a.m_tiles = (a.M + 127) / 128;
+  a.n_tiles = (a.N + 127) / 128;
+  rc = fill_epi(&a.epi, epi, y, y_bpitch, ldy, c_out);
+  if (rc) return rc;
+  return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/true);
+}
+
+int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
+                     const float* wt, int32_t ldw, int32_t w_tap_stride, int32_t n_out, float* dx,
+                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros) {
+  int rc = check_map(map, "tconv_dgrad");
+  if (rc) return rc;
+  VP3D_REQUIRE(dy && wt && dx && zeros, "tconv_dgrad: null pointer");
+  VP3D_REQUIRE(c_out > 0 && n_out > 0 && lddy >= c_out && ldw >= n_out && lddx >= n_out,
+               "tconv_dgrad: bad sizes (c_out=%d n_out=%d lddy=%d ldw=%d lddx=%d)", c_out, n_out, lddy, ldw, lddx);
+  RowsGemmArgs a;
+  a.A = dy;
+  a.B = wt;
+  a.zeros = zeros;
+  a.M = map->batch * map->t_dst;
+  a.N = n_out;
+  a.K = map->taps * c_out;
+  a.lda = lddy;
+  a.c_src = c_out;
+  a.ldb = ldw;
+  a.b_tap_stride = w_tap_stride;
+  a.t_dst = map->t_dst;
+  a.t_src = map->t_src;
+  a.t_stride = map->t_stride;
+  a.tap_step = map->tap_step;
+  a.t_off = map->t_off;
+  a.taps = map->taps;
+  a.m_tiles = (a.M + 127) / 128;
+  a.n_tiles = (a.N + 127) / 128;
+  rc = fill_epi(&a.epi, epi, dx, dx_bpitch, lddx, n_out);
+  if (rc) return rc;
+  return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/false);
+}
+
+int vp3d_tconv_wgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
+                     const float* x, int32_t ldx, int32_t c_in, float* partials, int32_t splits,
+                     const float* zeros) {
+  int rc = check_map(map, "tconv_wgrad");
+  if (rc) return rc;
+  VP3D_REQUIRE(dy && x && partials && zeros, "tconv_wgrad: null pointer");
+  VP3D_REQUIRE(c_out > 0 && c_in > 0 && lddy >= c_out && ldx >= 1 && splits >= 1, "tconv_wgrad: bad sizes");
+  RedGemmArgs a;
+  a.G = dy;
+  a.X = x;
+  a.zeros = zeros;
+  a.C = partials;
+  a.Mred = map->batch * map->t_dst;
+  a.Mo = c_out;
+  a.N = map->taps * c_in;
+  a.ldg = lddy;
+  a.ldx = ldx;
+  a.c_x = c_in;
+  a.t_dst = map->t_dst;
+  a.t_src = map->t_src;
+  a.t_stride = map->t_stride;
+  a.tap_step = map->tap_step;
+  a.t_off = map->t_off;
+  a.m_tiles = (a.Mo + 127) / 128;
+  a.n_tiles = (a.N + 127) / 128;
+  const int nkt = (a.Mred + 31) / 32;
+  VP3D_REQUIRE(splits <= nkt, "tconv_wgrad: splits=%d exceeds the %d reduction tiles", splits, nkt);
+  a.splits = splits;
+  a.kt_per_split = (nkt + splits - 1) / splits;
+  return launch_red_gemm((hipStream_t)stream, a);
+}
+
+}  // extern "C"

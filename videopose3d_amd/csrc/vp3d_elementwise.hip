@@ -1,0 +1,553 @@
+// HBM-bound kernels around the GEMMs: BatchNorm statistics / apply / backward, dropout (Philox, never stored),
+// weight packing / BN folding, split-K reduction of wgrad, column sums, camera projection.
+// All streaming kernels move 16 B per lane (float4) when the channel count allows it (C % 4 == 0).
+#include "vp3d_internal.h"
+
+namespace vp3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: the dropout mask is a pure function of
+// (seed, offset, layer, element index) and is regenerated in backward instead of being stored.
+// ---------------------------------------------------------------------------------------------------------
+struct DropP {
+  float p, inv_keep;
+  uint32_t k0, k1, off_lo, layer;
+  int on;
+};
+
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                        uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep*scale factors of the 4 elements 4*q .. 4*q+3
+__device__ __forceinline__ void drop4(const DropP& d, uint64_t q, float (&mk)[4]) {
+  uint32_t r[4];
+  philox4((uint32_t)q, (uint32_t)(q >> 32), d.layer, d.off_lo, d.k0, d.k1, r);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float u = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
+    mk[e] = (u >= d.p) ? d.inv_keep : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm statistics finalize (training): merge the GEMM's 64-row slab partials in fp64.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab, const float* __restrict__ psum,
+                                                     const float* __restrict__ pm2, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float momentum,
+                                                     float* running_mean, float* running_var, int64_t* nbt,
+                                                     float* scale, float* shift, float* save_mean,
+                                                     float* save_invstd) {
+  __shared__ double s1[4][64], s2[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    for (int s = g; s < nslab; s += 4) {
+      const int64_t left = M - (int64_t)s * 64;
+      const double cnt = (double)(left < 64 ? left : 64);
+      const double sum = (double)psum[(int64_t)s * C + c];
+      a1 += sum;
+      a2 += (double)pm2[(int64_t)s * C + c] + sum * sum / cnt;
+    }
+  }
+  s1[g][cl] = a1;
+  s2[g][cl] = a2;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    const double S1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
+    const double S2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+    const double mean = S1 / (double)M;
+    double var = (S2 - S1 * mean) / (double)M;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var != nullptr) {
+      const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) nbt[0] += 1;
+}
+
+__global__ void k_bn_fold(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                          float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out = [res +] dropout(relu(y*scale + shift))
+// ---------------------------------------------------------------------------------------------------------
+struct ResMap {
+  const float* res;
+  int t_dst, r_t, r_stride, r_off, r_ld;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_act_fwd(int64_t M, int C, const float* __restrict__ y,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    DropP d, ResMap rm, float* __restrict__ out) {
+  const int64_t total = M * C;
+  const int64_t nq = (total + VEC - 1) / VEC;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q * VEC;
+    const int64_t m = e0 / C;
+    const int c = (int)(e0 - m * C);
+    const float* rrow = nullptr;
+    if (rm.res != nullptr) {
+      const int64_t b = m / rm.t_dst;
+      const int t = (int)(m - b * rm.t_dst);
+      rrow = rm.res + (b * rm.r_t + (int64_t)t * rm.r_stride + rm.r_off) * rm.r_ld + c;
+    }
+    if (VEC == 4) {
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (d.on) drop4(d, (uint64_t)q, mk);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (rrow != nullptr) rv = *reinterpret_cast<const f32x4*>(rrow);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(yv[e], sc[e], sh[e]);
+        o[e] = rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f));
+      }
+      *reinterpret_cast<f32x4*>(out + e0) = o;
+    } else {
+      float mkv = 1.f;
+      if (d.on) {
+        float mk[4];
+        drop4(d, (uint64_t)(e0 >> 2), mk);
+        mkv = mk[e0 & 3];
+      }
+      const float z = fmaf(y[e0], scale[c], shift[c]);
+      out[e0] = (rrow != nullptr ? rrow[0] : 0.f) + (z > 0.f ? z * mkv : (z != z ? z : 0.f));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BN backward, pass 1: per-channel partial sums of g and g*xhat.   Thread owns VEC channels and strides rows;
+// partials[part][0][c] = sum g, partials[part][1][c] = sum g*xhat.
+// Launch: grid.x = channel strips of 256*VEC, grid.y = row groups; part = blockIdx.y * rows_per_block + rsub.
+// ---------------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(int64_t M, int C, const float* __restrict__ go,
+                                                       const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, DropP d,
+                                                       float* __restrict__ partials, int lanes_per_row,
+                                                       int rows_per_block) {
+  const int lr = threadIdx.x % lanes_per_row;
+  const int rsub = threadIdx.x / lanes_per_row;
+  const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
+  if (rsub >= rows_per_block || c >= C) return;
+  float sg[VEC], sgx[VEC], sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sg[e] = sgx[e] = 0.f;
+    sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
+  }
+  const int64_t row_step = (int64_t)gridDim.y * rows_per_block;
+  for (int64_t m = (int64_t)blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+    const int64_t e0 = m * C + c;
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (VEC == 4) {
+      if (d.on) drop4(d, (uint64_t)(e0 >> 2), mk);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(go + e0);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(yv[e], sc[e], sh[e]);
+        const float g = z > 0.f ? gv[e] * mk[e] : 0.f;
+        sg[e] += g;
+        sgx[e] += g * ((yv[e] - mu[e]) * is[e]);
+      }
+    } else {
+      float mkv = 1.f;
+      if (d.on) {
+        drop4(d, (uint64_t)(e0 >> 2), mk);
+        mkv = mk[e0 & 3];
+      }
+      const float yv = y[e0];
+      const float z = fmaf(yv, sc[0], sh[0]);
+      const float g = z > 0.f ? go[e0] * mkv : 0.f;
+      sg[0] += g;
+      sgx[0] += g * ((yv - mu[0]) * is[0]);
+    }
+  }
+  const int64_t part = (int64_t)blockIdx.y * rows_per_block + rsub;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    partials[(part * 2 + 0) * C + c + e] = sg[e];
+    partials[(part * 2 + 1) * C + c + e] = sgx[e];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __restrict__ partials, int nparts,
+                                                         float* dgamma, float* dbeta) {
+  __shared__ double s1[4][64], s2[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C)
+    for (int p = g; p < nparts; p += 4) {
+      a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
+      a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
+    }
+  s1[g][cl] = a1;
+  s2[g][cl] = a2;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    dbeta[c] = (float)(s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
+    dgamma[c] = (float)(s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t M, int C, const float* __restrict__ go,
+                                                      const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, DropP d,
+                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                      float* __restrict__ dy) {
+  const int64_t total = M * C;
+  const int64_t nq = (total + VEC - 1) / VEC;
+  const float inv_m = 1.0f / (float)M;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q * VEC;
+    const int c = (int)(e0 % C);
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (d.on) drop4(d, (uint64_t)(e0 >> 2), mk);
+    if (VEC == 4) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(go + e0);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sc = scale[c + e];
+        const float z = fmaf(yv[e], sc, shift[c + e]);
+        const float g = z > 0.f ? gv[e] * mk[e] : 0.f;
+        const float xh = (yv[e] - mean[c + e]) * invstd[c + e];
+        o[e] = sc * (g - dbeta[c + e] * inv_m - xh * (dgamma[c + e] * inv_m));
+      }
+      *reinterpret_cast<f32x4*>(dy + e0) = o;
+    } else {
+      const float sc = scale[c];
+      const float yv = y[e0];
+      const float z = fmaf(yv, sc, shift[c]);
+      const float g = z > 0.f ? go[e0] * mk[e0 & 3] : 0.f;
+      const float xh = (yv - mean[c]) * invstd[c];
+      dy[e0] = sc * (g - dbeta[c] * inv_m - xh * (dgamma[c] * inv_m));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------------------
+// out[co][k*c_in + ci] = w[co][ci][k] * scale[co]
+__global__ void __launch_bounds__(256) k_pack_weight(int c_out, int c_in, int taps, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, float* __restrict__ out) {
+  const int64_t total = (int64_t)c_out * c_in;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t co = i / c_in;
+    const int ci = (int)(i - co * c_in);
+    const float s = scale != nullptr ? scale[co] : 1.f;
+    const float* src = w + i * taps;
+    float* dst = out + co * (int64_t)taps * c_in + ci;
+    for (int k = 0; k < taps; ++k) dst[(int64_t)k * c_in] = src[k] * s;
+  }
+}
+
+// dw[co][ci][k] = sum_s partials[s][co][k*c_in + ci]
+__global__ void __launch_bounds__(256) k_wgrad_reduce(int splits, int c_out, int c_in, int taps,
+                                                      const float* __restrict__ partials, float* __restrict__ dw) {
+  const int64_t total = (int64_t)c_out * c_in;
+  const int64_t mat = (int64_t)c_out * taps * c_in;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t co = i / c_in;
+    const int ci = (int)(i - co * c_in);
+    for (int k = 0; k < taps; ++k) {
+      const float* src = partials + co * (int64_t)taps * c_in + (int64_t)k * c_in + ci;
+      float acc = 0.f;
+      for (int s = 0; s < splits; ++s) acc += src[(int64_t)s * mat];
+      dw[i * taps + k] = acc;
+    }
+  }
+}
+
+// out[n] = sum_m g[m*ld + n]
+__global__ void __launch_bounds__(256) k_colsum(int64_t M, int N, const float* __restrict__ g, int ld, float* out) {
+  __shared__ float red[256];
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int64_t m = threadIdx.x; m < M; m += 256) s += g[m * ld + n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_dropout_mask(int64_t n, DropP d, float* out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (d.on) drop4(d, (uint64_t)(e >> 2), mk);
+    out[e] = mk[e & 3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// camera projection (reference common/camera.py:37-67, 69-90) forward / backward wrt X
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_project_fwd(int64_t n_cam, int64_t ppc, const float* __restrict__ X,
+                                                     const float* __restrict__ cam, int linear, float* __restrict__ out) {
+  const int64_t total = n_cam * ppc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* cp = cam + (i / ppc) * 9;
+    const float x = X[i * 3], yv = X[i * 3 + 1], z = X[i * 3 + 2];
+    const float u = x / z, v = yv / z;
+    const float a = fminf(fmaxf(u, -1.f), 1.f), b = fminf(fmaxf(v, -1.f), 1.f);
+    float ox, oy;
+    if (linear) {
+      ox = cp[0] * a + cp[2];
+      oy = cp[1] * b + cp[3];
+    } else {
+      const float r2 = a * a + b * b;
+      const float s = 1.f + (cp[4] * r2 + cp[5] * (r2 * r2) + cp[6] * (r2 * r2 * r2)) + (cp[7] * a + cp[8] * b);
+      ox = cp[0] * (a * s + cp[7] * r2) + cp[2];
+      oy = cp[1] * (b * s + cp[8] * r2) + cp[3];
+    }
+    out[i * 2] = ox;
+    out[i * 2 + 1] = oy;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_project_bwd(int64_t n_cam, int64_t ppc, const float* __restrict__ X,
+                                                     const float* __restrict__ cam, const float* __restrict__ gout,
+                                                     int linear, float* __restrict__ dX) {
+  const int64_t total = n_cam * ppc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* cp = cam + (i / ppc) * 9;
+    const float k1 = linear ? 0.f : cp[4], k2 = linear ? 0.f : cp[5], k3 = linear ? 0.f : cp[6];
+    const float p1 = linear ? 0.f : cp[7], p2 = linear ? 0.f : cp[8];
+    const float x = X[i * 3], yv = X[i * 3 + 1], z = X[i * 3 + 2];
+    const float u = x / z, v = yv / z;
+    const float a = fminf(fmaxf(u, -1.f), 1.f), b = fminf(fmaxf(v, -1.f), 1.f);
+    const float r2 = a * a + b * b;
+    const float s = 1.f + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2 + p1 * a + p2 * b;
+    const float hx = cp[0] * gout[i * 2], hy = cp[1] * gout[i * 2 + 1];
+    const float ds = hx * a + hy * b;
+    const float dr2 = hx * p1 + hy * p2 + ds * (k1 + 2.f * k2 * r2 + 3.f * k3 * r2 * r2);
+    const float da = hx * s + ds * p1 + 2.f * a * dr2;
+    const float db = hy * s + ds * p2 + 2.f * b * dr2;
+    const float du = (u >= -1.f && u <= 1.f) ? da : 0.f;
+    const float dv = (v >= -1.f && v <= 1.f) ? db : 0.f;
+    dX[i * 3] = du / z;
+    dX[i * 3 + 1] = dv / z;
+    dX[i * 3 + 2] = -(du * u + dv * v) / z;
+  }
+}
+
+inline DropP make_drop(const vp3d_dropout* d) {
+  DropP r;
+  r.on = (d != nullptr && d->p > 0.f) ? 1 : 0;
+  r.p = r.on ? d->p : 0.f;
+  r.inv_keep = r.on ? 1.0f / (1.0f - d->p) : 1.f;
+  r.k0 = r.on ? (uint32_t)d->seed : 0u;
+  r.k1 = r.on ? (uint32_t)(d->seed >> 32) : 0u;
+  r.off_lo = r.on ? (uint32_t)d->offset : 0u;
+  r.layer = r.on ? d->layer : 0u;
+  return r;
+}
+
+inline int stream_grid(int64_t work_items, int threads = 256) {
+  int64_t blocks = (work_items + threads - 1) / threads;
+  const int64_t cap = 256 * 8;   // 256 CUs x 8 blocks, grid-stride beyond
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+}  // namespace vp3d
+
+using namespace vp3d;
+
+extern "C" {
+
+int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* stat_sum, const float* stat_m2,
+                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                     float* save_mean, float* save_invstd) {
+  VP3D_REQUIRE(C > 0 && M > 0, "bn_finalize: C=%d M=%lld", C, (long long)M);
+  VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd,
+               "bn_finalize: null pointer");
+  const int nslab = (int)vp3d_stat_slabs(M);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+                     stat_m2, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
+                     save_mean, save_invstd);
+  return check_launch("bn_finalize");
+}
+
+int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* scale, float* shift) {
+  VP3D_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_fold: bad argument");
+  hipLaunchKernelGGL(k_bn_fold, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  return check_launch("bn_fold");
+}
+
+int vp3d_bn_act_fwd(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
+                    const float* shift, const vp3d_dropout* drop, const float* res, int32_t t_dst, int32_t r_t,
+                    int32_t r_stride, int32_t r_off, int32_t r_ld, float* out) {
+  VP3D_REQUIRE(M > 0 && C > 0 && y && scale && shift && out, "bn_act_fwd: bad argument");
+  if (drop) VP3D_REQUIRE(drop->p >= 0.f && drop->p < 1.f, "bn_act_fwd: dropout p=%f", drop->p);
+  ResMap rm{res, t_dst, r_t, r_stride, r_off, r_ld};
+  if (res) VP3D_REQUIRE(t_dst > 0 && r_t > 0 && r_ld >= C, "bn_act_fwd: bad residual map");
+  const DropP d = make_drop(drop);
+  const bool vec = (C % 4 == 0) && aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) &&
+                   (!res || (aligned16(res) && r_ld % 4 == 0));
+  if (vec)
+    hipLaunchKernelGGL((k_bn_act_fwd<4>), dim3(stream_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, M, C, y,
+                       scale, shift, d, rm, out);
+  else
+    hipLaunchKernelGGL((k_bn_act_fwd<1>), dim3(stream_grid(M * C)), dim3(256), 0, (hipStream_t)stream, M, C, y, scale,
+                       shift, d, rm, out);
+  return check_launch("bn_act_fwd");
+}
+
+static void reduce_geometry(int64_t M, int C, bool vec, int* lanes_per_row, int* rows_per_block, int* gx, int* gy) {
+  const int v = vec ? 4 : 1;
+  const int cq = (C + v - 1) / v;             // channel groups per row
+  *lanes_per_row = cq < 256 ? cq : 256;
+  *rows_per_block = 256 / *lanes_per_row;
+  *gx = (cq + *lanes_per_row - 1) / *lanes_per_row;
+  int64_t want = (M + *rows_per_block - 1) / *rows_per_block;   // row groups if one row per thread-row
+  int64_t cap = 1024 / (*gx);
+  if (cap < 1) cap = 1;
+  // at least ~8 rows per thread so the partial buffer stays small
+  int64_t gy64 = (want + 7) / 8;
+  if (gy64 > cap) gy64 = cap;
+  if (gy64 < 1) gy64 = 1;
+  *gy = (int)gy64;
+}
+
+int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       const vp3d_dropout* drop, float* partials, int32_t* nparts) {
+  VP3D_REQUIRE(M > 0 && C > 0 && nparts, "bn_bwd_reduce: bad argument");
+  const bool vec = (C % 4 == 0);
+  int lpr, rpb, gx, gy;
+  reduce_geometry(M, C, vec, &lpr, &rpb, &gx, &gy);
+  *nparts = gy * rpb;
+  if (partials == nullptr) return VP3D_OK;   // size query
+  VP3D_REQUIRE(go && y && scale && shift && mean && invstd, "bn_bwd_reduce: null pointer");
+  VP3D_REQUIRE(!vec || (aligned16(go) && aligned16(y)), "bn_bwd_reduce: go / y must be 16-byte aligned");
+  const DropP d = make_drop(drop);
+  if (vec)
+    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, M, C, go, y, scale,
+                       shift, mean, invstd, d, partials, lpr, rpb);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, M, C, go, y, scale,
+                       shift, mean, invstd, d, partials, lpr, rpb);
+  return check_launch("bn_bwd_reduce");
+}
+
+int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials, int32_t nparts, float* dgamma,
+                         float* dbeta) {
+  VP3D_REQUIRE(C > 0 && nparts > 0 && partials && dgamma && dbeta, "bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, C, partials, nparts,
+                     dgamma, dbeta);
+  return check_launch("bn_bwd_finalize");
+}
+
+int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      const vp3d_dropout* drop, const float* dgamma, const float* dbeta, float* dy) {
+  VP3D_REQUIRE(M > 0 && C > 0 && go && y && scale && shift && mean && invstd && dgamma && dbeta && dy,
+               "bn_bwd_apply: bad argument");
+  const DropP d = make_drop(drop);
+  const bool vec = (C % 4 == 0) && aligned16(go) && aligned16(y) && aligned16(dy);
+  if (vec)
+    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(stream_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, M, C, go,
+                       y, scale, shift, mean, invstd, d, dgamma, dbeta, dy);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(stream_grid(M * C)), dim3(256), 0, (hipStream_t)stream, M, C, go, y,
+                       scale, shift, mean, invstd, d, dgamma, dbeta, dy);
+  return check_launch("bn_bwd_apply");
+}
+
+int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
+                     const float* scale, float* out) {
+  VP3D_REQUIRE(w && out && c_out > 0 && c_in > 0 && taps > 0, "pack_weight: bad argument");
+  hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream, c_out,
+                     c_in, taps, w, scale, out);
+  return check_launch("pack_weight");
+}
+
+int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t splits, int32_t c_out, int32_t c_in,
+                      int32_t taps, float* dw) {
+  VP3D_REQUIRE(partials && dw && splits > 0 && c_out > 0 && c_in > 0 && taps > 0, "wgrad_reduce: bad argument");
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
+                     splits, c_out, c_in, taps, partials, dw);
+  return check_launch("wgrad_reduce");
+}
+
+int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int32_t ld, float* out) {
+  VP3D_REQUIRE(M > 0 && N > 0 && g && out && ld >= N, "colsum: bad argument");
+  hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, (hipStream_t)stream, M, N, g, ld, out);
+  return check_launch("colsum");
+}
+
+int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out) {
+  VP3D_REQUIRE(n > 0 && out, "dropout_mask: bad argument");
+  hipLaunchKernelGGL(k_dropout_mask, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, make_drop(drop), out);
+  return check_launch("dropout_mask");
+}
+
+int vp3d_project_to_2d_fwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
+                           const float* cam, int32_t linear, float* out) {
+  VP3D_REQUIRE(n_cam > 0 && pts_per_cam > 0 && X && cam && out, "project_to_2d_fwd: bad argument");
+  hipLaunchKernelGGL(k_project_fwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
+                     pts_per_cam, X, cam, linear, out);
+  return check_launch("project_to_2d_fwd");
+}
+
+int vp3d_project_to_2d_bwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
+                           const float* cam, const float* gout, int32_t linear, float* dX) {
+  VP3D_REQUIRE(n_cam > 0 && pts_per_cam > 0 && X && cam && gout && dX, "project_to_2d_bwd: bad argument");
+  hipLaunchKernelGGL(k_project_bwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
+                     pts_per_cam, X, cam, gout, linear, dX);
+  return check_launch("project_to_2d_bwd");
+}
+
+}  // extern "C"

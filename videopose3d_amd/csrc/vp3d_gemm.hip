@@ -1,0 +1,469 @@
+// fp32-MFMA implicit-GEMM kernels for the temporal convolutions (gfx950 / CDNA4).
+//
+// One 128x128 output tile per 256-thread workgroup (4 waves, each a 64x64 sub-tile = 2x2 blocks of
+// v_mfma_f32_32x32x2_f32, 64 accumulator VGPRs), K consumed in 32-wide tiles that are DMA'd straight from
+// HBM/L2 into LDS with global_load_lds (16 B per lane, no VGPR round trip) into a 2-stage ring, so the next
+// K-tile streams in underneath the 64 MFMAs (4096 matrix-pipe cycles) of the current one.  Two workgroups are
+// resident per CU (2 x 64 KiB LDS), so one wave's barrier wait is covered by the other workgroup's MFMAs.
+//
+// Operand images in LDS
+//   "KC" (k contiguous: gathered activation rows, forward-packed weight rows): [128 rows][32 k] floats, 128 B
+//        rows, 16-B chunks XOR-swizzled by ((row>>1)&7) so the ds_read_b128 fragment reads are conflict-free.
+//        Because global_load_lds writes LDS lane-linearly, the swizzle is applied to the per-lane SOURCE
+//        address (which chunk of the row a lane fetches) and again on the read.
+//   "MC" (m/n contiguous: operands whose reduction index is the row): [32 k][128 cols] floats, read with
+//        conflict-free ds_read_b32.
+// K-permutation: a lane in wave half h supplies k = 8*kg + 4*h + j at MFMA step j of k-group kg, for BOTH
+// operands, so one ds_read_b128 feeds four MFMAs.  The sum over k is the same set of products.
+//
+// Rows of the A operand are gathered per output row (temporal taps / dilation / stride), out-of-range taps and
+// ragged tiles read a page of zeros, so no im2col buffer exists.
+#include "vp3d_internal.h"
+
+namespace vp3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NTHREADS = 256;
+constexpr int TILE_B = BM * BK * 4;       // 16 KiB per operand tile
+constexpr int STAGE_B = 2 * TILE_B;       // A + B
+constexpr int TAB_OFF = 2 * STAGE_B;      // two stages
+constexpr int SMEM_B = TAB_OFF + 2 * BM * 4;
+
+__device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA core: one 32-deep K tile for this wave's 64x64 sub-tile.
+// ---------------------------------------------------------------------------------------------------------
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
+                                             f32x16 (&acc)[2][2], int wm, int wn, int lane) {
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KC) {
+        const int row = wm * 64 + i * 32 + cl;
+        const int chunk = (kg * 2 + h) ^ ((row >> 1) & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sA + row * 128 + chunk * 16);
+        a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          a[i][j] = *reinterpret_cast<const float*>(sA + (kg * 8 + 4 * h + j) * 512 + (wm * 64 + i * 32 + cl) * 4);
+      }
+      if (B_KC) {
+        const int row = wn * 64 + i * 32 + cl;
+        const int chunk = (kg * 2 + h) ^ ((row >> 1) & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sB + row * 128 + chunk * 16);
+        b[i][0] = v[0]; b[i][1] = v[1]; b[i][2] = v[2]; b[i][3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          b[i][j] = *reinterpret_cast<const float*>(sB + (kg * 8 + 4 * h + j) * 512 + (wn * 64 + i * 32 + cl) * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// ---------------------------------------------------------------------------------------------------------
+template <bool HAS_TAB>
+__device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                         int lane, int M, int N, const int* tab_b, const int* tab_t,
+                                         int slab_index) {
+  const int h = lane >> 5, cl = lane & 31;
+  int n[2];
+  bool nok[2], rok[2];
+  float bias[2];
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    n[jn] = n0 + wn * 64 + jn * 32 + cl;
+    nok[jn] = n[jn] < N;
+    bias[jn] = (e.bias != nullptr && nok[jn]) ? e.bias[n[jn]] : 0.f;
+    const int rc = n[jn] - e.r_col0;
+    rok[jn] = e.R != nullptr && rc >= 0 && rc < e.r_cols;
+  }
+
+  if (e.stat_sum != nullptr) {
+    const int cnt = min(64, M - (m0 + wm * 64));   // wave-uniform number of valid rows in this 64-row slab
+    if (cnt > 0) {
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r = i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            s += (r < cnt) ? acc[i][jn][reg] : 0.f;
+          }
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r = i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const float d = acc[i][jn][reg] - mean;
+            q += (r < cnt) ? d * d : 0.f;
+          }
+        q += __shfl_xor(q, 32);
+        if (h == 0 && nok[jn]) {
+          e.stat_sum[(int64_t)slab_index * N + n[jn]] = s;
+          e.stat_m2[(int64_t)slab_index * N + n[jn]] = q;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const int m = m0 + r;
+      if (m >= M) continue;
+      int b, t;
+      if (HAS_TAB) {
+        b = tab_b[r];
+        t = tab_t[r];
+      } else {
+        b = 0;
+        t = m;
+      }
+      float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
+      const int tr = t * e.r_stride + e.r_off;
+      const bool r_row_ok = (unsigned)tr < (unsigned)e.r_t;
+      const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) {
+        if (!nok[jn]) continue;
+        float v = acc[i][jn][reg] + bias[jn];
+        if (e.relu) v = v < 0.f ? 0.f : v;
+        if (rok[jn] && r_row_ok) v += rrow[n[jn]];
+        crow[n[jn]] = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rows GEMM:  C[m][n] = sum_k A[gather(m,k)] * B     (forward: B_KC = true; dgrad: B_KC = false)
+// FAST: global_load_lds path (c_src % 32 == 0, N % 128 == 0, 16-B aligned rows).  Otherwise a bounds-checked
+// register-staged loader builds the identical LDS image (any shape; used for expand / shrink / odd channels).
+// ---------------------------------------------------------------------------------------------------------
+template <bool B_KC, bool FAST>
+__global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
+  int* tab_b = reinterpret_cast<int*>(smem + TAB_OFF);
+  int* tab_t = tab_b + BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware tile order: workgroup id b runs on XCD b%8; give every XCD whole m-tiles (all their n-tiles
+  // back to back) so the 8 column tiles of one activation row-panel share that XCD's L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int tile_n = q % p.n_tiles;
+  const int tile_m = (q / p.n_tiles) * 8 + xcd;
+  if (tile_m >= p.m_tiles) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  if (tid < BM) {
+    const int m = min(m0 + tid, p.M - 1);
+    const int b = m / p.t_dst;
+    tab_b[tid] = b;
+    tab_t[tid] = m - b * p.t_dst;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+  const int nkt = (p.K + BK - 1) / BK;
+
+  if (FAST) {
+    // per-thread staging assignments: KC tile piece (w,i) = rows (w*4+i)*8 .. +8, lane -> (row, 16-B chunk)
+    int a_t0[4];
+    int64_t a_off[4];
+    int zoff[4];
+    const float* b_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (w * 4 + i) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+      const int b = tab_b[r], t = tab_t[r];
+      a_t0[i] = t * p.t_stride + p.t_off;
+      a_off[i] = ((int64_t)b * p.t_src + a_t0[i]) * p.lda + chunk * 4;
+      zoff[i] = chunk * 4;
+      if (B_KC) {
+        b_ptr[i] = p.B + (int64_t)(n0 + r) * p.ldb + chunk * 4;
+      } else {
+        const int kr = (w * 4 + i) * 2 + (lane >> 5);
+        b_ptr[i] = p.B + (int64_t)kr * p.ldb + n0 + (lane & 31) * 4;
+      }
+    }
+    int tap = 0, c0 = 0;
+    int64_t tap_off = 0;
+
+    auto issue = [&](int stage) {
+      char* sA = smem + stage * STAGE_B;
+      char* sB = sA + TILE_B;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int st = a_t0[i] + tap * p.tap_step;
+        const float* g = ((unsigned)st < (unsigned)p.t_src) ? (p.A + a_off[i] + tap_off + c0) : (p.zeros + zoff[i]);
+        glds16(g, sA + (w * 4 + i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* g;
+        if (B_KC) g = b_ptr[i] + (int64_t)tap * p.c_src + c0;
+        else g = b_ptr[i] + (int64_t)c0 * p.ldb + (int64_t)tap * p.b_tap_stride;
+        glds16(g, sB + (w * 4 + i) * 1024);
+      }
+      c0 += BK;
+      if (c0 >= p.c_src) {
+        c0 = 0;
+        ++tap;
+        tap_off += (int64_t)p.tap_step * p.lda;
+      }
+    };
+
+    issue(0);
+    for (int it = 0; it < nkt; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces of tile `it` have landed
+      __syncthreads();   // ... and everyone's have, and everyone left stage (it+1)&1
+      if (it + 1 < nkt) issue((it + 1) & 1);
+      const char* sA = smem + (it & 1) * STAGE_B;
+      compute_tile<true, B_KC>(sA, sA + TILE_B, acc, wm, wn, lane);
+    }
+  } else {
+    for (int it = 0; it < nkt; ++it) {
+      char* sA = smem + (it & 1) * STAGE_B;
+      char* sB = sA + TILE_B;
+      const int k0 = it * BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // A (KC image)
+        const int r = (w * 4 + i) * 8 + (lane >> 3);
+        const int pchunk = lane & 7;
+        const int chunk = pchunk ^ ((r >> 1) & 7);
+        const int b = tab_b[r], t = tab_t[r];
+        const int t0 = t * p.t_stride + p.t_off;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + chunk * 4 + e;
+          float x = 0.f;
+          if (k < p.K) {
+            const int tp = k / p.c_src;
+            const int c = k - tp * p.c_src;
+            const int st = t0 + tp * p.tap_step;
+            if ((unsigned)st < (unsigned)p.t_src) x = p.A[((int64_t)b * p.t_src + st) * p.lda + c];
+          }
+          v[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(sA + r * 128 + pchunk * 16) = v;
+        // B
+        if (B_KC) {
+          const int nn = n0 + r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = k0 + chunk * 4 + e;
+            v[e] = (nn < p.N && k < p.K) ? p.B[(int64_t)nn * p.ldb + k] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(sB + r * 128 + pchunk * 16) = v;
+        } else {
+          const int kr = (w * 4 + i) * 2 + (lane >> 5);
+          const int k = k0 + kr;
+          const int tp = k / p.c_src;
+          const int co = k - tp * p.c_src;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int nn = n0 + (lane & 31) * 4 + e;
+            v[e] = (k < p.K && nn < p.N) ? p.B[(int64_t)co * p.ldb + (int64_t)tp * p.b_tap_stride + nn] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(sB + kr * 512 + (lane & 31) * 16) = v;
+        }
+      }
+      __syncthreads();
+      compute_tile<true, B_KC>(sA, sB, acc, wm, wn, lane);
+      // the next iteration writes the other stage; two stages + one barrier per tile is race-free because a
+      // wave can only be one tile ahead of the slowest wave (it must pass the barrier above).
+    }
+  }
+
+  epilogue<true>(p.epi, acc, m0, n0, wm, wn, lane, p.M, p.N, tab_b, tab_t, tile_m * 2 + wm);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reduction GEMM (wgrad):  C[i][n] = sum_m G[m][i] * X[gather(m, tap(n))][ci(n)]   both operands "MC".
+// ---------------------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[TAB_OFF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  const int bid = blockIdx.x;
+  const int split = bid % p.splits;
+  const int q = bid / p.splits;
+  const int tile_n = q % p.n_tiles;
+  const int tile_m = q / p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nkt_all = (p.Mred + BK - 1) / BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(nkt_all, kt_begin + p.kt_per_split);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+  const int colchunk = lane & 31;
+  if (FAST) {
+    const int tap = n0 / p.c_x;
+    const int ci0 = n0 - tap * p.c_x;
+    const int tap_t = tap * p.tap_step + p.t_off;
+    const float* gbase = p.G + m0 + colchunk * 4;
+    const float* xbase = p.X + ci0 + colchunk * 4;
+    const float* zsrc = p.zeros + colchunk * 4;
+    int kt = kt_begin;
+
+    auto issue = [&](int stage) {
+      char* sA = smem + stage * STAGE_B;
+      char* sB = sA + TILE_B;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kr = (w * 4 + i) * 2 + (lane >> 5);
+        const int m = kt * BK + kr;
+        const bool mok = m < p.Mred;
+        const int b = m / p.t_dst;
+        const int t = m - b * p.t_dst;
+        const int st = t * p.t_stride + tap_t;
+        const float* ga = mok ? gbase + (int64_t)m * p.ldg : zsrc;
+        const float* gb = (mok && (unsigned)st < (unsigned)p.t_src)
+                              ? xbase + ((int64_t)b * p.t_src + st) * p.ldx : zsrc;
+        glds16(ga, sA + (w * 4 + i) * 1024);
+        glds16(gb, sB + (w * 4 + i) * 1024);
+      }
+      ++kt;
+    };
+
+    if (kt_begin < kt_end) {
+      issue(0);
+      const int n_it = kt_end - kt_begin;
+      for (int it = 0; it < n_it; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < n_it) issue((it + 1) & 1);
+        const char* sA = smem + (it & 1) * STAGE_B;
+        compute_tile<false, false>(sA, sA + TILE_B, acc, wm, wn, lane);
+      }
+    }
+  } else {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      char* sA = smem + ((kt - kt_begin) & 1) * STAGE_B;
+      char* sB = sA + TILE_B;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kr = (w * 4 + i) * 2 + (lane >> 5);
+        const int m = kt * BK + kr;
+        const bool mok = m < p.Mred;
+        const int b = m / p.t_dst;
+        const int t = m - b * p.t_dst;
+        f32x4 va, vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int io = m0 + colchunk * 4 + e;
+          va[e] = (mok && io < p.Mo) ? p.G[(int64_t)m * p.ldg + io] : 0.f;
+          const int nn = n0 + colchunk * 4 + e;
+          float x = 0.f;
+          if (mok && nn < p.N) {
+            const int tp = nn / p.c_x;
+            const int ci = nn - tp * p.c_x;
+            const int st = t * p.t_stride + tp * p.tap_step + p.t_off;
+            if ((unsigned)st < (unsigned)p.t_src) x = p.X[((int64_t)b * p.t_src + st) * p.ldx + ci];
+          }
+          vb[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(sA + kr * 512 + colchunk * 16) = va;
+        *reinterpret_cast<f32x4*>(sB + kr * 512 + colchunk * 16) = vb;
+      }
+      __syncthreads();
+      compute_tile<false, false>(sA, sB, acc, wm, wn, lane);
+    }
+  }
+
+  Epi e;
+  e.C = p.C + (int64_t)split * p.Mo * p.N;
+  e.c_bpitch = 0;
+  e.ldc = p.N;
+  e.bias = nullptr;
+  e.relu = 0;
+  e.R = nullptr;
+  e.r_bpitch = 0;
+  e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
+  e.stat_sum = e.stat_m2 = nullptr;
+  epilogue<false>(e, acc, m0, n0, wm, wn, lane, p.Mo, p.N, nullptr, nullptr, 0);
+}
+
+}  // namespace
+
+int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig) {
+  const int groups = (a.m_tiles + 7) / 8;
+  const dim3 grid(groups * 8 * a.n_tiles), block(NTHREADS);
+  bool fast = (a.c_src % BK == 0) && (a.N % BN == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) &&
+              aligned16(a.B) && aligned16(a.zeros);
+  if (!b_kcontig) fast = fast && (a.b_tap_stride % 4 == 0);
+  if (b_kcontig) {
+    if (fast) hipLaunchKernelGGL((k_rows_gemm<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_rows_gemm<true, false>), grid, block, 0, s, a);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_rows_gemm<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_rows_gemm<false, false>), grid, block, 0, s, a);
+  }
+  return check_launch("rows_gemm");
+}
+
+int launch_red_gemm(hipStream_t s, const RedGemmArgs& a) {
+  const dim3 grid(a.m_tiles * a.n_tiles * a.splits), block(NTHREADS);
+  const bool fast = (a.Mo % BM == 0) && (a.c_x % BN == 0) && (a.ldg % 4 == 0) && (a.ldx % 4 == 0) &&
+                    aligned16(a.G) && aligned16(a.X) && aligned16(a.zeros);
+  if (fast) hipLaunchKernelGGL((k_red_gemm<true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_red_gemm<false>), grid, block, 0, s, a);
+  return check_launch("red_gemm");
+}
+
+}  // namespace vp3d

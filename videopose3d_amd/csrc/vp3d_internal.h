@@ -1,0 +1,68 @@
+// Internal declarations shared by the libvp3d translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vp3d.h"
+
+namespace vp3d {
+
+// thread-local last-error string
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define VP3D_REQUIRE(cond, ...)              \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::vp3d::set_error(__VA_ARGS__);        \
+      return VP3D_E_INVALID;                 \
+    }                                        \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Epilogue as the kernels see it (vp3d_epilogue + output addressing).
+struct Epi {
+  float* C;
+  int64_t c_bpitch;  // floats per sample in C
+  int32_t ldc;       // floats per row in C
+  const float* bias;
+  int32_t relu;
+  const float* R;
+  int64_t r_bpitch;
+  int32_t r_ld, r_t, r_stride, r_off, r_col0, r_cols;
+  float* stat_sum;
+  float* stat_m2;
+};
+
+// GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";
+// dgrad: B n-contiguous "NN").
+struct RowsGemmArgs {
+  const float* A;
+  const float* B;
+  const float* zeros;
+  int32_t M, N, K;
+  int32_t lda, c_src;          // row pitch of A, channels per tap (K = taps*c_src)
+  int32_t ldb, b_tap_stride;   // NT: B[n*ldb + k];  NN: B[(k % c_src)*ldb + (k / c_src)*b_tap_stride + n]
+  int32_t t_dst, t_src, t_stride, tap_step, t_off, taps;
+  int32_t m_tiles, n_tiles;
+  Epi epi;
+};
+
+// wgrad: C[i][n] = sum_m G[m][i] * X[row(m, tap(n))][ci(n)],   n = tap*c_x + ci.
+struct RedGemmArgs {
+  const float* G;
+  const float* X;
+  const float* zeros;
+  float* C;                 // partials [splits][Mo][N]
+  int32_t Mred;             // reduction length (rows)
+  int32_t Mo, N;            // output rows (c_out) and columns (taps*c_x)
+  int32_t ldg, ldx, c_x;
+  int32_t t_dst, t_src, t_stride, tap_step, t_off;
+  int32_t m_tiles, n_tiles, splits, kt_per_split;
+};
+
+int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
+int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
+
+}  // namespace vp3d

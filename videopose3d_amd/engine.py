@@ -1,0 +1,179 @@
+"""Execution of the temporal stack on the HIP kernels: eval forward (BN folded into the GEMM epilogue),
+training forward (GEMM + fused BN-statistics epilogue -> finalize -> BN/ReLU/dropout/residual) and the
+hand-written backward (BN backward -> wgrad / dgrad GEMMs with the residual-gradient scatter fused in the
+dgrad epilogue), exposed to autograd through one ``torch.autograd.Function`` for the whole stack.
+
+Mirrors the wiring of reference common/model.py:126-138 (dilated) / :187-197 (strided):
+    h0 = act(conv(x; expand_conv); expand_bn)
+    for each block:  u = act(conv(h; layers_conv[2i]); layers_bn[2i])
+                     h = res_i(h) + act(conv(u; layers_conv[2i+1]); layers_bn[2i+1])
+    out = conv(h; shrink) + shrink.bias
+with act = dropout(relu(bn(.))).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .plan import StackPlan
+
+
+def _convs(mod) -> List[torch.nn.Conv1d]:
+    return [mod.expand_conv] + list(mod.layers_conv)
+
+
+def _bns(mod) -> List[torch.nn.BatchNorm1d]:
+    return [mod.expand_bn] + list(mod.layers_bn)
+
+
+def param_list(mod) -> List[torch.nn.Parameter]:
+    """Order of the parameter tensors handed to the autograd Function."""
+    ps = []
+    for conv, bn in zip(_convs(mod), _bns(mod)):
+        ps += [conv.weight, bn.weight, bn.bias]
+    ps += [mod.shrink.weight, mod.shrink.bias]
+    return ps
+
+
+# --------------------------------------------------------------------------------------------------------
+# eval: BN folded into packed weights + bias, cached until a parameter / buffer changes
+# --------------------------------------------------------------------------------------------------------
+def _eval_key(mod):
+    key = [mod._stats_epoch]
+    for conv, bn in zip(_convs(mod), _bns(mod)):
+        for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var):
+            key.append((t.data_ptr(), t._version))
+    key.append((mod.shrink.weight.data_ptr(), mod.shrink.weight._version))
+    return tuple(key)
+
+
+def folded_weights(mod):
+    key = _eval_key(mod)
+    cache = mod.__dict__.get("_fold_cache")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    packs = []
+    for conv, bn in zip(_convs(mod), _bns(mod)):
+        scale, shift = ops.bn_fold(bn)
+        packs.append((ops.pack_weight(conv.weight.detach(), scale), shift))
+    mod.__dict__["_fold_cache"] = (key, packs)
+    return packs
+
+
+def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+    plan: StackPlan = mod._plan
+    plan.lengths(x3.shape[1])
+    packs = folded_weights(mod)
+    wt, bias = packs[0]
+    h = ops.conv_fwd(x3, wt, plan.convs[0], bias=bias, relu=True)
+    for i in range(plan.n_blocks):
+        wt, bias = packs[1 + 2 * i]
+        u = ops.conv_fwd(h, wt, plan.convs[1 + 2 * i], bias=bias, relu=True)
+        wt, bias = packs[2 + 2 * i]
+        h = ops.conv_fwd(u, wt, plan.convs[2 + 2 * i], bias=bias, relu=True, residual=(h, plan.res[i]))
+        del u
+    return ops.conv_fwd(h, ops.pack_weight(mod.shrink.weight.detach()), plan.shrink, bias=mod.shrink.bias.detach())
+
+
+# --------------------------------------------------------------------------------------------------------
+# training
+# --------------------------------------------------------------------------------------------------------
+class _Saved:
+    __slots__ = ("x", "y", "coef", "drop", "wt")
+
+    def __init__(self, x, y, coef, drop, wt):
+        self.x, self.y, self.coef, self.drop, self.wt = x, y, coef, drop, wt
+
+
+def forward_train(mod, x3: torch.Tensor, save: bool):
+    """Returns (out3, saved) ; saved is None unless `save`."""
+    plan: StackPlan = mod._plan
+    plan.lengths(x3.shape[1])
+    convs, bns = _convs(mod), _bns(mod)
+    p = float(mod.drop.p)
+    seed, offset = mod._next_dropout_state() if p > 0 else (0, 0)
+    mod._stats_epoch += 1            # running statistics are about to change (written by raw pointer)
+    saved = []
+
+    def layer(idx, h, residual=None):
+        spec = plan.convs[idx]
+        wt = ops.pack_weight(convs[idx].weight.detach())
+        b, t_in, _ = h.shape
+        m_rows = b * spec.t_out(t_in)
+        stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
+        y = ops.conv_fwd(h, wt, spec, stats=stats)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats)
+        drop = ops.make_dropout(p, seed, offset, idx)
+        a = ops.bn_act_fwd(y, coef, drop, residual)
+        if save:
+            saved.append(_Saved(h, y, coef, drop, wt))
+        return a
+
+    h = layer(0, x3)
+    for i in range(plan.n_blocks):
+        u = layer(1 + 2 * i, h)
+        h = layer(2 + 2 * i, u, residual=(h, plan.res[i]))
+    wts = ops.pack_weight(mod.shrink.weight.detach())
+    out = ops.conv_fwd(h, wts, plan.shrink, bias=mod.shrink.bias.detach())
+    if not save:
+        return out, None
+    return out, dict(layers=saved, h_last=h, wts=wts)
+
+
+def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
+    """Gradients in the order of ``param_list`` (+ optional input gradient)."""
+    plan: StackPlan = mod._plan
+    L: List[_Saved] = saved["layers"]
+    h_last = saved["h_last"]
+    b, t_out, _ = h_last.shape
+    gout3 = gout3.contiguous()
+    g2 = gout3.view(b * t_out, -1)
+    d_sb = ops.colsum(g2)
+    d_sw = ops.conv_wgrad(gout3, h_last, plan.shrink)
+    dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
+    grads = [None] * (3 * len(L))
+
+    def act_bwd(idx, go):
+        s = L[idx]
+        dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop)
+        grads[3 * idx + 1] = dgam
+        grads[3 * idx + 2] = dbet
+        grads[3 * idx] = ops.conv_wgrad(dy, s.x, plan.convs[idx])
+        return dy
+
+    for i in reversed(range(plan.n_blocks)):
+        i1, i2 = 1 + 2 * i, 2 + 2 * i
+        dy2 = act_bwd(i2, dh)
+        da1 = ops.conv_dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].x.shape[1])
+        del dy2
+        dy1 = act_bwd(i1, da1)
+        del da1
+        dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].x.shape[1], residual=(dh, plan.res[i]))
+        del dy1
+    dy0 = act_bwd(0, dh)
+    dx = None
+    if need_dx:
+        dx = ops.conv_dgrad(dy0, L[0].wt, plan.convs[0], L[0].x.shape[1])
+    return grads + [d_sw, d_sb], dx
+
+
+class TemporalStackFn(torch.autograd.Function):
+    """Whole-stack training step: forward saves raw conv outputs + BN coefficients; backward is hand-written."""
+
+    @staticmethod
+    def forward(ctx, mod, x3, *params):
+        out, saved = forward_train(mod, x3, save=True)
+        ctx.mod = mod
+        ctx.saved = saved
+        ctx.need_dx = x3.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.saved is None:
+            raise RuntimeError("vp3d: backward called twice on the same graph (activations were freed)")
+        grads, dx = backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
+        ctx.saved = None
+        return (None, dx) + tuple(grads)

@@ -1,0 +1,134 @@
+"""Drop-in replacements for the reference ``common/model.py`` classes, executed on MI355X HIP kernels.
+
+Same constructor signatures, ``forward`` contract, helper methods and -- strictly -- the same ``state_dict``
+keys / shapes / dtypes as reference common/model.py:10-197, so that ``run.py`` (``from common.model import *``,
+run.py:21) works unchanged: ``.cuda()``, ``.train()/.eval()``, ``parameters()`` for Adam,
+``load_state_dict(model_pos_train.state_dict())`` (run.py:426), checkpoints (run.py:600-608).
+
+The ``nn.Conv1d`` / ``nn.BatchNorm1d`` sub-modules exist ONLY as parameter / buffer containers (that is what
+fixes the state_dict names and reproduces the reference's default initialisation, RNG order included).  Their
+``forward`` is never called: all arithmetic runs in libvp3d.so through ``engine``.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import engine
+from ._lib import Vp3dError
+from .plan import make_plan
+
+
+class TemporalModelBase(nn.Module):
+    """Do not instantiate this class (mirrors reference model.py:10-77)."""
+
+    _kind = None
+
+    def __init__(self, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels):
+        super().__init__()
+        for fw in filter_widths:
+            assert fw % 2 != 0, "Only odd filter widths are supported"
+        self.num_joints_in = num_joints_in
+        self.in_features = in_features
+        self.num_joints_out = num_joints_out
+        self.filter_widths = filter_widths
+        # creation order == reference (model.py:28-33) so that seeded default init gives identical weights
+        self.drop = nn.Dropout(dropout)
+        self.relu = nn.ReLU(inplace=True)
+        self.pad = [filter_widths[0] // 2]
+        self.expand_bn = nn.BatchNorm1d(channels, momentum=0.1)
+        self.shrink = nn.Conv1d(channels, num_joints_out * 3, 1)
+        self._stats_epoch = 0
+        self._drop_calls = 0
+        self._drop_seed = None
+
+    # ---- construction helper shared by the two concrete classes -------------------------------------
+    def _build(self, channels, causal, dense, strided):
+        fw = self.filter_widths
+        c_in = self.num_joints_in * self.in_features
+        plan = make_plan("strided" if strided else "dilated", c_in, channels, self.num_joints_out * 3, fw, causal,
+                         dense)
+        self.expand_conv = nn.Conv1d(c_in, channels, fw[0], stride=plan.convs[0].stride, bias=False)
+        layers_conv, layers_bn = [], []
+        for spec in plan.convs[1:]:
+            layers_conv.append(nn.Conv1d(channels, channels, spec.taps, dilation=spec.dil, stride=spec.stride,
+                                         bias=False))
+            layers_bn.append(nn.BatchNorm1d(channels, momentum=0.1))
+        self.pad = list(plan.pad)
+        self.causal_shift = list(plan.causal_shift)
+        self.layers_conv = nn.ModuleList(layers_conv)
+        self.layers_bn = nn.ModuleList(layers_bn)
+        self._plan = plan
+
+    # ---- reference helper API -------------------------------------------------------------------------
+    def set_bn_momentum(self, momentum):
+        self.expand_bn.momentum = momentum
+        for bn in self.layers_bn:
+            bn.momentum = momentum
+
+    def receptive_field(self):
+        """Total receptive field of this model as # of frames."""
+        return self._plan.receptive_field()
+
+    def total_causal_shift(self):
+        """Asymmetric offset for sequence padding (value reproduced as the reference computes it)."""
+        return self._plan.total_causal_shift()
+
+    # ---- dropout stream ---------------------------------------------------------------------------------
+    def _next_dropout_state(self):
+        if self._drop_seed is None:
+            rank = int(os.environ.get("RANK", "0"))
+            self._drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + id(self) % 65521) \
+                & 0xFFFFFFFFFFFFFFFF
+        off = self._drop_calls
+        self._drop_calls += 1
+        return self._drop_seed, off
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, x):
+        assert len(x.shape) == 4
+        assert x.shape[-2] == self.num_joints_in
+        assert x.shape[-1] == self.in_features
+        if not x.is_cuda:
+            raise Vp3dError("videopose3d_amd runs on MI355X HIP kernels only: got a %s tensor. Move the model and "
+                            "the input to the GPU (there is deliberately no CPU fallback)." % x.device)
+        if self.expand_conv.weight.device != x.device:
+            raise Vp3dError("model parameters are on %s but the input is on %s"
+                            % (self.expand_conv.weight.device, x.device))
+        b, t = x.shape[0], x.shape[1]
+        x3 = x.to(torch.float32).contiguous().view(b, t, -1)     # [B,T,J*F] is already channels-last rows
+        with torch.cuda.device(x.device):
+            if self.training:
+                if torch.is_grad_enabled():
+                    out3 = engine.TemporalStackFn.apply(self, x3, *engine.param_list(self))
+                else:
+                    with torch.no_grad():
+                        out3, _ = engine.forward_train(self, x3, save=False)
+            else:
+                if torch.is_grad_enabled() and x.requires_grad:
+                    raise Vp3dError("gradients through the eval-mode (folded BatchNorm) path are not implemented; "
+                                    "call model.train() or wrap evaluation in torch.no_grad() as run.py does")
+                with torch.no_grad():
+                    out3 = engine.forward_eval(self, x3)
+        return out3.view(b, -1, self.num_joints_out, 3)
+
+
+class TemporalModel(TemporalModelBase):
+    """3D pose model with dilated temporal convolutions (all use-cases; reference model.py:79-138)."""
+
+    def __init__(self, num_joints_in, in_features, num_joints_out, filter_widths, causal=False, dropout=0.25,
+                 channels=1024, dense=False):
+        super().__init__(num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels)
+        self._build(channels, causal, dense, strided=False)
+
+
+class TemporalModelOptimized1f(TemporalModelBase):
+    """Single-frame-batching variant with strided convolutions (training, stride 1; reference model.py:140-197).
+    Weights are interchangeable with ``TemporalModel``."""
+
+    def __init__(self, num_joints_in, in_features, num_joints_out, filter_widths, causal=False, dropout=0.25,
+                 channels=1024):
+        super().__init__(num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels)
+        self._build(channels, causal, False, strided=True)

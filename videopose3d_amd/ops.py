@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C ABI (include/vp3d.h).  PyTorch is used only for device memory and the
+current HIP stream; every FLOP of the path is executed by libvp3d.so.
+
+All activation tensors are contiguous fp32 ``[B, T, C]`` (channels-last rows).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Dropout, Epilogue, RowMap, check
+from .plan import ConvSpec, ResSpec, wgrad_splits
+
+_zero_pages = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.Vp3dError("%s: the vp3d HIP path needs a CUDA/HIP tensor, got device %s (there is no CPU fallback)"
+                             % (name, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.Vp3dError("%s: expected float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.Vp3dError("%s: expected a contiguous tensor" % name)
+
+
+def zeros_page(device) -> torch.Tensor:
+    """A 4 KiB page of device zeros: the source for out-of-range taps / ragged tile rows."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    z = _zero_pages.get(key)
+    if z is None:
+        z = torch.zeros(1024, dtype=torch.float32, device=torch.device("cuda", key))
+        _zero_pages[key] = z
+    return z
+
+
+def make_dropout(p: float, seed: int, offset: int, layer: int) -> Optional[Dropout]:
+    if p <= 0.0:
+        return None
+    return Dropout(float(p), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), int(layer))
+
+
+def _epi(bias=None, relu=False, residual=None, stats=None, n_cols=0) -> Optional[Epilogue]:
+    """residual = (tensor[B,T_r,C_r], r_stride, r_off, r_col0)."""
+    if bias is None and not relu and residual is None and stats is None:
+        return None
+    e = Epilogue()
+    e.bias = _p(bias)
+    e.relu = 1 if relu else 0
+    if residual is not None:
+        r, r_stride, r_off, r_col0 = residual
+        _chk(r, "residual")
+        e.residual = r.data_ptr()
+        e.r_bpitch = r.shape[1] * r.shape[2]
+        e.r_ld = r.shape[2]
+        e.r_t = r.shape[1]
+        e.r_stride = r_stride
+        e.r_off = r_off
+        e.r_col0 = r_col0
+        e.r_cols = r.shape[2]
+    if stats is not None:
+        e.stat_sum = stats[0].data_ptr()
+        e.stat_m2 = stats[1].data_ptr()
+    return e
+
+
+def stat_buffers(m_rows: int, c: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    slabs = (m_rows + 63) // 64
+    buf = torch.empty((2, slabs, c), dtype=torch.float32, device=device)
+    return buf[0], buf[1]
+
+
+# --------------------------------------------------------------------------------------------------------
+# convolutions
+# --------------------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Reference Conv1d.weight [C_out, C_in, taps] -> packed [C_out, taps*C_in] (optionally row-scaled)."""
+    _chk(w, "weight")
+    c_out, c_in, taps = w.shape
+    if taps == 1 and scale is None:
+        return w.view(c_out, c_in)
+    out = torch.empty((c_out, taps * c_in), dtype=torch.float32, device=w.device)
+    check(_lib.lib().vp3d_pack_weight(_stream(), w.data_ptr(), c_out, c_in, taps, _p(scale), out.data_ptr()),
+          "vp3d_pack_weight")
+    return out
+
+
+def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, relu=False,
+             residual: Optional[Tuple[torch.Tensor, ResSpec]] = None, stats=None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = conv(x) with the fused epilogue.  x [B,T_in,C_in], wt packed [C_out, taps*C_in]."""
+    _chk(x, "x")
+    _chk(wt, "wt")
+    b, t_in, c_in = x.shape
+    assert c_in == spec.c_in and wt.shape == (spec.c_out, spec.taps * spec.c_in), (x.shape, wt.shape, spec)
+    t_out = spec.t_out(t_in)
+    if out is None:
+        out = torch.empty((b, t_out, spec.c_out), dtype=torch.float32, device=x.device)
+    if spec.dil == 1:
+        # taps are contiguous rows: one "tap" of taps*C_in channels (pure reshape GEMM for the strided convs)
+        rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+        c_src = spec.taps * c_in
+    else:
+        rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, spec.taps)
+        c_src = c_in
+    res = None
+    if residual is not None:
+        r, rs = residual
+        assert r.shape[0] == b and r.shape[2] == spec.c_out
+        assert rs.start + rs.step * (t_out - 1) < r.shape[1], "residual slice out of range"
+        res = (r, rs.step, rs.start, 0)
+    e = _epi(bias, relu, res, stats, spec.c_out)
+    check(_lib.lib().vp3d_tconv_fwd(_stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1],
+                                    spec.c_out, out.data_ptr(), t_out * spec.c_out, spec.c_out,
+                                    C.byref(e) if e is not None else None, zeros_page(x.device).data_ptr()),
+          "vp3d_tconv_fwd")
+    return out
+
+
+def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
+               residual: Optional[Tuple[torch.Tensor, ResSpec]] = None) -> torch.Tensor:
+    """dx [B,T_in,C_in] = conv^T(dy) (+ scatter of the block's residual gradient).  wt is the forward pack."""
+    _chk(dy, "dy")
+    _chk(wt, "wt")
+    b, t_out, c_out = dy.shape
+    assert c_out == spec.c_out and t_out == spec.t_out(t_in)
+    c_in, taps = spec.c_in, spec.taps
+    ldw = wt.shape[1]
+    z = zeros_page(dy.device).data_ptr()
+    if spec.stride == taps and spec.dil == 1 and taps > 1:
+        # windows do not overlap: dx viewed as [B*T_out, taps*C_in] = dy @ Wt   (plain GEMM)
+        covered = taps * t_out
+        dx = (torch.empty if covered == t_in else torch.zeros)((b, t_in, c_in), dtype=torch.float32, device=dy.device)
+        rm = RowMap(b, t_out, t_out, 1, 0, 0, 1)
+        res = None
+        if residual is not None:
+            r, rs = residual                      # dx[b, start + step*t] += r[b, t]   with step == taps
+            assert rs.step == taps and 0 <= rs.start < taps and r.shape == (b, t_out, c_in)
+            res = (r, 1, 0, rs.start * c_in)
+        e = _epi(residual=res, n_cols=taps * c_in)
+        check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0,
+                                          taps * c_in, dx.data_ptr(), t_in * c_in, taps * c_in,
+                                          C.byref(e) if e is not None else None, z), "vp3d_tconv_dgrad")
+        return dx
+    if spec.stride != 1:
+        raise _lib.Vp3dError("conv_dgrad: stride %d with %d taps is not a configuration of the temporal model"
+                             % (spec.stride, taps))
+    # gather form: dx[b,s] = sum_k dy[b, s - k*dil] @ W_k^T
+    dx = torch.empty((b, t_in, c_in), dtype=torch.float32, device=dy.device)
+    rm = RowMap(b, t_in, t_out, 1, -spec.dil, 0, taps)
+    res = None
+    if residual is not None:
+        r, rs = residual                          # dx[b, s] += r[b, s - start]
+        assert rs.step == 1 and r.shape[0] == b and r.shape[2] == c_in
+        res = (r, 1, -rs.start, 0)
+    e = _epi(residual=res, n_cols=c_in)
+    check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in,
+                                      c_in, dx.data_ptr(), t_in * c_in, c_in, C.byref(e) if e is not None else None, z),
+          "vp3d_tconv_dgrad")
+    return dx
+
+
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec) -> torch.Tensor:
+    """dW in the reference layout [C_out, C_in, taps]."""
+    _chk(dy, "dy")
+    _chk(x, "x")
+    b, t_out, c_out = dy.shape
+    _, t_in, c_in = x.shape
+    assert c_out == spec.c_out and c_in == spec.c_in and t_out == spec.t_out(t_in)
+    taps = spec.taps
+    if spec.dil == 1:
+        rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+        c_x = taps * c_in
+    else:
+        rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, taps)
+        c_x = c_in
+    n_cols = taps * c_in
+    m_rows = b * t_out
+    splits = wgrad_splits(m_rows, c_out, n_cols)
+    dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
+    direct = splits == 1 and taps == 1
+    part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().vp3d_tconv_wgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), c_in, c_x,
+                                      part.data_ptr(), splits, zeros_page(dy.device).data_ptr()), "vp3d_tconv_wgrad")
+    if not direct:
+        check(_lib.lib().vp3d_wgrad_reduce(_stream(), part.data_ptr(), splits, c_out, c_in, taps, dw.data_ptr()),
+              "vp3d_wgrad_reduce")
+    return dw
+
+
+def colsum(g2d: torch.Tensor) -> torch.Tensor:
+    _chk(g2d, "g")
+    m, n = g2d.shape
+    out = torch.empty((n,), dtype=torch.float32, device=g2d.device)
+    check(_lib.lib().vp3d_colsum(_stream(), m, n, g2d.data_ptr(), n, out.data_ptr()), "vp3d_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------
+# batch norm / activation
+# --------------------------------------------------------------------------------------------------------
+def bn_fold(bn: torch.nn.BatchNorm1d) -> Tuple[torch.Tensor, torch.Tensor]:
+    c = bn.num_features
+    buf = torch.empty((2, c), dtype=torch.float32, device=bn.weight.device)
+    check(_lib.lib().vp3d_bn_fold(_stream(), c, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                  bn.running_var.data_ptr(), float(bn.eps), buf[0].data_ptr(), buf[1].data_ptr()),
+          "vp3d_bn_fold")
+    return buf[0], buf[1]
+
+
+def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats) -> torch.Tensor:
+    """Returns a [4, C] tensor: scale, shift, mean, invstd.  Updates the running buffers in place."""
+    c = bn.num_features
+    if m_rows <= 1:
+        # same failure as torch.nn.functional.batch_norm in training mode
+        raise ValueError("Expected more than 1 value per channel when training, got input size [%d, %d]" % (m_rows, c))
+    buf = torch.empty((4, c), dtype=torch.float32, device=bn.weight.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is None and track:
+        momentum = 1.0 / float(int(bn.num_batches_tracked.item()) + 1)   # cumulative average (not used by run.py)
+    check(_lib.lib().vp3d_bn_finalize(
+        _stream(), c, m_rows, stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+        float(bn.eps), momentum, bn.running_mean.data_ptr() if track else None,
+        bn.running_var.data_ptr() if track else None,
+        bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
+        buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()), "vp3d_bn_finalize")
+    return buf
+
+
+def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
+               residual: Optional[Tuple[torch.Tensor, ResSpec]] = None) -> torch.Tensor:
+    _chk(y, "y")
+    b, t, c = y.shape
+    out = torch.empty_like(y)
+    if residual is not None:
+        r, rs = residual
+        _chk(r, "residual")
+        assert r.shape[0] == b and r.shape[2] == c and rs.start + rs.step * (t - 1) < r.shape[1]
+        args = (r.data_ptr(), t, r.shape[1], rs.step, rs.start, c)
+    else:
+        args = (None, t, 0, 0, 0, c)
+    check(_lib.lib().vp3d_bn_act_fwd(_stream(), b * t, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                     C.byref(drop) if drop is not None else None, *args, out.data_ptr()),
+          "vp3d_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout]):
+    """Returns (dy, dgamma, dbeta) for a = dropout(relu(bn(y)))."""
+    _chk(go, "go")
+    _chk(y, "y")
+    b, t, c = y.shape
+    assert go.shape == y.shape
+    m = b * t
+    L = _lib.lib()
+    dref = C.byref(drop) if drop is not None else None
+    nparts = C.c_int32(0)
+    check(L.vp3d_bn_bwd_reduce(_stream(), m, c, None, None, None, None, None, None, None, None, C.byref(nparts)),
+          "vp3d_bn_bwd_reduce(query)")
+    parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
+    sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
+    check(L.vp3d_bn_bwd_reduce(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
+                               C.byref(nparts)), "vp3d_bn_bwd_reduce")
+    dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+    check(L.vp3d_bn_bwd_finalize(_stream(), c, parts.data_ptr(), nparts.value, dgb[0].data_ptr(), dgb[1].data_ptr()),
+          "vp3d_bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgb[0].data_ptr(),
+                              dgb[1].data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
+    return dy, dgb[0], dgb[1]
+
+
+def dropout_mask(n: int, drop: Optional[Dropout], device) -> torch.Tensor:
+    out = torch.empty((n,), dtype=torch.float32, device=device)
+    check(_lib.lib().vp3d_dropout_mask(_stream(), n, C.byref(drop) if drop is not None else None, out.data_ptr()),
+          "vp3d_dropout_mask")
+    return out
