@@ -16,6 +16,33 @@ from .plan import ConvSpec, ResSpec, wgrad_splits
 
 _zero_pages = {}
 
+# Optional per-launch instrumentation used by bench.py (roofline): when a list is installed, every GEMM entry
+# point is bracketed with HIP events on the launch stream and (family, algorithmic FLOPs, start, end) is appended.
+_prof = None
+
+
+def set_profiler(records):
+    global _prof
+    _prof = records
+
+
+class _Timed:
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.family, self.flops, self.e0, self.e1))
+        return False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -121,7 +148,8 @@ def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, re
         assert rs.start + rs.step * (t_out - 1) < r.shape[1], "residual slice out of range"
         res = (r, rs.step, rs.start, 0)
     e = _epi(bias, relu, res, stats, spec.c_out)
-    check(_lib.lib().vp3d_tconv_fwd(_stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1],
+    with _Timed("tconv_fwd", 2.0 * b * t_out * spec.c_out * spec.taps * c_in):
+      check(_lib.lib().vp3d_tconv_fwd(_stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1],
                                     spec.c_out, out.data_ptr(), t_out * spec.c_out, spec.c_out,
                                     C.byref(e) if e is not None else None, zeros_page(x.device).data_ptr()),
           "vp3d_tconv_fwd")
@@ -149,7 +177,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
             assert rs.step == taps and 0 <= rs.start < taps and r.shape == (b, t_out, c_in)
             res = (r, 1, 0, rs.start * c_in)
         e = _epi(residual=res, n_cols=taps * c_in)
-        check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0,
+        with _Timed("tconv_dgrad", 2.0 * b * t_out * c_out * taps * c_in):
+          check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0,
                                           taps * c_in, dx.data_ptr(), t_in * c_in, taps * c_in,
                                           C.byref(e) if e is not None else None, z), "vp3d_tconv_dgrad")
         return dx
@@ -165,7 +194,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
         assert rs.step == 1 and r.shape[0] == b and r.shape[2] == c_in
         res = (r, 1, -rs.start, 0)
     e = _epi(residual=res, n_cols=c_in)
-    check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in,
+    with _Timed("tconv_dgrad", 2.0 * b * t_out * c_out * taps * c_in):
+      check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in,
                                       c_in, dx.data_ptr(), t_in * c_in, c_in, C.byref(e) if e is not None else None, z),
           "vp3d_tconv_dgrad")
     return dx
@@ -191,7 +221,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec) -> torch.Tenso
     dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
     direct = splits == 1 and taps == 1
     part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)
-    check(_lib.lib().vp3d_tconv_wgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), c_in, c_x,
+    with _Timed("tconv_wgrad", 2.0 * m_rows * c_out * n_cols):
+      check(_lib.lib().vp3d_tconv_wgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), c_in, c_x,
                                       part.data_ptr(), splits, zeros_page(dy.device).data_ptr()), "vp3d_tconv_wgrad")
     if not direct:
         check(_lib.lib().vp3d_wgrad_reduce(_stream(), part.data_ptr(), splits, c_out, c_in, taps, dw.data_ptr()),
