@@ -98,22 +98,27 @@ const char* vp3d_last_error(void);
 
 /* number of 64-row statistic slabs a [M, *] output produces (size stat_sum / stat_m2 as slabs*N floats) */
 int64_t vp3d_stat_slabs(int64_t M);
+/* split-K factor vp3d_tconv_fwd / _dgrad would use for an [M,N,K] problem when given a workspace (1 = none):
+ * small-M layers (the T_out = 1..3 tail) are K-sliced to fill the 256 CUs; size the workspace as splits*M*N floats */
+int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K);
 
 /* y[b,t,:] = sum_k x[b, map(t,k), :] @ W_k  (+ epilogue).   M = B*t_dst, N = c_out, K = taps*c_in.
  *   x  : gathered activations, row pitch ldx floats, c_in channels used per tap
  *   wt : packed weights  wt[n*ldw + k*c_in + ci] == W[n][ci][k]   (vp3d_pack_weight, mode 0)
  *   y  : output rows at y[b*y_bpitch + t*ldy + n]
- *   zeros: >= 1024 B of device zeros (source for out-of-range taps / ragged tiles) */
+ *   zeros: >= 1024 B of device zeros (source for out-of-range taps / ragged tiles)
+ *   splitk_ws: optional workspace (NULL = never split K), see vp3d_rows_gemm_splits */
 int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
                    const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
-                   const vp3d_epilogue* epi, const float* zeros);
+                   const vp3d_epilogue* epi, const float* zeros, float* splitk_ws, int64_t splitk_ws_floats);
 
 /* dx[b,s,:] = sum_k dy[b, map(s,k), :] @ W_k^T (+ epilogue: the residual-gradient scatter).
  *   M = B*t_dst rows of dx, N = n_out columns, K = taps*c_out.
  *   wt: the SAME forward-packed weights; column n of tap k is read at wt[co*ldw + k*w_tap_stride + n]. */
 int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
                      const float* wt, int32_t ldw, int32_t w_tap_stride, int32_t n_out, float* dx,
-                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros);
+                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros, float* splitk_ws,
+                     int64_t splitk_ws_floats);
 
 /* dWt[co][k*c_in + ci] = sum_m dy[m][co] * x[map(m,k)][ci].   Reduction over M = B*t_dst rows, split in
  * `splits` slices whose partial [c_out, taps*c_in] matrices go to `partials` (splits*c_out*taps*c_in floats);
@@ -121,13 +126,25 @@ int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* 
 int vp3d_tconv_wgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
                      const float* x, int32_t ldx, int32_t c_in, float* partials, int32_t splits,
                      const float* zeros);
-/* dW[co][ci][k] (reference Conv1d.weight layout) = sum_s partials[s][co][k*c_in + ci] */
-int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t splits, int32_t c_out, int32_t c_in,
-                      int32_t taps, float* dw);
+/* dW[co][ci][k] (reference Conv1d.weight layout) = sum_s partials[s][co*ld_part + k*c_in + ci]
+ * (partial matrices are c_out*ld_part floats apart; ld_part >= taps*c_in) */
+int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t ld_part, int32_t splits, int32_t c_out,
+                      int32_t c_in, int32_t taps, float* dw);
 
-/* mode 0: out[co][k*c_in + ci] = w[co][ci][k] * (scale ? scale[co] : 1)      (reference layout -> packed) */
+/* out[co*ld_out + k*c_in + ci] = w[co][ci][k] * (scale ? scale[co] : 1)   (reference layout -> packed rows);
+ * columns [taps*c_in, ld_out) are zero-filled (K padding for the expand conv) */
 int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
-                     const float* scale, float* out);
+                     const float* scale, float* out, int32_t ld_out);
+
+/* Row staging for convs whose taps*C_in is not a multiple of 32 (expand_conv: 3*34 = 102): row m = (b,t) of `out`
+ * receives the k_valid contiguous floats at x[(b*t_src + t*t_stride)*ldx] followed by zeros up to kpad, so that the
+ * conv becomes a 1-tap GEMM over 16-byte-aligned kpad-wide rows (dil == 1 only: taps are adjacent rows). */
+int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid,
+                int32_t kpad, float* out);
+
+/* out[m][n] = bias[n] + sum_k x[m][k]*w[n][k] for a skinny N (the shrink conv, model.py:33,137,196; N = 3*J_out) */
+int vp3d_skinny_fwd(vp3d_stream_t stream, int64_t M, int32_t N, int32_t K, const float* x, const float* w,
+                    const float* bias, float* out);
 /* eval-mode BN folding: scale[c] = gamma/sqrt(running_var+eps), shift[c] = beta - running_mean*scale */
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift);

@@ -165,12 +165,14 @@ def bn_eval(y, gamma, beta, running_mean, running_var, eps=BN_EPS):
     return y * s + (beta - running_mean * s)
 
 
-def bn_act_bwd(go, z, xhat, gamma, invstd, mk):
+def bn_act_bwd(go, z, xhat, gamma, invstd, mk, pos=None):
     """Backward of a = dropout(relu(bn(y))).  go = dL/da, mk = keep-mask*scale (or None).
 
     g = go*mk*[z>0]; dbeta = sum g; dgamma = sum g*xhat;
-    dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)."""
-    g = go * (z > 0)
+    dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
+    pos (optional bool array) pins the ReLU decisions [z>0]: two fp32 implementations legitimately disagree on
+    the sign of |z| ~ 1e-7 elements, and one such flip moves a gradient entry by a whole term."""
+    g = go * ((z > 0) if pos is None else pos)
     if mk is not None:
         g = g * mk
     m = g.shape[0] * g.shape[1]
@@ -270,8 +272,9 @@ def forward(params, x, filter_widths, *, causal=False, kind="dilated", dense=Fal
     return out.reshape(b, -1, j_out3 // 3, 3), cache, new_running
 
 
-def backward(cache, gout):
-    """Gradients of all parameters given gout = dL/d(out) [B,T_out,J_out,3] (training-mode cache)."""
+def backward(cache, gout, trace=None, relu_pos=None):
+    """Gradients of all parameters given gout = dL/d(out) [B,T_out,J_out,3] (training-mode cache).
+    If `trace` is a dict it receives the intermediate activation gradients (dy per BN layer, dh per block)."""
     plan, p = cache["plan"], cache["p"]
     grads = {}
     h_last = cache["h_last"]
@@ -284,9 +287,13 @@ def backward(cache, gout):
     def act_bwd(go, idx):
         L = cache["layers"][idx]
         pre = _bn_prefix(idx)
-        dy, dgam, dbet = bn_act_bwd(go, L["z"], L["xhat"], p[pre + ".weight"], L["invstd"], L["mk"])
+        dy, dgam, dbet = bn_act_bwd(go, L["z"], L["xhat"], p[pre + ".weight"], L["invstd"], L["mk"],
+                                    None if relu_pos is None else relu_pos[idx])
         grads[pre + ".weight"] = dgam
         grads[pre + ".bias"] = dbet
+        if trace is not None:
+            trace["go%d" % idx] = go
+            trace["dy%d" % idx] = dy
         return dy, L["x"]
 
     for i in reversed(range(len(plan["res"]))):

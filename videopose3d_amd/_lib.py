@@ -40,12 +40,16 @@ SIGNATURES = {
     "vp3d_version": (C.c_int, []),
     "vp3d_last_error": (C.c_char_p, []),
     "vp3d_stat_slabs": (_i64, [_i64]),
-    "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp]),
+    "vp3d_rows_gemm_splits": (C.c_int, [_i64, _i32, _i32]),
+    "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
+                                 _vp, _i64]),
     "vp3d_tconv_dgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32,
-                                   _P(Epilogue), _vp]),
+                                   _P(Epilogue), _vp, _vp, _i64]),
     "vp3d_tconv_wgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
-    "vp3d_wgrad_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "vp3d_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "vp3d_wgrad_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vp3d_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32]),
+    "vp3d_im2row": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _vp]),
+    "vp3d_skinny_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vp3d_bn_fold": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vp3d_bn_finalize": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_bn_act_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

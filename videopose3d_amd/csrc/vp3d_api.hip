@@ -56,6 +56,19 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   return VP3D_OK;
 }
 
+// split-K only when the caller handed a workspace big enough for splits*M*N partial floats
+static void set_splits(RowsGemmArgs* a, float* ws, int64_t ws_floats) {
+  a->splits = 1;
+  a->kt_per_split = 0;
+  a->part = nullptr;
+  if (ws == nullptr) return;
+  const int s = rows_gemm_splits(a->M, a->N, a->K);
+  if (s > 1 && ws_floats >= (int64_t)s * a->M * a->N && aligned16(ws)) {
+    a->splits = s;
+    a->part = ws;
+  }
+}
+
 static int check_map(const vp3d_rowmap* m, const char* who) {
   VP3D_REQUIRE(m != nullptr, "%s: null rowmap", who);
   VP3D_REQUIRE(m->batch > 0 && m->t_dst > 0 && m->t_src > 0 && m->taps > 0, "%s: bad rowmap (B=%d t_dst=%d t_src=%d taps=%d)",
@@ -74,10 +87,14 @@ extern "C" {
 int vp3d_version(void) { return VP3D_VERSION; }
 const char* vp3d_last_error(void) { return g_err; }
 int64_t vp3d_stat_slabs(int64_t M) { return (M + 63) / 64; }
+int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || M >= ((int64_t)1 << 31) || N <= 0 || K <= 0) return 1;
+  return rows_gemm_splits((int)M, N, K);
+}
 
 int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
                    const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
-                   const vp3d_epilogue* epi, const float* zeros) {
+                   const vp3d_epilogue* epi, const float* zeros, float* splitk_ws, int64_t splitk_ws_floats) {
   int rc = check_map(map, "tconv_fwd");
   if (rc) return rc;
   VP3D_REQUIRE(x && wt && y && zeros, "tconv_fwd: null pointer");
@@ -104,12 +121,14 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
   a.n_tiles = (a.N + 127) / 128;
   rc = fill_epi(&a.epi, epi, y, y_bpitch, ldy, c_out);
   if (rc) return rc;
+  set_splits(&a, splitk_ws, splitk_ws_floats);
   return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/true);
 }
 
 int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
                      const float* wt, int32_t ldw, int32_t w_tap_stride, int32_t n_out, float* dx,
-                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros) {
+                     int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros, float* splitk_ws,
+                     int64_t splitk_ws_floats) {
   int rc = check_map(map, "tconv_dgrad");
   if (rc) return rc;
   VP3D_REQUIRE(dy && wt && dx && zeros, "tconv_dgrad: null pointer");
@@ -136,6 +155,7 @@ int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* 
   a.n_tiles = (a.N + 127) / 128;
   rc = fill_epi(&a.epi, epi, dx, dx_bpitch, lddx, n_out);
   if (rc) return rc;
+  set_splits(&a, splitk_ws, splitk_ws_floats);
   return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/false);
 }
 

@@ -52,12 +52,13 @@ __global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab
                                                      float* running_mean, float* running_var, int64_t* nbt,
                                                      float* scale, float* shift, float* save_mean,
                                                      float* save_invstd) {
-  __shared__ double s1[4][64], s2[4][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  // 32 channels x 8 slab groups per block: C/32 blocks share the (slabs x C) partial arrays
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int s = g; s < nslab; s += 4) {
+    for (int s = g; s < nslab; s += 8) {
       const int64_t left = M - (int64_t)s * 64;
       const double cnt = (double)(left < 64 ? left : 64);
       const double sum = (double)psum[(int64_t)s * C + c];
@@ -69,8 +70,12 @@ __global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab
   s2[g][cl] = a2;
   __syncthreads();
   if (g == 0 && c < C) {
-    const double S1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
-    const double S2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      S1 += s1[i][cl];
+      S2 += s2[i][cl];
+    }
     const double mean = S1 / (double)M;
     double var = (S2 - S1 * mean) / (double)M;
     if (var < 0.0) var = 0.0;
@@ -107,28 +112,38 @@ struct ResMap {
   int t_dst, r_t, r_stride, r_off, r_ld;
 };
 
+// Thread layout of the streaming BN kernels ("column-owned"): a thread owns VEC consecutive channels (its
+// per-channel coefficients stay in registers) and walks rows m = blockIdx.y*rows_per_block + rsub, += gridDim.y *
+// rows_per_block; a wave covers 64*VEC consecutive channels of one row (1 KiB, coalesced).  No divisions per element.
 template <int VEC>
-__global__ void __launch_bounds__(256) k_bn_act_fwd(int64_t M, int C, const float* __restrict__ y,
+__global__ void __launch_bounds__(256) k_bn_act_fwd(int M, int C, const float* __restrict__ y,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    DropP d, ResMap rm, float* __restrict__ out) {
-  const int64_t total = M * C;
-  const int64_t nq = (total + VEC - 1) / VEC;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e0 = q * VEC;
-    const int64_t m = e0 / C;
-    const int c = (int)(e0 - m * C);
+                                                    DropP d, ResMap rm, float* __restrict__ out, int lanes_per_row,
+                                                    int rows_per_block) {
+  const int lr = threadIdx.x % lanes_per_row;
+  const int rsub = threadIdx.x / lanes_per_row;
+  const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
+  if (rsub >= rows_per_block || c >= C) return;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc[e] = scale[c + e];
+    sh[e] = shift[c + e];
+  }
+  const int row_step = gridDim.y * rows_per_block;
+#pragma unroll 2
+  for (int m = blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+    const int64_t e0 = (int64_t)m * C + c;
     const float* rrow = nullptr;
     if (rm.res != nullptr) {
-      const int64_t b = m / rm.t_dst;
-      const int t = (int)(m - b * rm.t_dst);
-      rrow = rm.res + (b * rm.r_t + (int64_t)t * rm.r_stride + rm.r_off) * rm.r_ld + c;
+      const int b = m / rm.t_dst;
+      const int t = m - b * rm.t_dst;
+      rrow = rm.res + ((int64_t)b * rm.r_t + (int64_t)t * rm.r_stride + rm.r_off) * rm.r_ld + c;
     }
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (d.on) drop4(d, (uint64_t)(e0 >> 2), mk);
     if (VEC == 4) {
-      float mk[4] = {1.f, 1.f, 1.f, 1.f};
-      if (d.on) drop4(d, (uint64_t)q, mk);
       const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
       f32x4 rv = {0.f, 0.f, 0.f, 0.f};
       if (rrow != nullptr) rv = *reinterpret_cast<const f32x4*>(rrow);
       f32x4 o;
@@ -139,14 +154,8 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd(int64_t M, int C, const floa
       }
       *reinterpret_cast<f32x4*>(out + e0) = o;
     } else {
-      float mkv = 1.f;
-      if (d.on) {
-        float mk[4];
-        drop4(d, (uint64_t)(e0 >> 2), mk);
-        mkv = mk[e0 & 3];
-      }
-      const float z = fmaf(y[e0], scale[c], shift[c]);
-      out[e0] = (rrow != nullptr ? rrow[0] : 0.f) + (z > 0.f ? z * mkv : (z != z ? z : 0.f));
+      const float z = fmaf(y[e0], sc[0], sh[0]);
+      out[e0] = (rrow != nullptr ? rrow[0] : 0.f) + (z > 0.f ? z * mk[e0 & 3] : (z != z ? z : 0.f));
     }
   }
 }
@@ -157,7 +166,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd(int64_t M, int C, const floa
 // Launch: grid.x = channel strips of 256*VEC, grid.y = row groups; part = blockIdx.y * rows_per_block + rsub.
 // ---------------------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ void __launch_bounds__(256) k_bn_bwd_reduce(int64_t M, int C, const float* __restrict__ go,
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(int M, int C, const float* __restrict__ go,
                                                        const float* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, DropP d,
@@ -173,9 +182,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(int64_t M, int C, const f
     sg[e] = sgx[e] = 0.f;
     sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
   }
-  const int64_t row_step = (int64_t)gridDim.y * rows_per_block;
-  for (int64_t m = (int64_t)blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
-    const int64_t e0 = m * C + c;
+  const int row_step = gridDim.y * rows_per_block;
+#pragma unroll 2
+  for (int m = blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+    const int64_t e0 = (int64_t)m * C + c;
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (VEC == 4) {
       if (d.on) drop4(d, (uint64_t)(e0 >> 2), mk);
@@ -211,12 +221,12 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(int64_t M, int C, const f
 
 __global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __restrict__ partials, int nparts,
                                                          float* dgamma, float* dbeta) {
-  __shared__ double s1[4][64], s2[4][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C)
-    for (int p = g; p < nparts; p += 4) {
+    for (int p = g; p < nparts; p += 8) {
       a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
       a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
     }
@@ -224,24 +234,40 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __r
   s2[g][cl] = a2;
   __syncthreads();
   if (g == 0 && c < C) {
-    dbeta[c] = (float)(s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
-    dgamma[c] = (float)(s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]);
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      S1 += s1[i][cl];
+      S2 += s2[i][cl];
+    }
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
   }
 }
 
 template <int VEC>
-__global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t M, int C, const float* __restrict__ go,
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(int M, int C, const float* __restrict__ go,
                                                       const float* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, DropP d,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                      float* __restrict__ dy) {
-  const int64_t total = M * C;
-  const int64_t nq = (total + VEC - 1) / VEC;
+                                                      float* __restrict__ dy, int lanes_per_row, int rows_per_block) {
+  const int lr = threadIdx.x % lanes_per_row;
+  const int rsub = threadIdx.x / lanes_per_row;
+  const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
+  if (rsub >= rows_per_block || c >= C) return;
   const float inv_m = 1.0f / (float)M;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e0 = q * VEC;
-    const int c = (int)(e0 % C);
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], kb[VEC], kg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
+    kb[e] = dbeta[c + e] * inv_m;
+    kg[e] = dgamma[c + e] * inv_m;
+  }
+  const int row_step = gridDim.y * rows_per_block;
+#pragma unroll 2
+  for (int m = blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+    const int64_t e0 = (int64_t)m * C + c;
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (d.on) drop4(d, (uint64_t)(e0 >> 2), mk);
     if (VEC == 4) {
@@ -250,20 +276,18 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t M, int C, const fl
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float sc = scale[c + e];
-        const float z = fmaf(yv[e], sc, shift[c + e]);
+        const float z = fmaf(yv[e], sc[e], sh[e]);
         const float g = z > 0.f ? gv[e] * mk[e] : 0.f;
-        const float xh = (yv[e] - mean[c + e]) * invstd[c + e];
-        o[e] = sc * (g - dbeta[c + e] * inv_m - xh * (dgamma[c + e] * inv_m));
+        const float xh = (yv[e] - mu[e]) * is[e];
+        o[e] = sc[e] * (g - kb[e] - xh * kg[e]);
       }
       *reinterpret_cast<f32x4*>(dy + e0) = o;
     } else {
-      const float sc = scale[c];
       const float yv = y[e0];
-      const float z = fmaf(yv, sc, shift[c]);
+      const float z = fmaf(yv, sc[0], sh[0]);
       const float g = z > 0.f ? go[e0] * mk[e0 & 3] : 0.f;
-      const float xh = (yv - mean[c]) * invstd[c];
-      dy[e0] = sc * (g - dbeta[c] * inv_m - xh * (dgamma[c] * inv_m));
+      const float xh = (yv - mu[0]) * is[0];
+      dy[e0] = sc[0] * (g - kb[0] - xh * kg[0]);
     }
   }
 }
@@ -271,30 +295,34 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t M, int C, const fl
 // ---------------------------------------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------------------------------------
-// out[co][k*c_in + ci] = w[co][ci][k] * scale[co]
+// out[co*ld_out + k*c_in + ci] = w[co][ci][k] * scale[co];  columns [taps*c_in, ld_out) are zero-filled
 __global__ void __launch_bounds__(256) k_pack_weight(int c_out, int c_in, int taps, const float* __restrict__ w,
-                                                     const float* __restrict__ scale, float* __restrict__ out) {
+                                                     const float* __restrict__ scale, float* __restrict__ out,
+                                                     int ld_out) {
   const int64_t total = (int64_t)c_out * c_in;
+  const int pad = ld_out - taps * c_in;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t co = i / c_in;
     const int ci = (int)(i - co * c_in);
     const float s = scale != nullptr ? scale[co] : 1.f;
     const float* src = w + i * taps;
-    float* dst = out + co * (int64_t)taps * c_in + ci;
+    float* dst = out + co * (int64_t)ld_out + ci;
     for (int k = 0; k < taps; ++k) dst[(int64_t)k * c_in] = src[k] * s;
+    for (int z = ci; z < pad; z += c_in) out[co * (int64_t)ld_out + taps * c_in + z] = 0.f;
   }
 }
 
-// dw[co][ci][k] = sum_s partials[s][co][k*c_in + ci]
+// dw[co][ci][k] = sum_s partials[s][co*ld_part + k*c_in + ci]
 __global__ void __launch_bounds__(256) k_wgrad_reduce(int splits, int c_out, int c_in, int taps,
-                                                      const float* __restrict__ partials, float* __restrict__ dw) {
+                                                      const float* __restrict__ partials, int ld_part,
+                                                      float* __restrict__ dw) {
   const int64_t total = (int64_t)c_out * c_in;
-  const int64_t mat = (int64_t)c_out * taps * c_in;
+  const int64_t mat = (int64_t)c_out * ld_part;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t co = i / c_in;
     const int ci = (int)(i - co * c_in);
     for (int k = 0; k < taps; ++k) {
-      const float* src = partials + co * (int64_t)taps * c_in + (int64_t)k * c_in + ci;
+      const float* src = partials + co * (int64_t)ld_part + (int64_t)k * c_in + ci;
       float acc = 0.f;
       for (int s = 0; s < splits; ++s) acc += src[(int64_t)s * mat];
       dw[i * taps + k] = acc;
@@ -315,6 +343,62 @@ __global__ void __launch_bounds__(256) k_colsum(int64_t M, int N, const float* _
     __syncthreads();
   }
   if (threadIdx.x == 0) out[n] = red[0];
+}
+
+// out[m][0..kpad) = the k_valid contiguous floats starting at x[(b*t_src + t*t_stride)*ldx], zero padded.
+// (expand conv: taps*C_in = 102 contiguous floats per output row -> 128-wide rows the fast GEMM path can DMA)
+__global__ void __launch_bounds__(256) k_im2row(int M, int t_dst, int t_src, int t_stride, int ldx, int k_valid,
+                                                int kpad, const float* __restrict__ x, float* __restrict__ out) {
+  const int qpr = kpad >> 2;                          // float4 per output row
+  const int64_t total = (int64_t)M * qpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / qpr);
+    const int k0 = (int)(i - (int64_t)m * qpr) * 4;
+    const int b = m / t_dst;
+    const int t = m - b * t_dst;
+    const float* src = x + ((int64_t)b * t_src + (int64_t)t * t_stride) * ldx;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k0 + e < k_valid) ? src[k0 + e] : 0.f;
+    *reinterpret_cast<f32x4*>(out + (int64_t)m * kpad + k0) = v;
+  }
+}
+
+// Skinny GEMM for the shrink conv: out[m][n] = bias[n] + sum_k x[m][k]*w[n][k], N <= 64-ish, K % 256 == 0.
+// One wave computes 4 rows: lanes split K (coalesced float4), per output a 64-lane shuffle reduction.
+__global__ void __launch_bounds__(256) k_skinny_fwd(int M, int N, int K, const float* __restrict__ x,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int m0 = wave * 4;
+  if (m0 >= M) return;
+  const int nrow = min(4, M - m0);
+  for (int n = 0; n < N; ++n) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)n * K + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r < nrow) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)(m0 + r) * K + k);
+          acc[r] = fmaf(xv[0], wv[0], acc[r]);
+          acc[r] = fmaf(xv[1], wv[1], acc[r]);
+          acc[r] = fmaf(xv[2], wv[2], acc[r]);
+          acc[r] = fmaf(xv[3], wv[3], acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
+    }
+    if (lane < nrow) {
+      const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      out[(int64_t)(m0 + lane) * N + n] = v + (bias != nullptr ? bias[n] : 0.f);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_dropout_mask(int64_t n, DropP d, float* out) {
@@ -412,7 +496,7 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd,
                "bn_finalize: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
                      stat_m2, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                      save_mean, save_invstd);
   return check_launch("bn_finalize");
@@ -426,6 +510,24 @@ int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const floa
   return check_launch("bn_fold");
 }
 
+// Launch geometry of the column-owned streaming kernels: lanes_per_row threads cover a row strip of
+// lanes_per_row*VEC channels, rows_per_block rows per block pass; grid.y row groups up to ~max_blocks blocks.
+static void col_geometry(int64_t M, int C, bool vec, int64_t max_blocks, int min_rows_per_thread, int* lanes_per_row,
+                         int* rows_per_block, int* gx, int* gy) {
+  const int v = vec ? 4 : 1;
+  const int cq = (C + v - 1) / v;
+  *lanes_per_row = cq < 256 ? cq : 256;
+  *rows_per_block = 256 / *lanes_per_row;
+  *gx = (cq + *lanes_per_row - 1) / *lanes_per_row;
+  const int64_t want = (M + *rows_per_block - 1) / *rows_per_block;
+  int64_t cap = max_blocks / (*gx);
+  if (cap < 1) cap = 1;
+  int64_t gy64 = (want + min_rows_per_thread - 1) / min_rows_per_thread;
+  if (gy64 > cap) gy64 = cap;
+  if (gy64 < 1) gy64 = 1;
+  *gy = (int)gy64;
+}
+
 int vp3d_bn_act_fwd(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
                     const float* shift, const vp3d_dropout* drop, const float* res, int32_t t_dst, int32_t r_t,
                     int32_t r_stride, int32_t r_off, int32_t r_ld, float* out) {
@@ -434,50 +536,37 @@ int vp3d_bn_act_fwd(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, 
   ResMap rm{res, t_dst, r_t, r_stride, r_off, r_ld};
   if (res) VP3D_REQUIRE(t_dst > 0 && r_t > 0 && r_ld >= C, "bn_act_fwd: bad residual map");
   const DropP d = make_drop(drop);
-  const bool vec = (C % 4 == 0) && aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) &&
-                   (!res || (aligned16(res) && r_ld % 4 == 0));
+  VP3D_REQUIRE(M < ((int64_t)1 << 31), "bn_act_fwd: more than 2^31 rows");
+  const bool vec = (C % 4 == 0) && aligned16(y) && aligned16(out) && (!res || (aligned16(res) && r_ld % 4 == 0));
+  int lpr, rpb, gx, gy;
+  col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
   if (vec)
-    hipLaunchKernelGGL((k_bn_act_fwd<4>), dim3(stream_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, M, C, y,
-                       scale, shift, d, rm, out);
+    hipLaunchKernelGGL((k_bn_act_fwd<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
+                       rm, out, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_act_fwd<1>), dim3(stream_grid(M * C)), dim3(256), 0, (hipStream_t)stream, M, C, y, scale,
-                       shift, d, rm, out);
+    hipLaunchKernelGGL((k_bn_act_fwd<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
+                       rm, out, lpr, rpb);
   return check_launch("bn_act_fwd");
-}
-
-static void reduce_geometry(int64_t M, int C, bool vec, int* lanes_per_row, int* rows_per_block, int* gx, int* gy) {
-  const int v = vec ? 4 : 1;
-  const int cq = (C + v - 1) / v;             // channel groups per row
-  *lanes_per_row = cq < 256 ? cq : 256;
-  *rows_per_block = 256 / *lanes_per_row;
-  *gx = (cq + *lanes_per_row - 1) / *lanes_per_row;
-  int64_t want = (M + *rows_per_block - 1) / *rows_per_block;   // row groups if one row per thread-row
-  int64_t cap = 1024 / (*gx);
-  if (cap < 1) cap = 1;
-  // at least ~8 rows per thread so the partial buffer stays small
-  int64_t gy64 = (want + 7) / 8;
-  if (gy64 > cap) gy64 = cap;
-  if (gy64 < 1) gy64 = 1;
-  *gy = (int)gy64;
 }
 
 int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
                        const vp3d_dropout* drop, float* partials, int32_t* nparts) {
   VP3D_REQUIRE(M > 0 && C > 0 && nparts, "bn_bwd_reduce: bad argument");
+  VP3D_REQUIRE(M < ((int64_t)1 << 31), "bn_bwd_reduce: more than 2^31 rows");
   const bool vec = (C % 4 == 0);
   int lpr, rpb, gx, gy;
-  reduce_geometry(M, C, vec, &lpr, &rpb, &gx, &gy);
+  col_geometry(M, C, vec, 1024, 8, &lpr, &rpb, &gx, &gy);
   *nparts = gy * rpb;
   if (partials == nullptr) return VP3D_OK;   // size query
   VP3D_REQUIRE(go && y && scale && shift && mean && invstd, "bn_bwd_reduce: null pointer");
   VP3D_REQUIRE(!vec || (aligned16(go) && aligned16(y)), "bn_bwd_reduce: go / y must be 16-byte aligned");
   const DropP d = make_drop(drop);
   if (vec)
-    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, M, C, go, y, scale,
+    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, partials, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, M, C, go, y, scale,
+    hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, partials, lpr, rpb);
   return check_launch("bn_bwd_reduce");
 }
@@ -485,7 +574,7 @@ int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* 
 int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials, int32_t nparts, float* dgamma,
                          float* dbeta) {
   VP3D_REQUIRE(C > 0 && nparts > 0 && partials && dgamma && dbeta, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, C, partials, nparts,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, C, partials, nparts,
                      dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
 }
@@ -496,29 +585,33 @@ int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* g
   VP3D_REQUIRE(M > 0 && C > 0 && go && y && scale && shift && mean && invstd && dgamma && dbeta && dy,
                "bn_bwd_apply: bad argument");
   const DropP d = make_drop(drop);
+  VP3D_REQUIRE(M < ((int64_t)1 << 31), "bn_bwd_apply: more than 2^31 rows");
   const bool vec = (C % 4 == 0) && aligned16(go) && aligned16(y) && aligned16(dy);
+  int lpr, rpb, gx, gy;
+  col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
   if (vec)
-    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(stream_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, M, C, go,
-                       y, scale, shift, mean, invstd, d, dgamma, dbeta, dy);
+    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+                       shift, mean, invstd, d, dgamma, dbeta, dy, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(stream_grid(M * C)), dim3(256), 0, (hipStream_t)stream, M, C, go, y,
-                       scale, shift, mean, invstd, d, dgamma, dbeta, dy);
+    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+                       shift, mean, invstd, d, dgamma, dbeta, dy, lpr, rpb);
   return check_launch("bn_bwd_apply");
 }
 
 int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
-                     const float* scale, float* out) {
-  VP3D_REQUIRE(w && out && c_out > 0 && c_in > 0 && taps > 0, "pack_weight: bad argument");
+                     const float* scale, float* out, int32_t ld_out) {
+  VP3D_REQUIRE(w && out && c_out > 0 && c_in > 0 && taps > 0 && ld_out >= taps * c_in, "pack_weight: bad argument");
   hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream, c_out,
-                     c_in, taps, w, scale, out);
+                     c_in, taps, w, scale, out, ld_out);
   return check_launch("pack_weight");
 }
 
-int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t splits, int32_t c_out, int32_t c_in,
-                      int32_t taps, float* dw) {
-  VP3D_REQUIRE(partials && dw && splits > 0 && c_out > 0 && c_in > 0 && taps > 0, "wgrad_reduce: bad argument");
+int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t ld_part, int32_t splits, int32_t c_out,
+                      int32_t c_in, int32_t taps, float* dw) {
+  VP3D_REQUIRE(partials && dw && splits > 0 && c_out > 0 && c_in > 0 && taps > 0 && ld_part >= taps * c_in,
+               "wgrad_reduce: bad argument");
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
-                     splits, c_out, c_in, taps, partials, dw);
+                     splits, c_out, c_in, taps, partials, ld_part, dw);
   return check_launch("wgrad_reduce");
 }
 
@@ -526,6 +619,30 @@ int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int3
   VP3D_REQUIRE(M > 0 && N > 0 && g && out && ld >= N, "colsum: bad argument");
   hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, (hipStream_t)stream, M, N, g, ld, out);
   return check_launch("colsum");
+}
+
+int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid,
+                int32_t kpad, float* out) {
+  VP3D_REQUIRE(map && x && out, "im2row: null pointer");
+  VP3D_REQUIRE(map->batch > 0 && map->t_dst > 0 && map->t_src > 0 && k_valid > 0 && kpad >= k_valid && kpad % 4 == 0 &&
+                   aligned16(out), "im2row: bad sizes (k_valid=%d kpad=%d)", k_valid, kpad);
+  VP3D_REQUIRE((int64_t)(map->t_dst - 1) * map->t_stride * ldx + k_valid <= (int64_t)map->t_src * ldx,
+               "im2row: rows run past the end of a sample");
+  const int64_t M = (int64_t)map->batch * map->t_dst;
+  VP3D_REQUIRE(M < ((int64_t)1 << 31), "im2row: more than 2^31 rows");
+  hipLaunchKernelGGL(k_im2row, dim3(stream_grid(M * (kpad / 4))), dim3(256), 0, (hipStream_t)stream, (int)M, map->t_dst,
+                     map->t_src, map->t_stride, ldx, k_valid, kpad, x, out);
+  return check_launch("im2row");
+}
+
+int vp3d_skinny_fwd(vp3d_stream_t stream, int64_t M, int32_t N, int32_t K, const float* x, const float* w,
+                    const float* bias, float* out) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && x && w && out, "skinny_fwd: bad argument");
+  VP3D_REQUIRE(K % 4 == 0 && aligned16(x) && aligned16(w), "skinny_fwd: K must be a multiple of 4 and x / w 16-byte aligned");
+  const int64_t waves = (M + 3) / 4;
+  hipLaunchKernelGGL(k_skinny_fwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (int)M, N, K, x,
+                     w, bias, out);
+  return check_launch("skinny_fwd");
 }
 
 int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out) {

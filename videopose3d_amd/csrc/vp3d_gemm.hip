@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
 
   // XCD-aware tile order: workgroup id b runs on XCD b%8; give every XCD whole m-tiles (all their n-tiles
   // back to back) so the 8 column tiles of one activation row-panel share that XCD's L2.
+  const int split = blockIdx.y;            // split-K slice (grid.y == p.splits)
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = bid >> 3;
   const int tile_n = q % p.n_tiles;
@@ -204,7 +205,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
-  const int nkt = (p.K + BK - 1) / BK;
+  const int nkt_all = (p.K + BK - 1) / BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(nkt_all, kt_begin + p.kt_per_split);
+  const int nkt = max(0, kt_end - kt_begin);
 
   if (FAST) {
     // per-thread staging assignments: KC tile piece (w,i) = rows (w*4+i)*8 .. +8, lane -> (row, 16-B chunk)
@@ -227,8 +231,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
         b_ptr[i] = p.B + (int64_t)kr * p.ldb + n0 + (lane & 31) * 4;
       }
     }
-    int tap = 0, c0 = 0;
-    int64_t tap_off = 0;
+    int tap = (kt_begin * BK) / p.c_src;
+    int c0 = kt_begin * BK - tap * p.c_src;
+    int64_t tap_off = (int64_t)tap * p.tap_step * p.lda;
 
     auto issue = [&](int stage) {
       char* sA = smem + stage * STAGE_B;
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
       }
     };
 
-    issue(0);
+    if (nkt > 0) issue(0);
     for (int it = 0; it < nkt; ++it) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces of tile `it` have landed
       __syncthreads();   // ... and everyone's have, and everyone left stage (it+1)&1
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     for (int it = 0; it < nkt; ++it) {
       char* sA = smem + (it & 1) * STAGE_B;
       char* sB = sA + TILE_B;
-      const int k0 = it * BK;
+      const int k0 = (kt_begin + it) * BK;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         // A (KC image)
@@ -318,7 +323,75 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     }
   }
 
+  if (p.splits > 1) {
+    // split-K: raw partial tile to the workspace [split][M][N]; vp3d k_splitk_finish applies the epilogue
+    Epi e;
+    e.C = p.part + (int64_t)split * p.M * p.N;
+    e.c_bpitch = 0;
+    e.ldc = p.N;
+    e.bias = nullptr;
+    e.relu = 0;
+    e.R = nullptr;
+    e.r_bpitch = 0;
+    e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
+    e.stat_sum = e.stat_m2 = nullptr;
+    epilogue<false>(e, acc, m0, n0, wm, wn, lane, p.M, p.N, nullptr, nullptr, 0);
+    return;
+  }
   epilogue<true>(p.epi, acc, m0, n0, wm, wn, lane, p.M, p.N, tab_b, tab_t, tile_m * 2 + wm);
+}
+
+// Finish of a split-K rows GEMM: sum the partial tiles and apply the fused epilogue (bias / ReLU / residual /
+// 64-row-slab BatchNorm statistics).  grid = (slabs, ceil(N/256)); a thread owns one column of one 64-row slab.
+__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int splits, int M, int N,
+                                                       int t_dst, const Epi e) {
+  const int slab = blockIdx.x;
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int m_base = slab * 64;
+  const int cnt = min(64, M - m_base);
+  const int64_t mat = (int64_t)M * N;
+  const float bias = e.bias != nullptr ? e.bias[n] : 0.f;
+  const int rc = n - e.r_col0;
+  const bool rok = e.R != nullptr && rc >= 0 && rc < e.r_cols;
+  float raw[64];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    float v = 0.f;
+    if (r < cnt) {
+      const float* src = part + (int64_t)(m_base + r) * N + n;
+      for (int sp = 0; sp < splits; ++sp) v += src[(int64_t)sp * mat];
+    }
+    raw[r] = v;
+    s += v;
+  }
+  if (e.stat_sum != nullptr) {
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const float d = raw[r] - mean;
+      q += (r < cnt) ? d * d : 0.f;
+    }
+    e.stat_sum[(int64_t)slab * N + n] = s;
+    e.stat_m2[(int64_t)slab * N + n] = q;
+  }
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    if (r < cnt) {
+      const int m = m_base + r;
+      const int b = m / t_dst;
+      const int t = m - b * t_dst;
+      float v = raw[r] + bias;
+      if (e.relu) v = v < 0.f ? 0.f : v;
+      if (rok) {
+        const int tr = t * e.r_stride + e.r_off;
+        if ((unsigned)tr < (unsigned)e.r_t) v += e.R[(int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc];
+      }
+      e.C[(int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -441,9 +514,25 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
 
 }  // namespace
 
-int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig) {
+int rows_gemm_splits(int M, int N, int K) {
+  // Small-M layers (the T_out = 1..3 tail of the strided model) leave most of the 256 CUs idle with one
+  // 128x128 tile per workgroup: slice K until ~512 workgroups exist, keeping >= 8 K-tiles per slice.
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int nkt = (K + BK - 1) / BK;
+  if (tiles > 256 || nkt < 16) return 1;
+  int s = 512 / tiles;
+  if (s > nkt / 8) s = nkt / 8;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : s;
+}
+
+int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
+  RowsGemmArgs a = a_in;
+  const int nkt = (a.K + BK - 1) / BK;
+  if (a.part == nullptr || a.splits < 1) a.splits = 1;
+  a.kt_per_split = (nkt + a.splits - 1) / a.splits;
   const int groups = (a.m_tiles + 7) / 8;
-  const dim3 grid(groups * 8 * a.n_tiles), block(NTHREADS);
+  const dim3 grid(groups * 8 * a.n_tiles, a.splits), block(NTHREADS);
   bool fast = (a.c_src % BK == 0) && (a.N % BN == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) &&
               aligned16(a.B) && aligned16(a.zeros);
   if (!b_kcontig) fast = fast && (a.b_tap_stride % 4 == 0);
@@ -454,7 +543,11 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig) {
     if (fast) hipLaunchKernelGGL((k_rows_gemm<false, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rows_gemm<false, false>), grid, block, 0, s, a);
   }
-  return check_launch("rows_gemm");
+  int rc = check_launch("rows_gemm");
+  if (rc != VP3D_OK || a.splits == 1) return rc;
+  const dim3 fgrid((a.M + 63) / 64, (a.N + 255) / 256);
+  hipLaunchKernelGGL(k_splitk_finish, fgrid, dim3(256), 0, s, a.part, a.splits, a.M, a.N, a.t_dst, a.epi);
+  return check_launch("splitk_finish");
 }
 
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a) {

@@ -46,6 +46,8 @@ struct RowsGemmArgs {
   int32_t ldb, b_tap_stride;   // NT: B[n*ldb + k];  NN: B[(k % c_src)*ldb + (k / c_src)*b_tap_stride + n]
   int32_t t_dst, t_src, t_stride, tap_step, t_off, taps;
   int32_t m_tiles, n_tiles;
+  int32_t splits, kt_per_split;   // split-K (rows GEMM): partial tiles go to `part`, k_splitk_finish sums them
+  float* part;
   Epi epi;
 };
 
@@ -62,6 +64,7 @@ struct RedGemmArgs {
   int32_t m_tiles, n_tiles, splits, kt_per_split;
 };
 
+int rows_gemm_splits(int M, int N, int K);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
 

@@ -17,7 +17,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .plan import StackPlan
+from .plan import ConvSpec, StackPlan
 
 
 def _convs(mod) -> List[torch.nn.Conv1d]:
@@ -55,11 +55,29 @@ def folded_weights(mod):
     if cache is not None and cache[0] == key:
         return cache[1]
     packs = []
-    for conv, bn in zip(_convs(mod), _bns(mod)):
+    for idx, (conv, bn) in enumerate(zip(_convs(mod), _bns(mod))):
         scale, shift = ops.bn_fold(bn)
-        packs.append((ops.pack_weight(conv.weight.detach(), scale), shift))
+        kpad = ops.padded_k(mod._plan.convs[idx]) if idx == 0 else 0
+        packs.append((ops.pack_weight(conv.weight.detach(), scale, ld_out=kpad or None), shift))
     mod.__dict__["_fold_cache"] = (key, packs)
     return packs
+
+
+def _expand_input(plan: StackPlan, x3: torch.Tensor):
+    """expand_conv reads taps*C_in = 102 contiguous floats per output row: stage them as 128-wide zero-padded
+    rows (one cheap pass over the 34-channel input) so that the GEMM runs on the LDS-DMA fast path."""
+    spec = plan.convs[0]
+    kpad = ops.padded_k(spec)
+    if not kpad:
+        return x3, spec, 0
+    return ops.im2row(x3, spec, kpad), ConvSpec(kpad, spec.c_out, 1, 1, 1), kpad
+
+
+def _shrink(mod, h: torch.Tensor) -> torch.Tensor:
+    w = mod.shrink.weight.detach()
+    if w.shape[1] % 4 == 0:
+        return ops.skinny_fwd(h, w.view(w.shape[0], w.shape[1]), mod.shrink.bias.detach())
+    return ops.conv_fwd(h, ops.pack_weight(w), mod._plan.shrink, bias=mod.shrink.bias.detach())
 
 
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
@@ -67,24 +85,26 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
     plan.lengths(x3.shape[1])
     packs = folded_weights(mod)
     wt, bias = packs[0]
-    h = ops.conv_fwd(x3, wt, plan.convs[0], bias=bias, relu=True)
+    xin, spec0, _ = _expand_input(plan, x3)
+    h = ops.conv_fwd(xin, wt, spec0, bias=bias, relu=True)
+    del xin
     for i in range(plan.n_blocks):
         wt, bias = packs[1 + 2 * i]
         u = ops.conv_fwd(h, wt, plan.convs[1 + 2 * i], bias=bias, relu=True)
         wt, bias = packs[2 + 2 * i]
         h = ops.conv_fwd(u, wt, plan.convs[2 + 2 * i], bias=bias, relu=True, residual=(h, plan.res[i]))
         del u
-    return ops.conv_fwd(h, ops.pack_weight(mod.shrink.weight.detach()), plan.shrink, bias=mod.shrink.bias.detach())
+    return _shrink(mod, h)
 
 
 # --------------------------------------------------------------------------------------------------------
 # training
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x", "y", "coef", "drop", "wt")
+    __slots__ = ("x", "y", "coef", "drop", "wt", "kpad", "t_in")
 
-    def __init__(self, x, y, coef, drop, wt):
-        self.x, self.y, self.coef, self.drop, self.wt = x, y, coef, drop, wt
+    def __init__(self, x, y, coef, drop, wt, kpad, t_in):
+        self.x, self.y, self.coef, self.drop, self.wt, self.kpad, self.t_in = x, y, coef, drop, wt, kpad, t_in
 
 
 def forward_train(mod, x3: torch.Tensor, save: bool):
@@ -99,27 +119,29 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
 
     def layer(idx, h, residual=None):
         spec = plan.convs[idx]
-        wt = ops.pack_weight(convs[idx].weight.detach())
         b, t_in, _ = h.shape
-        m_rows = b * spec.t_out(t_in)
+        kpad = 0
+        if idx == 0:
+            h, spec, kpad = _expand_input(plan, h)
+        wt = ops.pack_weight(convs[idx].weight.detach(), ld_out=kpad or None)
+        m_rows = b * spec.t_out(h.shape[1])
         stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
         y = ops.conv_fwd(h, wt, spec, stats=stats)
         coef = ops.bn_finalize(bns[idx], m_rows, stats)
         drop = ops.make_dropout(p, seed, offset, idx)
         a = ops.bn_act_fwd(y, coef, drop, residual)
         if save:
-            saved.append(_Saved(h, y, coef, drop, wt))
+            saved.append(_Saved(h, y, coef, drop, wt, kpad, t_in))
         return a
 
     h = layer(0, x3)
     for i in range(plan.n_blocks):
         u = layer(1 + 2 * i, h)
         h = layer(2 + 2 * i, u, residual=(h, plan.res[i]))
-    wts = ops.pack_weight(mod.shrink.weight.detach())
-    out = ops.conv_fwd(h, wts, plan.shrink, bias=mod.shrink.bias.detach())
+    out = _shrink(mod, h)
     if not save:
         return out, None
-    return out, dict(layers=saved, h_last=h, wts=wts)
+    return out, dict(layers=saved, h_last=h, wts=ops.pack_weight(mod.shrink.weight.detach()), x3=x3)
 
 
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
@@ -140,22 +162,23 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop)
         grads[3 * idx + 1] = dgam
         grads[3 * idx + 2] = dbet
-        grads[3 * idx] = ops.conv_wgrad(dy, s.x, plan.convs[idx])
+        grads[3 * idx] = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad)
         return dy
 
     for i in reversed(range(plan.n_blocks)):
         i1, i2 = 1 + 2 * i, 2 + 2 * i
         dy2 = act_bwd(i2, dh)
-        da1 = ops.conv_dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].x.shape[1])
+        da1 = ops.conv_dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].t_in)
         del dy2
         dy1 = act_bwd(i1, da1)
         del da1
-        dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].x.shape[1], residual=(dh, plan.res[i]))
+        dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].t_in, residual=(dh, plan.res[i]))
         del dy1
     dy0 = act_bwd(0, dh)
     dx = None
     if need_dx:
-        dx = ops.conv_dgrad(dy0, L[0].wt, plan.convs[0], L[0].x.shape[1])
+        wt0 = L[0].wt if not L[0].kpad else ops.pack_weight(mod.expand_conv.weight.detach())
+        dx = ops.conv_dgrad(dy0, wt0, plan.convs[0], L[0].t_in)
     return grads + [d_sw, d_sb], dx
 
 

@@ -111,16 +111,53 @@ def stat_buffers(m_rows: int, c: int, device) -> Tuple[torch.Tensor, torch.Tenso
 # --------------------------------------------------------------------------------------------------------
 # convolutions
 # --------------------------------------------------------------------------------------------------------
-def pack_weight(w: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Reference Conv1d.weight [C_out, C_in, taps] -> packed [C_out, taps*C_in] (optionally row-scaled)."""
+def _timed_call(family, flops, fn, *args):
+    with _Timed(family, flops):
+        check(fn(*args), fn.__name__)
+
+
+def pack_weight(w: torch.Tensor, scale: Optional[torch.Tensor] = None, ld_out: Optional[int] = None) -> torch.Tensor:
+    """Reference Conv1d.weight [C_out, C_in, taps] -> packed [C_out, ld_out >= taps*C_in] rows
+    (wt[co][k*C_in + ci] = w[co][ci][k], optionally row-scaled; padding columns are zero)."""
     _chk(w, "weight")
     c_out, c_in, taps = w.shape
-    if taps == 1 and scale is None:
+    ld = taps * c_in if ld_out is None else int(ld_out)
+    if taps == 1 and scale is None and ld == c_in:
         return w.view(c_out, c_in)
-    out = torch.empty((c_out, taps * c_in), dtype=torch.float32, device=w.device)
-    check(_lib.lib().vp3d_pack_weight(_stream(), w.data_ptr(), c_out, c_in, taps, _p(scale), out.data_ptr()),
+    out = torch.empty((c_out, ld), dtype=torch.float32, device=w.device)
+    check(_lib.lib().vp3d_pack_weight(_stream(), w.data_ptr(), c_out, c_in, taps, _p(scale), out.data_ptr(), ld),
           "vp3d_pack_weight")
     return out
+
+
+def padded_k(spec: ConvSpec) -> int:
+    """Row width the fast (LDS-DMA) GEMM path needs for this conv: taps*C_in rounded up to 32 when the taps are
+    adjacent rows (dil == 1) and C_in itself is not DMA-friendly (expand_conv: 3*34 = 102 -> 128); else 0."""
+    k = spec.taps * spec.c_in
+    if spec.dil == 1 and (spec.c_in % 32 != 0) and k >= 32:
+        return (k + 31) // 32 * 32
+    return 0
+
+
+def im2row(x: torch.Tensor, spec: ConvSpec, kpad: int) -> torch.Tensor:
+    """[B,T_in,C_in] -> [B,T_out,kpad]: row (b,t) = the taps*C_in contiguous floats at x[b, t*stride], zero padded."""
+    _chk(x, "x")
+    assert spec.dil == 1
+    b, t_in, c_in = x.shape
+    t_out = spec.t_out(t_in)
+    out = torch.empty((b, t_out, kpad), dtype=torch.float32, device=x.device)
+    rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+    check(_lib.lib().vp3d_im2row(_stream(), C.byref(rm), x.data_ptr(), c_in, spec.taps * c_in, kpad, out.data_ptr()),
+          "vp3d_im2row")
+    return out
+
+
+def _splitk_ws(m, n, k, device):
+    s = _lib.lib().vp3d_rows_gemm_splits(m, n, k)
+    if s <= 1:
+        return None, 0
+    ws = torch.empty((s * m * n,), dtype=torch.float32, device=device)
+    return ws, ws.numel()
 
 
 def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, relu=False,
@@ -148,11 +185,24 @@ def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, re
         assert rs.start + rs.step * (t_out - 1) < r.shape[1], "residual slice out of range"
         res = (r, rs.step, rs.start, 0)
     e = _epi(bias, relu, res, stats, spec.c_out)
-    with _Timed("tconv_fwd", 2.0 * b * t_out * spec.c_out * spec.taps * c_in):
-      check(_lib.lib().vp3d_tconv_fwd(_stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1],
-                                    spec.c_out, out.data_ptr(), t_out * spec.c_out, spec.c_out,
-                                    C.byref(e) if e is not None else None, zeros_page(x.device).data_ptr()),
-          "vp3d_tconv_fwd")
+    m, k = b * t_out, spec.taps * c_in
+    ws, ws_n = _splitk_ws(m, spec.c_out, k, x.device)
+    _timed_call("tconv_fwd", 2.0 * m * spec.c_out * k, _lib.lib().vp3d_tconv_fwd,
+                _stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1], spec.c_out,
+                out.data_ptr(), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
+                zeros_page(x.device).data_ptr(), _p(ws), ws_n)
+    return out
+
+
+def skinny_fwd(x: torch.Tensor, w2d: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """The shrink conv (N = 3*J_out columns): out[b,t,:] = x[b,t,:] @ w2d^T + bias."""
+    _chk(x, "x")
+    _chk(w2d, "w")
+    b, t, k = x.shape
+    n = w2d.shape[0]
+    out = torch.empty((b, t, n), dtype=torch.float32, device=x.device)
+    _timed_call("skinny_fwd", 2.0 * b * t * n * k, _lib.lib().vp3d_skinny_fwd, _stream(), b * t, n, k, x.data_ptr(),
+                w2d.data_ptr(), _p(bias), out.data_ptr())
     return out
 
 
@@ -166,6 +216,7 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
     c_in, taps = spec.c_in, spec.taps
     ldw = wt.shape[1]
     z = zeros_page(dy.device).data_ptr()
+    flops = 2.0 * b * t_out * c_out * taps * c_in
     if spec.stride == taps and spec.dil == 1 and taps > 1:
         # windows do not overlap: dx viewed as [B*T_out, taps*C_in] = dy @ Wt   (plain GEMM)
         covered = taps * t_out
@@ -177,10 +228,10 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
             assert rs.step == taps and 0 <= rs.start < taps and r.shape == (b, t_out, c_in)
             res = (r, 1, 0, rs.start * c_in)
         e = _epi(residual=res, n_cols=taps * c_in)
-        with _Timed("tconv_dgrad", 2.0 * b * t_out * c_out * taps * c_in):
-          check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0,
-                                          taps * c_in, dx.data_ptr(), t_in * c_in, taps * c_in,
-                                          C.byref(e) if e is not None else None, z), "vp3d_tconv_dgrad")
+        ws, ws_n = _splitk_ws(b * t_out, taps * c_in, c_out, dy.device)
+        _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
+                    _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0, taps * c_in,
+                    dx.data_ptr(), t_in * c_in, taps * c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n)
         return dx
     if spec.stride != 1:
         raise _lib.Vp3dError("conv_dgrad: stride %d with %d taps is not a configuration of the temporal model"
@@ -194,39 +245,48 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
         assert rs.step == 1 and r.shape[0] == b and r.shape[2] == c_in
         res = (r, 1, -rs.start, 0)
     e = _epi(residual=res, n_cols=c_in)
-    with _Timed("tconv_dgrad", 2.0 * b * t_out * c_out * taps * c_in):
-      check(_lib.lib().vp3d_tconv_dgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in,
-                                      c_in, dx.data_ptr(), t_in * c_in, c_in, C.byref(e) if e is not None else None, z),
-          "vp3d_tconv_dgrad")
+    ws, ws_n = _splitk_ws(b * t_in, c_in, taps * c_out, dy.device)
+    _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
+                _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in, c_in, dx.data_ptr(),
+                t_in * c_in, c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n)
     return dx
 
 
-def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec) -> torch.Tensor:
-    """dW in the reference layout [C_out, C_in, taps]."""
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: int = 0) -> torch.Tensor:
+    """dW in the reference layout [C_out, C_in, taps].
+
+    rows_kpad > 0: `x` is the im2row staging of the conv input ([B,T_out,rows_kpad], see ``im2row``) and the
+    reduction runs as a 1-tap GEMM over those rows."""
     _chk(dy, "dy")
     _chk(x, "x")
     b, t_out, c_out = dy.shape
-    _, t_in, c_in = x.shape
-    assert c_out == spec.c_out and c_in == spec.c_in and t_out == spec.t_out(t_in)
-    taps = spec.taps
-    if spec.dil == 1:
-        rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
-        c_x = taps * c_in
+    c_in, taps = spec.c_in, spec.taps
+    assert c_out == spec.c_out
+    if rows_kpad:
+        assert x.shape == (b, t_out, rows_kpad)
+        rm = RowMap(b, t_out, t_out, 1, 0, 0, 1)
+        ldx, c_x, n_cols = rows_kpad, rows_kpad, rows_kpad
     else:
-        rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, taps)
-        c_x = c_in
-    n_cols = taps * c_in
+        _, t_in, c_in_x = x.shape
+        assert c_in_x == c_in and t_out == spec.t_out(t_in)
+        if spec.dil == 1:
+            rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+            c_x = taps * c_in
+        else:
+            rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, taps)
+            c_x = c_in
+        ldx, n_cols = c_in, taps * c_in
     m_rows = b * t_out
     splits = wgrad_splits(m_rows, c_out, n_cols)
     dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
-    direct = splits == 1 and taps == 1
+    direct = splits == 1 and taps == 1 and not rows_kpad
     part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)
-    with _Timed("tconv_wgrad", 2.0 * m_rows * c_out * n_cols):
-      check(_lib.lib().vp3d_tconv_wgrad(_stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), c_in, c_x,
-                                      part.data_ptr(), splits, zeros_page(dy.device).data_ptr()), "vp3d_tconv_wgrad")
+    _timed_call("tconv_wgrad", 2.0 * m_rows * c_out * taps * c_in, _lib.lib().vp3d_tconv_wgrad,
+                _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), ldx, c_x, part.data_ptr(), splits,
+                zeros_page(dy.device).data_ptr())
     if not direct:
-        check(_lib.lib().vp3d_wgrad_reduce(_stream(), part.data_ptr(), splits, c_out, c_in, taps, dw.data_ptr()),
-              "vp3d_wgrad_reduce")
+        check(_lib.lib().vp3d_wgrad_reduce(_stream(), part.data_ptr(), n_cols, splits, c_out, c_in, taps,
+                                           dw.data_ptr()), "vp3d_wgrad_reduce")
     return dw
 
 
