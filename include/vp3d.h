@@ -99,7 +99,8 @@ const char* vp3d_last_error(void);
 /* number of 64-row statistic slabs a [M, *] output produces (size stat_sum / stat_m2 as slabs*N floats) */
 int64_t vp3d_stat_slabs(int64_t M);
 /* split-K factor vp3d_tconv_fwd / _dgrad would use for an [M,N,K] problem when given a workspace (1 = none):
- * small-M layers (the T_out = 1..3 tail) are K-sliced to fill the 256 CUs; size the workspace as splits*M*N floats */
+ * small-M layers (the T_out = 1..3 tail) are K-sliced to fill the 256 CUs; size the workspace as
+ * splits * M * ((N+3)&~3) floats */
 int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K);
 
 /* y[b,t,:] = sum_k x[b, map(t,k), :] @ W_k  (+ epilogue).   M = B*t_dst, N = c_out, K = taps*c_in.
@@ -142,9 +143,6 @@ int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_
 int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid,
                 int32_t kpad, float* out);
 
-/* out[m][n] = bias[n] + sum_k x[m][k]*w[n][k] for a skinny N (the shrink conv, model.py:33,137,196; N = 3*J_out) */
-int vp3d_skinny_fwd(vp3d_stream_t stream, int64_t M, int32_t N, int32_t K, const float* x, const float* w,
-                    const float* bias, float* out);
 /* eval-mode BN folding: scale[c] = gamma/sqrt(running_var+eps), shift[c] = beta - running_mean*scale */
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift);

@@ -28,6 +28,21 @@ def timeit(fn, iters=5, warm=2):
 def run(tag, b, t, spec, do_bwd=True):
     x = torch.randn(b, t, spec.c_in, device=dev)
     w = torch.randn(spec.c_out, spec.c_in, spec.taps, device=dev) * 0.02
+    kpad = ops.padded_k(spec)
+    if kpad:                                  # expand conv: im2row staging + 1-tap GEMM over padded rows
+        flops = 2.0 * b * spec.t_out(t) * spec.c_out * spec.c_in * spec.taps
+        wt = ops.pack_weight(w, ld_out=kpad)
+        ms0 = timeit(lambda: ops.im2row(x, spec, kpad))
+        xp = ops.im2row(x, spec, kpad)
+        s1 = ConvSpec(kpad, spec.c_out, 1)
+        ms = timeit(lambda: ops.conv_fwd(xp, wt, s1))
+        line = "%-34s M=%7d N=%5d K=%5d  im2row %6.3f ms fwd %8.3f ms %6.1f TF" % (tag, b * spec.t_out(t), spec.c_out, kpad, ms0, ms, flops / ms / 1e9)
+        if do_bwd:
+            g = torch.randn(b, spec.t_out(t), spec.c_out, device=dev)
+            ms = timeit(lambda: ops.conv_wgrad(g, xp, spec, rows_kpad=kpad))
+            line += " | wgrad %8.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
+        print(line, flush=True)
+        return
     wt = ops.pack_weight(w)
     t_out = spec.t_out(t)
     g = torch.randn(b, t_out, spec.c_out, device=dev)

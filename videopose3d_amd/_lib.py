@@ -49,7 +49,6 @@ SIGNATURES = {
     "vp3d_wgrad_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vp3d_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32]),
     "vp3d_im2row": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _vp]),
-    "vp3d_skinny_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vp3d_bn_fold": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vp3d_bn_finalize": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_bn_act_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -63,7 +63,7 @@ static void set_splits(RowsGemmArgs* a, float* ws, int64_t ws_floats) {
   a->part = nullptr;
   if (ws == nullptr) return;
   const int s = rows_gemm_splits(a->M, a->N, a->K);
-  if (s > 1 && ws_floats >= (int64_t)s * a->M * a->N && aligned16(ws)) {
+  if (s > 1 && ws_floats >= (int64_t)s * a->M * ((a->N + 3) & ~3) && aligned16(ws)) {
     a->splits = s;
     a->part = ws;
   }

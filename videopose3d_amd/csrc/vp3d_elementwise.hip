@@ -364,43 +364,6 @@ __global__ void __launch_bounds__(256) k_im2row(int M, int t_dst, int t_src, int
   }
 }
 
-// Skinny GEMM for the shrink conv: out[m][n] = bias[n] + sum_k x[m][k]*w[n][k], N <= 64-ish, K % 256 == 0.
-// One wave computes 4 rows: lanes split K (coalesced float4), per output a 64-lane shuffle reduction.
-__global__ void __launch_bounds__(256) k_skinny_fwd(int M, int N, int K, const float* __restrict__ x,
-                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int m0 = wave * 4;
-  if (m0 >= M) return;
-  const int nrow = min(4, M - m0);
-  for (int n = 0; n < N; ++n) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 4; k < K; k += 256) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)n * K + k);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r < nrow) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)(m0 + r) * K + k);
-          acc[r] = fmaf(xv[0], wv[0], acc[r]);
-          acc[r] = fmaf(xv[1], wv[1], acc[r]);
-          acc[r] = fmaf(xv[2], wv[2], acc[r]);
-          acc[r] = fmaf(xv[3], wv[3], acc[r]);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
-    }
-    if (lane < nrow) {
-      const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
-      out[(int64_t)(m0 + lane) * N + n] = v + (bias != nullptr ? bias[n] : 0.f);
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256) k_dropout_mask(int64_t n, DropP d, float* out) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
@@ -633,16 +596,6 @@ int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, in
   hipLaunchKernelGGL(k_im2row, dim3(stream_grid(M * (kpad / 4))), dim3(256), 0, (hipStream_t)stream, (int)M, map->t_dst,
                      map->t_src, map->t_stride, ldx, k_valid, kpad, x, out);
   return check_launch("im2row");
-}
-
-int vp3d_skinny_fwd(vp3d_stream_t stream, int64_t M, int32_t N, int32_t K, const float* x, const float* w,
-                    const float* bias, float* out) {
-  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && x && w && out, "skinny_fwd: bad argument");
-  VP3D_REQUIRE(K % 4 == 0 && aligned16(x) && aligned16(w), "skinny_fwd: K must be a multiple of 4 and x / w 16-byte aligned");
-  const int64_t waves = (M + 3) / 4;
-  hipLaunchKernelGGL(k_skinny_fwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (int)M, N, K, x,
-                     w, bias, out);
-  return check_launch("skinny_fwd");
 }
 
 int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out) {

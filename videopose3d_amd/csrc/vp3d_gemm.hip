@@ -41,35 +41,39 @@ __device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
 // ---------------------------------------------------------------------------------------------------------
 // MFMA core: one 32-deep K tile for this wave's 64x64 sub-tile.
 // ---------------------------------------------------------------------------------------------------------
+template <bool KC>
+__device__ __forceinline__ void load_frag(const char* __restrict__ sT, int w_half, int kg, int h, int cl,
+                                          float (&f)[2][4]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (KC) {
+      const int row = w_half * 64 + i * 32 + cl;
+      const int chunk = (kg * 2 + h) ^ ((row >> 1) & 7);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * 128 + chunk * 16);
+      f[i][0] = v[0]; f[i][1] = v[1]; f[i][2] = v[2]; f[i][3] = v[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        f[i][j] = *reinterpret_cast<const float*>(sT + (kg * 8 + 4 * h + j) * 512 + (w_half * 64 + i * 32 + cl) * 4);
+    }
+  }
+}
+
+// Software-pipelined over the four 8-deep k-groups: the LDS reads of group kg+1 are issued before the 16 MFMAs
+// (1024 matrix-pipe cycles) of group kg, so the pipe never waits on LDS latency inside a K-tile.
 template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
                                              f32x16 (&acc)[2][2], int wm, int wn, int lane) {
   const int h = lane >> 5, cl = lane & 31;
+  float a[2][2][4], b[2][2][4];
+  load_frag<A_KC>(sA, wm, 0, h, cl, a[0]);
+  load_frag<B_KC>(sB, wn, 0, h, cl, b[0]);
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg) {
-    float a[2][4], b[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (A_KC) {
-        const int row = wm * 64 + i * 32 + cl;
-        const int chunk = (kg * 2 + h) ^ ((row >> 1) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sA + row * 128 + chunk * 16);
-        a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          a[i][j] = *reinterpret_cast<const float*>(sA + (kg * 8 + 4 * h + j) * 512 + (wm * 64 + i * 32 + cl) * 4);
-      }
-      if (B_KC) {
-        const int row = wn * 64 + i * 32 + cl;
-        const int chunk = (kg * 2 + h) ^ ((row >> 1) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sB + row * 128 + chunk * 16);
-        b[i][0] = v[0]; b[i][1] = v[1]; b[i][2] = v[2]; b[i][3] = v[3];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[i][j] = *reinterpret_cast<const float*>(sB + (kg * 8 + 4 * h + j) * 512 + (wn * 64 + i * 32 + cl) * 4);
-      }
+    const int cur = kg & 1, nxt = cur ^ 1;
+    if (kg < 3) {
+      load_frag<A_KC>(sA, wm, kg + 1, h, cl, a[nxt]);
+      load_frag<B_KC>(sB, wn, kg + 1, h, cl, b[nxt]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -77,8 +81,22 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][j], b[cur][jn][j], acc[i][jn], 0, 0, 0);
   }
+  // Pin the interleave (hipcc otherwise sinks every ds_read to just before its first use, i.e. read -> wait ->
+  // 4 MFMA -> read -> wait ...): masks 0x100 = DS read, 0x008 = MFMA.
+  constexpr int kReadsPerGroup = (A_KC ? 2 : 4) + (B_KC ? 2 : 4);   // b128 per 32 rows, or merged ds_read2_b32 per j
+  __builtin_amdgcn_sched_group_barrier(0x100, kReadsPerGroup, 0);
+#pragma unroll
+  for (int kg = 0; kg < 3; ++kg) {
+#pragma unroll
+    for (int q = 0; q < kReadsPerGroup; ++q) {       // front-load: the next group's reads ride the first MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - kReadsPerGroup, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -216,6 +234,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     int64_t a_off[4];
     int zoff[4];
     const float* b_ptr[4];
+    bool b_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (w * 4 + i) * 8 + (lane >> 3);
@@ -225,8 +244,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
       a_off[i] = ((int64_t)b * p.t_src + a_t0[i]) * p.lda + chunk * 4;
       zoff[i] = chunk * 4;
       if (B_KC) {
-        b_ptr[i] = p.B + (int64_t)(n0 + r) * p.ldb + chunk * 4;
+        b_ok[i] = (n0 + r) < p.N;          // weight rows beyond N (e.g. shrink: N = 51) come from the zero page
+        b_ptr[i] = b_ok[i] ? p.B + (int64_t)(n0 + r) * p.ldb + chunk * 4 : p.zeros + chunk * 4;
       } else {
+        b_ok[i] = true;
         const int kr = (w * 4 + i) * 2 + (lane >> 5);
         b_ptr[i] = p.B + (int64_t)kr * p.ldb + n0 + (lane & 31) * 4;
       }
@@ -247,7 +268,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* g;
-        if (B_KC) g = b_ptr[i] + (int64_t)tap * p.c_src + c0;
+        if (B_KC) g = b_ok[i] ? b_ptr[i] + (int64_t)tap * p.c_src + c0 : b_ptr[i];
         else g = b_ptr[i] + (int64_t)c0 * p.ldb + (int64_t)tap * p.b_tap_stride;
         glds16(g, sB + (w * 4 + i) * 1024);
       }
@@ -326,9 +347,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
   if (p.splits > 1) {
     // split-K: raw partial tile to the workspace [split][M][N]; vp3d k_splitk_finish applies the epilogue
     Epi e;
-    e.C = p.part + (int64_t)split * p.M * p.N;
+    const int ldp = (p.N + 3) & ~3;
+    e.C = p.part + (int64_t)split * p.M * ldp;
     e.c_bpitch = 0;
-    e.ldc = p.N;
+    e.ldc = ldp;
     e.bias = nullptr;
     e.relu = 0;
     e.R = nullptr;
@@ -342,54 +364,101 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
 }
 
 // Finish of a split-K rows GEMM: sum the partial tiles and apply the fused epilogue (bias / ReLU / residual /
-// 64-row-slab BatchNorm statistics).  grid = (slabs, ceil(N/256)); a thread owns one column of one 64-row slab.
+// 64-row-slab BatchNorm statistics).  One workgroup = one 64-row slab x 64 columns: thread (rg, cq) owns rows
+// rg, rg+16, rg+32, rg+48 of the slab and the float4 column group cq; 16-B loads, LDS reduction for the statistics.
 __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int splits, int M, int N,
-                                                       int t_dst, const Epi e) {
+                                                       int ldp, int vec, int t_dst, const Epi e) {
+  __shared__ float red[16][64];
+  __shared__ float mean_s[64];
   const int slab = blockIdx.x;
-  const int n = blockIdx.y * 256 + threadIdx.x;
-  if (n >= N) return;
+  const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int n = blockIdx.y * 64 + cq * 4;
   const int m_base = slab * 64;
   const int cnt = min(64, M - m_base);
-  const int64_t mat = (int64_t)M * N;
-  const float bias = e.bias != nullptr ? e.bias[n] : 0.f;
-  const int rc = n - e.r_col0;
-  const bool rok = e.R != nullptr && rc >= 0 && rc < e.r_cols;
-  float raw[64];
-  float s = 0.f;
+  const int64_t mat = (int64_t)M * ldp;           // ldp = N rounded up to 4: partial rows are 16-B aligned
+  const bool nok = n < N;
+  f32x4 raw[4];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    float v = 0.f;
-    if (r < cnt) {
-      const float* src = part + (int64_t)(m_base + r) * N + n;
-      for (int sp = 0; sp < splits; ++sp) v += src[(int64_t)sp * mat];
+  for (int i = 0; i < 4; ++i) {
+    const int r = rg + 16 * i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nok && r < cnt) {
+      const float* src = part + (int64_t)(m_base + r) * ldp + n;
+      for (int sp = 0; sp < splits; ++sp) v += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * mat);
     }
-    raw[r] = v;
+    raw[i] = v;
     s += v;
   }
   if (e.stat_sum != nullptr) {
-    const float mean = s / (float)cnt;
-    float q = 0.f;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      const float d = raw[r] - mean;
-      q += (r < cnt) ? d * d : 0.f;
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = s[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      mean_s[threadIdx.x] = t / (float)cnt;
+      const int nn = blockIdx.y * 64 + threadIdx.x;
+      if (nn < N) e.stat_sum[(int64_t)slab * N + nn] = t;
     }
-    e.stat_sum[(int64_t)slab * N + n] = s;
-    e.stat_m2[(int64_t)slab * N + n] = q;
-  }
+    __syncthreads();
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    if (r < cnt) {
-      const int m = m_base + r;
-      const int b = m / t_dst;
-      const int t = m - b * t_dst;
-      float v = raw[r] + bias;
-      if (e.relu) v = v < 0.f ? 0.f : v;
-      if (rok) {
-        const int tr = t * e.r_stride + e.r_off;
-        if ((unsigned)tr < (unsigned)e.r_t) v += e.R[(int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc];
+    for (int i = 0; i < 4; ++i) {
+      if (rg + 16 * i < cnt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = raw[i][c] - mean_s[cq * 4 + c];
+          q[c] += d * d;
+        }
       }
-      e.C[(int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = q[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      const int nn = blockIdx.y * 64 + threadIdx.x;
+      if (nn < N) e.stat_m2[(int64_t)slab * N + nn] = t;
+    }
+  }
+  if (!nok) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rg + 16 * i;
+    if (r >= cnt) continue;
+    const int m = m_base + r;
+    const int b = m / t_dst;
+    const int t = m - b * t_dst;
+    const int tr = t * e.r_stride + e.r_off;
+    const bool r_row_ok = e.R != nullptr && (unsigned)tr < (unsigned)e.r_t;
+    float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
+    const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+    if (vec) {      // N, ldc, r_ld, r_col0 multiples of 4 and 16-B aligned bases: whole float4 in or out of range
+      f32x4 v = raw[i];
+      if (e.bias != nullptr) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+      if (e.relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+      }
+      const int rc = n - e.r_col0;
+      if (r_row_ok && rc >= 0 && rc < e.r_cols) v += *reinterpret_cast<const f32x4*>(rrow + n);
+      *reinterpret_cast<f32x4*>(crow + n) = v;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int nn = n + c;
+        if (nn >= N) continue;
+        float v = raw[i][c] + (e.bias != nullptr ? e.bias[nn] : 0.f);
+        if (e.relu) v = v < 0.f ? 0.f : v;
+        const int rc = nn - e.r_col0;
+        if (r_row_ok && rc >= 0 && rc < e.r_cols) v += rrow[nn];
+        crow[nn] = v;
+      }
     }
   }
 }
@@ -515,15 +584,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
 }  // namespace
 
 int rows_gemm_splits(int M, int N, int K) {
-  // Small-M layers (the T_out = 1..3 tail of the strided model) leave most of the 256 CUs idle with one
-  // 128x128 tile per workgroup: slice K until ~512 workgroups exist, keeping >= 8 K-tiles per slice.
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  // Layers whose 128x128 tile count does not fill (or badly quantises over) the 256 CUs are K-sliced.  Cost model
+  // in units of one K-tile of matrix-pipe time (~1.7 us): a CU retires its workgroups one block-time each
+  // (two co-resident workgroups share the pipe), every workgroup pays ~3 units of prologue/epilogue, and the
+  // finishing pass streams splits*M*N floats at ~4 TB/s.
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int nkt = (K + BK - 1) / BK;
-  if (tiles > 256 || nkt < 16) return 1;
-  int s = 512 / tiles;
-  if (s > nkt / 8) s = nkt / 8;
-  if (s > 8) s = 8;
-  return s < 1 ? 1 : s;
+  if (tiles > 1024 || nkt < 8) return 1;
+  double best = 1e30;
+  int best_s = 1;
+  for (int s = 1; s <= 8; ++s) {
+    if (s > 1 && nkt / s < 4) break;
+    const double rounds = (double)((tiles * s + 255) / 256);
+    double cost = rounds * ((double)((nkt + s - 1) / s) + 3.0);
+    if (s > 1) cost += 3.0 + (double)s * (double)M * (double)N * 4.0 / (4.0e6 * 1.7);
+    if (cost < best * 0.97) {           // prefer fewer slices unless clearly better
+      best = cost;
+      best_s = s;
+    }
+  }
+  return best_s;
 }
 
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
@@ -533,9 +613,9 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   a.kt_per_split = (nkt + a.splits - 1) / a.splits;
   const int groups = (a.m_tiles + 7) / 8;
   const dim3 grid(groups * 8 * a.n_tiles, a.splits), block(NTHREADS);
-  bool fast = (a.c_src % BK == 0) && (a.N % BN == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) &&
-              aligned16(a.B) && aligned16(a.zeros);
-  if (!b_kcontig) fast = fast && (a.b_tap_stride % 4 == 0);
+  bool fast = (a.c_src % BK == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) && aligned16(a.B) &&
+              aligned16(a.zeros);
+  if (!b_kcontig) fast = fast && (a.N % BN == 0) && (a.b_tap_stride % 4 == 0);
   if (b_kcontig) {
     if (fast) hipLaunchKernelGGL((k_rows_gemm<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rows_gemm<true, false>), grid, block, 0, s, a);
@@ -545,8 +625,14 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   }
   int rc = check_launch("rows_gemm");
   if (rc != VP3D_OK || a.splits == 1) return rc;
-  const dim3 fgrid((a.M + 63) / 64, (a.N + 255) / 256);
-  hipLaunchKernelGGL(k_splitk_finish, fgrid, dim3(256), 0, s, a.part, a.splits, a.M, a.N, a.t_dst, a.epi);
+  const dim3 fgrid((a.M + 63) / 64, (a.N + 63) / 64);
+  const Epi& e = a.epi;
+  const int vec = (a.N % 4 == 0) && (e.ldc % 4 == 0) && (e.c_bpitch % 4 == 0) && aligned16(e.C) &&
+                  (e.bias == nullptr || aligned16(e.bias)) &&
+                  (e.R == nullptr || (aligned16(e.R) && e.r_ld % 4 == 0 && e.r_bpitch % 4 == 0 && e.r_col0 % 4 == 0 &&
+                                      e.r_cols % 4 == 0));
+  hipLaunchKernelGGL(k_splitk_finish, fgrid, dim3(256), 0, s, a.part, a.splits, a.M, a.N, (a.N + 3) & ~3, vec, a.t_dst,
+                     a.epi);
   return check_launch("splitk_finish");
 }
 

@@ -74,10 +74,9 @@ def _expand_input(plan: StackPlan, x3: torch.Tensor):
 
 
 def _shrink(mod, h: torch.Tensor) -> torch.Tensor:
-    w = mod.shrink.weight.detach()
-    if w.shape[1] % 4 == 0:
-        return ops.skinny_fwd(h, w.view(w.shape[0], w.shape[1]), mod.shrink.bias.detach())
-    return ops.conv_fwd(h, ops.pack_weight(w), mod._plan.shrink, bias=mod.shrink.bias.detach())
+    # N = 3*J_out (51) columns: weight rows beyond N come from the zero page, K is sliced (split-K) to fill the GPU
+    return ops.conv_fwd(h, ops.pack_weight(mod.shrink.weight.detach()), mod._plan.shrink,
+                        bias=mod.shrink.bias.detach())
 
 
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:

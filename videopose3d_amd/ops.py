@@ -156,7 +156,7 @@ def _splitk_ws(m, n, k, device):
     s = _lib.lib().vp3d_rows_gemm_splits(m, n, k)
     if s <= 1:
         return None, 0
-    ws = torch.empty((s * m * n,), dtype=torch.float32, device=device)
+    ws = torch.empty((s * m * ((n + 3) // 4 * 4),), dtype=torch.float32, device=device)
     return ws, ws.numel()
 
 
@@ -191,18 +191,6 @@ def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, re
                 _stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1], spec.c_out,
                 out.data_ptr(), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
                 zeros_page(x.device).data_ptr(), _p(ws), ws_n)
-    return out
-
-
-def skinny_fwd(x: torch.Tensor, w2d: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """The shrink conv (N = 3*J_out columns): out[b,t,:] = x[b,t,:] @ w2d^T + bias."""
-    _chk(x, "x")
-    _chk(w2d, "w")
-    b, t, k = x.shape
-    n = w2d.shape[0]
-    out = torch.empty((b, t, n), dtype=torch.float32, device=x.device)
-    _timed_call("skinny_fwd", 2.0 * b * t * n * k, _lib.lib().vp3d_skinny_fwd, _stream(), b * t, n, k, x.data_ptr(),
-                w2d.data_ptr(), _p(bias), out.data_ptr())
     return out
 
 
