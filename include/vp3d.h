@@ -102,6 +102,8 @@ int64_t vp3d_stat_slabs(int64_t M);
  * small-M layers (the T_out = 1..3 tail) are K-sliced to fill the 256 CUs; size the workspace as
  * splits * M * ((N+3)&~3) floats */
 int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K);
+/* recommended `splits` for vp3d_tconv_wgrad (reduction over M rows into a [c_out, n_cols] matrix) */
+int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols);
 
 /* y[b,t,:] = sum_k x[b, map(t,k), :] @ W_k  (+ epilogue).   M = B*t_dst, N = c_out, K = taps*c_in.
  *   x  : gathered activations, row pitch ldx floats, c_in channels used per tap

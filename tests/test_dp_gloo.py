@@ -1,0 +1,88 @@
+"""Data-parallel path on CPU: world_size-2 gloo process group (the N>1 path of bench.py / videopose3d_amd.dp)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import videopose3d_amd as V
+from videopose3d_amd import dp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                       # different initial weights per rank on purpose
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=32)
+    sync = dp.FlatGradSync(m.parameters())
+    assert sync.world == world and sync.numel == sum(p.numel() for p in m.parameters())
+    sync.broadcast_parameters(m.buffers())
+    flat_w = torch.cat([p.detach().flatten() for p in m.parameters()])
+    gathered = [torch.empty_like(flat_w) for _ in range(world)]
+    dist.all_gather(gathered, flat_w)
+    assert all(torch.equal(gathered[0], g) for g in gathered)            # replicas start identical
+
+    # gradients: every p.grad is a view of the flat buffer; autograd-style in-place accumulation lands in it
+    sync.zero_grad()
+    for i, p in enumerate(m.parameters()):
+        assert p.grad.data_ptr() >= sync.flat.data_ptr()
+        p.grad.add_(torch.full_like(p, float(rank + 1) * (i + 1)))
+    sync.sync()
+    for i, p in enumerate(m.parameters()):
+        expect = (i + 1) * sum(range(1, world + 1)) / world
+        assert torch.allclose(p.grad, torch.full_like(p, expect)), (i, float(p.grad.flatten()[0]), expect)
+
+    # short last batch: per-rank mean gradients re-weighted by their sample counts == global mean
+    sync.zero_grad()
+    counts = [5, 3]
+    for p in m.parameters():
+        p.grad.add_(float(rank + 1))
+    sync.sync(local_count=counts[rank], global_count=sum(counts))
+    expect = sum((r_ + 1) * c for r_, c in enumerate(counts)) / sum(counts)
+    assert torch.allclose(next(iter(m.parameters())).grad, torch.full_like(next(iter(m.parameters())), expect))
+
+    # zero_grad re-attaches views dropped by optimizer.zero_grad(set_to_none=True)
+    for p in m.parameters():
+        p.grad = None
+    sync.zero_grad()
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in m.parameters())
+
+    # batch sharding of an identically-seeded generator permutation (generators.py:89-104)
+    perm = np.random.RandomState(1234).permutation(1000)
+    batch = perm[:257]                                                   # odd-sized global batch
+    mine, none_kept = dp.shard_batch([batch, None], rank, world)
+    assert none_kept is None
+    np.save(os.path.join(out_dir, "shard%d.npy" % rank), mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(str(tmp_path / ("shard%d.npy" % r))) for r in range(world)]
+    full = np.random.RandomState(1234).permutation(1000)[:257]
+    assert np.array_equal(np.concatenate(parts), full)                   # disjoint, ordered, complete
+    assert abs(len(parts[0]) - len(parts[1])) <= 1
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 8, 1024, 1031):
+        for world in (1, 2, 4, 8):
+            spans = [dp.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1

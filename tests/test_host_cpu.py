@@ -112,7 +112,11 @@ def test_plan_shapes_cfg2_cfg3():
     assert flops(p3, 243) == 352569344
 
 
-def test_wgrad_splits_bounds():
+def test_split_heuristics_bounds():
+    h = _lib.lib()
     for m in (2, 31, 1024, 27648, 82944):
-        s = P.wgrad_splits(m, 1024, 3072)
+        s = h.vp3d_wgrad_splits(m, 1024, 3072)
         assert 1 <= s <= max(1, (m + 31) // 32)
+    assert h.vp3d_wgrad_splits(27648, 1024, 3072) * 192 % 256 == 0      # whole 256-CU rounds on the big layer
+    assert h.vp3d_rows_gemm_splits(240640, 1024, 3072) == 1             # big forward GEMMs are never sliced
+    assert h.vp3d_rows_gemm_splits(1024, 1024, 3072) > 1                # the T_out = 1 tail is

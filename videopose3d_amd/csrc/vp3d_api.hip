@@ -92,6 +92,11 @@ int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K) {
   return rows_gemm_splits((int)M, N, K);
 }
 
+int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols) {
+  if (M <= 0 || M >= ((int64_t)1 << 31) || c_out <= 0 || n_cols <= 0) return 1;
+  return red_gemm_splits((int)M, c_out, n_cols);
+}
+
 int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
                    const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
                    const vp3d_epilogue* epi, const float* zeros, float* splitk_ws, int64_t splitk_ws_floats) {

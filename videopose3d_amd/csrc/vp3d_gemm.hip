@@ -606,6 +606,26 @@ int rows_gemm_splits(int M, int N, int K) {
   return best_s;
 }
 
+int red_gemm_splits(int Mred, int Mo, int N) {
+  // wgrad reduces over M rows into a [Mo, N] matrix (192 tiles for a 3-tap 1024x1024 conv): slice the reduction so
+  // that the workgroup count is a whole number of 256-CU rounds; same cost model, the finish streams s*Mo*N floats.
+  const int64_t tiles = (int64_t)((Mo + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int nkt = (Mred + BK - 1) / BK;
+  double best = 1e30;
+  int best_s = 1;
+  for (int s = 1; s <= 64; ++s) {
+    if (s > 1 && nkt / s < 4) break;
+    const double rounds = (double)((tiles * s + 255) / 256);
+    double cost = rounds * ((double)((nkt + s - 1) / s) + 3.0);
+    if (s > 1) cost += 3.0 + (double)s * (double)Mo * (double)N * 4.0 / (4.0e6 * 1.7);
+    if (cost < best * 0.97) {
+      best = cost;
+      best_s = s;
+    }
+  }
+  return best_s;
+}
+
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   RowsGemmArgs a = a_in;
   const int nkt = (a.K + BK - 1) / BK;

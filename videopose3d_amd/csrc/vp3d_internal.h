@@ -65,6 +65,7 @@ struct RedGemmArgs {
 };
 
 int rows_gemm_splits(int M, int N, int K);
+int red_gemm_splits(int Mred, int Mo, int N);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
 

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import Dropout, Epilogue, RowMap, check
-from .plan import ConvSpec, ResSpec, wgrad_splits
+from .plan import ConvSpec, ResSpec
 
 _zero_pages = {}
 
@@ -265,7 +265,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: 
             c_x = c_in
         ldx, n_cols = c_in, taps * c_in
     m_rows = b * t_out
-    splits = wgrad_splits(m_rows, c_out, n_cols)
+    splits = _lib.lib().vp3d_wgrad_splits(m_rows, c_out, n_cols)
     dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
     direct = splits == 1 and taps == 1 and not rows_kpad
     part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)

@@ -100,12 +100,3 @@ def make_plan(kind: str, in_channels: int, channels: int, out_channels: int, fil
         next_dil *= fw[i]
     return StackPlan(kind, fw, bool(causal), bool(dense), tuple(pad), tuple(shift), tuple(convs), tuple(res),
                      ConvSpec(channels, out_channels, 1, 1, 1))
-
-
-def wgrad_splits(m_rows: int, c_out: int, n_cols: int) -> int:
-    """Split factor for the wgrad reduction (over M rows) so that the launch fills 256 CUs x 2 workgroups."""
-    tiles = ((c_out + 127) // 128) * ((n_cols + 127) // 128)
-    nkt = (m_rows + 31) // 32
-    want = max(1, -(-1024 // tiles))            # ~1024+ workgroups
-    most = max(1, nkt // 4)                     # keep >= 4 K-tiles (128 rows) per slice
-    return max(1, min(want, most, 64))
