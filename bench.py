@@ -96,7 +96,7 @@ def main():
 
     torch.manual_seed(0)
     model = TemporalModelOptimized1f(17, 2, 17, FW, causal=False, dropout=0.25, channels=C).to(dev).train()
-    sync = dp.FlatGradSync(model.parameters(), world=world)
+    sync = dp.FlatGradSync(model.parameters(), world=world, direct_module=model)
     sync.broadcast_parameters(model.buffers())
     gen = torch.Generator().manual_seed(1234 + rank)
     x, tgt = synthetic_batch(B, gen)

@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab
   const int c = blockIdx.x * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
+#pragma unroll 8
     for (int s = g; s < nslab; s += 8) {
       const int64_t left = M - (int64_t)s * 64;
       const double cnt = (double)(left < 64 ? left : 64);
@@ -225,11 +226,27 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __r
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
-  if (c < C)
-    for (int p = g; p < nparts; p += 8) {
+  if (c < C) {
+    // fp32 partials are summed 8 at a time (independent loads in flight) and carried in fp64
+    int p = g;
+    for (; p + 56 < nparts; p += 64) {
+      float v1[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v1[u] = partials[((int64_t)(p + 8 * u) * 2 + 0) * C + c];
+        v2[u] = partials[((int64_t)(p + 8 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a1 += (double)v1[u];
+        a2 += (double)v2[u];
+      }
+    }
+    for (; p < nparts; p += 8) {
       a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
       a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
     }
+  }
   s1[g][cl] = a1;
   s2[g][cl] = a2;
   __syncthreads();

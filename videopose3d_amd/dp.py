@@ -55,7 +55,11 @@ class FlatGradSync:
     """Keeps every parameter's ``.grad`` as a view into ONE contiguous fp32 buffer so that the gradient exchange
     is a single large all-reduce (xGMI rings are per-link bound: few large messages, not many small ones)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], world: Optional[int] = None, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], world: Optional[int] = None, group=None,
+                 direct_module: Optional[torch.nn.Module] = None):
+        """direct_module: a videopose3d_amd model whose backward should WRITE its conv-weight gradients straight
+        into the flat buffer (no autograd accumulation pass).  Requires zero_grad() before every backward; gradient
+        accumulation over several backward passes is then not supported for those tensors."""
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -65,6 +69,14 @@ class FlatGradSync:
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self._attach()
+        self._views = {id(p): p.grad for p in self.params}
+        if direct_module is not None:
+            direct_module.__dict__["_vp3d_grad_sink"] = self
+
+    def view_for(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
+        """The flat-buffer view that is (and stays) p.grad, or None when p is not managed / was detached."""
+        v = self._views.get(id(p))
+        return v if (v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr()) else None
 
     def _attach(self):
         off = 0
@@ -78,6 +90,7 @@ class FlatGradSync:
         self.flat.zero_()
         if any(p.grad is None for p in self.params):
             self._attach()
+            self._views = {id(p): p.grad for p in self.params}
 
     def broadcast_parameters(self, buffers: Iterable[torch.Tensor] = ()):
         """Make every replica start from rank 0's weights (and BN buffers)."""

@@ -155,13 +155,19 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     d_sw = ops.conv_wgrad(gout3, h_last, plan.shrink)
     dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
     grads = [None] * (3 * len(L))
+    # Optional gradient sink (dp.FlatGradSync(direct=True)): the big conv-weight gradients are written straight
+    # into the flat all-reduce buffer instead of being returned to autograd and accumulated by an extra pass.
+    sink = mod.__dict__.get("_vp3d_grad_sink")
+    convs = _convs(mod)
 
     def act_bwd(idx, go):
         s = L[idx]
         dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop)
         grads[3 * idx + 1] = dgam
         grads[3 * idx + 2] = dbet
-        grads[3 * idx] = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad)
+        out = sink.view_for(convs[idx].weight) if sink is not None else None
+        dw = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad, out=out)
+        grads[3 * idx] = None if out is not None else dw
         return dy
 
     for i in reversed(range(plan.n_blocks)):

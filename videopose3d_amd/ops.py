@@ -240,7 +240,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
     return dx
 
 
-def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: int = 0) -> torch.Tensor:
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW in the reference layout [C_out, C_in, taps].
 
     rows_kpad > 0: `x` is the im2row staging of the conv input ([B,T_out,rows_kpad], see ``im2row``) and the
@@ -266,7 +267,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: 
         ldx, n_cols = c_in, taps * c_in
     m_rows = b * t_out
     splits = _lib.lib().vp3d_wgrad_splits(m_rows, c_out, n_cols)
-    dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
+    if out is not None:
+        assert out.shape == (c_out, c_in, taps) and out.is_contiguous() and out.dtype == torch.float32
+        dw = out
+    else:
+        dw = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dy.device)
     direct = splits == 1 and taps == 1 and not rows_kpad
     part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)
     _timed_call("tconv_wgrad", 2.0 * m_rows * c_out * taps * c_in, _lib.lib().vp3d_tconv_wgrad,
