@@ -20,7 +20,7 @@ import torch
 REF = os.environ.get("VP3D_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 from common.model import TemporalModel, TemporalModelOptimized1f  # noqa: E402  (reference, executed only)
-from common.loss import mpjpe  # noqa: E402
+from common.loss import mpjpe, weighted_mpjpe  # noqa: E402
 from common.camera import project_to_2d, project_to_2d_linear  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -154,6 +154,97 @@ def make_camera():
     print("wrote camera")
 
 
+H36M_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]    # 17-joint skeleton (h36m_dataset.py:245-251)
+
+
+def make_semi():
+    """BASELINE config 5: one semi-supervised step exactly as run.py:322-394 composes it (both models, trajectory
+    loss, back-projection through project_to_2d, bone-length term), reference classes on CPU."""
+    torch.manual_seed(11)
+    gen = torch.Generator().manual_seed(111)
+    fw, C, B = [3, 3, 3], 32, 6
+    pos = TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=C)
+    traj = TemporalModelOptimized1f(17, 2, 1, fw, dropout=0.0, channels=C)
+    pad = (pos.receptive_field() - 1) // 2
+    inputs_2d = (torch.randn(B, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    inputs_2d_semi = (torch.randn(B, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    inputs_3d = torch.randn(B, 1, 17, 3, generator=gen) * 0.3
+    inputs_3d[:, :, 0, 2] = inputs_3d[:, :, 0, 2].abs() + 3.0            # root depth (camera space)
+    cam = torch.cat((torch.rand(B, 2, generator=gen) + 1.0, torch.randn(B, 2, generator=gen) * 0.05,
+                     torch.randn(B, 3, generator=gen) * 0.2, torch.randn(B, 2, generator=gen) * 0.01), dim=1)
+    out = {"inputs_2d": inputs_2d.numpy(), "inputs_2d_semi": inputs_2d_semi.numpy(), "inputs_3d": inputs_3d.numpy().copy(),
+           "cam": cam.numpy(), "parents": np.array(H36M_PARENTS)}
+    for k, v in sd_numpy(pos).items():
+        out["pos0/" + k] = v
+    for k, v in sd_numpy(traj).items():
+        out["traj0/" + k] = v
+    pos.train(); traj.train()
+    inputs_traj = inputs_3d[:, :, :1].clone()
+    inputs_3d[:, :, 0] = 0
+    split = B
+    cat = torch.cat((inputs_2d, inputs_2d_semi), dim=0)
+    p_cat = pos(cat)
+    loss_3d = mpjpe(p_cat[:split], inputs_3d)
+    t_cat = traj(cat)
+    w = 1 / inputs_traj[:, :, :, 2]
+    loss_traj = weighted_mpjpe(t_cat[:split], inputs_traj, w)
+    target_semi = inputs_2d_semi[:, pad:-pad, :, :2].contiguous()
+    recon = project_to_2d(p_cat[split:] + t_cat[split:], cam)
+    loss_rec = mpjpe(recon, target_semi)
+    dists = p_cat[:, :, 1:] - p_cat[:, :, H36M_PARENTS[1:]]
+    bone = torch.mean(torch.norm(dists, dim=3), dim=1)
+    penalty = torch.mean(torch.abs(torch.mean(bone[:split], dim=0) - torch.mean(bone[split:], dim=0)))
+    total = loss_3d + loss_traj + loss_rec + penalty
+    total.backward()
+    out["losses"] = np.array([loss_3d.item(), loss_traj.item(), loss_rec.item(), penalty.item()])
+    for k, p in pos.named_parameters():
+        out["posgrad/" + k] = p.grad.numpy().copy()
+    for k, p in traj.named_parameters():
+        out["trajgrad/" + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "semi_step.npz"), **out)
+    print("wrote semi_step losses", out["losses"])
+
+
+def make_train_loop():
+    """A run.py-style mini training loop (run.py:401-420 + 583-593): 6 Adam(amsgrad) steps on fixed batches, lr and
+    BN-momentum decay, then the train->eval state_dict hand-off (run.py:426) and an eval forward."""
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(211)
+    fw, C, B = [3, 3, 3], 32, 12
+    tr = TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=C)
+    ev = TemporalModel(17, 2, 17, fw, dropout=0.0, channels=C)
+    out = {}
+    for k, v in sd_numpy(tr).items():
+        out["sd0/" + k] = v
+    xs = (torch.randn(6, B, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    ys = torch.randn(6, B, 1, 17, 3, generator=gen) * 0.3
+    ys[:, :, :, 0] = 0
+    lr, lr_decay, mom0 = 1e-3, 0.95, 0.1
+    opt = torch.optim.Adam(tr.parameters(), lr=lr, amsgrad=True)
+    losses = []
+    tr.train()
+    for i in range(6):
+        opt.zero_grad()
+        loss = mpjpe(tr(xs[i]), ys[i])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        lr *= lr_decay
+        for g in opt.param_groups:
+            g["lr"] *= lr_decay
+        tr.set_bn_momentum(mom0 * np.exp(-(i + 1) / 6 * np.log(mom0 / 0.001)))
+    ev.load_state_dict(tr.state_dict())
+    ev.eval()
+    x_eval = (torch.randn(2, 27 + 40, 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    with torch.no_grad():
+        y_eval = ev(x_eval)
+    out.update(xs=xs.numpy(), ys=ys.numpy(), losses=np.array(losses), x_eval=x_eval.numpy(), y_eval=y_eval.numpy())
+    for k, v in sd_numpy(tr).items():
+        out["sd1/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "train_loop.npz"), **out)
+    print("wrote train_loop losses", losses)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     make_case("dil_333_c32", "dilated", [3, 3, 3], False, 32, extra_t=11)
@@ -171,3 +262,5 @@ if __name__ == "__main__":
     make_case("dil_333_c128", "dilated", [3, 3, 3], False, 128, batch=2, extra_t=30, seed=6)
     make_kat()
     make_camera()
+    make_semi()
+    make_train_loop()

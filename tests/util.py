@@ -9,8 +9,22 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not p.endswith("camera.npz"))
+    special = {"camera", "semi_step", "train_loop"}          # fixtures with their own layout / tests
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+                  if n not in special)
+
+
+def load_npz_groups(name):
+    """Fixture with 'group/key' entries -> dict of dicts (plain keys stay at top level)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    for k in z.files:
+        if "/" in k:
+            grp, key = k.split("/", 1)
+            out.setdefault(grp, {})[key] = z[k]
+        else:
+            out[k] = z[k]
+    return out
 
 
 def load_golden(name):

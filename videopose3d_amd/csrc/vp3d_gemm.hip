@@ -200,11 +200,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
   // XCD-aware tile order: workgroup id b runs on XCD b%8; give every XCD whole m-tiles (all their n-tiles
   // back to back) so the 8 column tiles of one activation row-panel share that XCD's L2.
   const int split = blockIdx.y;            // split-K slice (grid.y == p.splits)
+  // Wide outputs (dgrad of a strided conv: N = 3C = 24 column tiles) are walked in groups of 8 column tiles so
+  // that the ~64 workgroups an XCD runs concurrently form an 8x8 patch (8 A panels + 8 B panels in its 4 MiB L2).
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = bid >> 3;
-  const int tile_n = q % p.n_tiles;
-  const int tile_m = (q / p.n_tiles) * 8 + xcd;
-  if (tile_m >= p.m_tiles) return;
+  const int gn = min(p.n_tiles, 8);
+  const int m_groups = (p.m_tiles + 7) >> 3;
+  const int inner = q % gn, rest = q / gn;
+  const int tile_n = (rest / m_groups) * gn + inner;
+  const int tile_m = (rest % m_groups) * 8 + xcd;
+  if (tile_m >= p.m_tiles || tile_n >= p.n_tiles) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   if (tid < BM) {
@@ -631,8 +636,10 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   const int nkt = (a.K + BK - 1) / BK;
   if (a.part == nullptr || a.splits < 1) a.splits = 1;
   a.kt_per_split = (nkt + a.splits - 1) / a.splits;
-  const int groups = (a.m_tiles + 7) / 8;
-  const dim3 grid(groups * 8 * a.n_tiles, a.splits), block(NTHREADS);
+  const int m_groups = (a.m_tiles + 7) / 8;
+  const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
+  const int n_groups = (a.n_tiles + gn - 1) / gn;
+  const dim3 grid(8 * gn * m_groups * n_groups, a.splits), block(NTHREADS);
   bool fast = (a.c_src % BK == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) && aligned16(a.B) &&
               aligned16(a.zeros);
   if (!b_kcontig) fast = fast && (a.N % BN == 0) && (a.b_tap_stride % 4 == 0);
