@@ -34,6 +34,7 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->r_bpitch = 0;
   e->r_ld = e->r_t = e->r_stride = e->r_off = e->r_col0 = e->r_cols = 0;
   e->stat_sum = e->stat_m2 = nullptr;
+  e->vec = 0;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;

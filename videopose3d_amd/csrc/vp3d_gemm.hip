@@ -61,7 +61,7 @@ __device__ __forceinline__ void load_frag(const char* __restrict__ sT, int w_hal
 
 // Software-pipelined over the four 8-deep k-groups: the LDS reads of group kg+1 are issued before the 16 MFMAs
 // (1024 matrix-pipe cycles) of group kg, so the pipe never waits on LDS latency inside a K-tile.
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool WITH_DMA>
 __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
                                              f32x16 (&acc)[2][2], int wm, int wn, int lane) {
   const int h = lane >> 5, cl = lane & 31;
@@ -83,18 +83,34 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
         for (int jn = 0; jn < 2; ++jn)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][j], b[cur][jn][j], acc[i][jn], 0, 0, 0);
   }
-  // Pin the interleave (hipcc otherwise sinks every ds_read to just before its first use, i.e. read -> wait ->
-  // 4 MFMA -> read -> wait ...): masks 0x100 = DS read, 0x008 = MFMA.
-  constexpr int kReadsPerGroup = (A_KC ? 2 : 4) + (B_KC ? 2 : 4);   // b128 per 32 rows, or merged ds_read2_b32 per j
-  __builtin_amdgcn_sched_group_barrier(0x100, kReadsPerGroup, 0);
+  // Pin the instruction interleave of the whole K-tile (hipcc otherwise sinks every ds_read to just before its
+  // first use -- read -> wait -> 4 MFMA -> read ... -- and emits the next tile's LDS-DMA issue, ~60 VALU/SALU of
+  // address arithmetic + 8 global_load_lds, as one block in front of the first MFMA).  Masks: 0x008 MFMA,
+  // 0x100 DS read, 0x010 VMEM, 0x002 VALU.  Each fp32 32x32x2 MFMA occupies the matrix pipe for 64 cycles, so
+  // ~10 other instructions issue for free behind it.
+  constexpr int R = (A_KC ? 2 : 4) + (B_KC ? 2 : 4);   // LDS reads per k-group: b128 per 32 rows / merged read2_b32 per j
+  __builtin_amdgcn_sched_group_barrier(0x100, R, 0);    // k-group 0 operands
+  constexpr int kUsed0 = 0;
+  // (Interleaving the next tile's 8 LDS-DMA issues into the first MFMAs with VALU/VMEM groups was tried and made
+  // hipcc's solver scramble the whole tile; the DMA block stays in front of the first MFMA, with its address
+  // arithmetic reduced to running pointers.)
+  constexpr int kRoom0 = 16 - kUsed0;                   // MFMAs of group 0 still unscheduled
+  constexpr int kPer0 = R <= kRoom0 ? 1 : 2;            // group-1 reads per MFMA slot
+  constexpr int kSlots0 = (R + kPer0 - 1) / kPer0;
 #pragma unroll
-  for (int kg = 0; kg < 3; ++kg) {
+  for (int q = 0; q < kSlots0; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, kPer0, 0);
+  }
+  if constexpr (kRoom0 - kSlots0 > 0) __builtin_amdgcn_sched_group_barrier(0x008, kRoom0 - kSlots0, 0);
 #pragma unroll
-    for (int q = 0; q < kReadsPerGroup; ++q) {       // front-load: the next group's reads ride the first MFMAs
+  for (int kg = 1; kg < 3; ++kg) {                      // next group's reads ride the first MFMAs of this one
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 - kReadsPerGroup, 0);
+    if constexpr (16 - R > 0) __builtin_amdgcn_sched_group_barrier(0x008, 16 - R, 0);
   }
   __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
 }
@@ -102,28 +118,22 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
 // ---------------------------------------------------------------------------------------------------------
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // ---------------------------------------------------------------------------------------------------------
+// The accumulators are first turned into a row-major [128][128] fp32 tile in LDS (the 64 KiB of the two operand
+// stages are free after the last K-tile), then written out by a coalesced pass: a thread handles one float4 of a
+// 512-B row segment per step -> 16-B global stores (and 16-B residual / bias loads) instead of 64 scattered dword
+// accesses per lane.  BatchNorm slab statistics are taken from the registers before the staging.
 template <bool HAS_TAB>
-__device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
-                                         int lane, int M, int N, const int* tab_b, const int* tab_t,
-                                         int slab_index) {
+__device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int wm,
+                                         int wn, int tid, int lane, int M, int N, const int* tab_b,
+                                         const int* tab_t, int slab_index) {
   const int h = lane >> 5, cl = lane & 31;
-  int n[2];
-  bool nok[2], rok[2];
-  float bias[2];
-#pragma unroll
-  for (int jn = 0; jn < 2; ++jn) {
-    n[jn] = n0 + wn * 64 + jn * 32 + cl;
-    nok[jn] = n[jn] < N;
-    bias[jn] = (e.bias != nullptr && nok[jn]) ? e.bias[n[jn]] : 0.f;
-    const int rc = n[jn] - e.r_col0;
-    rok[jn] = e.R != nullptr && rc >= 0 && rc < e.r_cols;
-  }
 
   if (e.stat_sum != nullptr) {
     const int cnt = min(64, M - (m0 + wm * 64));   // wave-uniform number of valid rows in this 64-row slab
     if (cnt > 0) {
 #pragma unroll
       for (int jn = 0; jn < 2; ++jn) {
+        const int n = n0 + wn * 64 + jn * 32 + cl;
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -144,19 +154,38 @@ __device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], int 
             q += (r < cnt) ? d * d : 0.f;
           }
         q += __shfl_xor(q, 32);
-        if (h == 0 && nok[jn]) {
-          e.stat_sum[(int64_t)slab_index * N + n[jn]] = s;
-          e.stat_m2[(int64_t)slab_index * N + n[jn]] = q;
+        if (h == 0 && n < N) {
+          e.stat_sum[(int64_t)slab_index * N + n] = s;
+          e.stat_m2[(int64_t)slab_index * N + n] = q;
         }
       }
     }
   }
 
+  __syncthreads();                               // every wave is done reading the operand stages
+  float* ct = reinterpret_cast<float*>(smem);    // [128][128]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        ct[r * BN + wn * 64 + jn * 32 + cl] = acc[i][jn][reg];
+      }
+  __syncthreads();
+
+  const int col = (tid & 31) * 4;
+  const int n = n0 + col;
+  if (n >= N) return;
+  const int rc = n - e.r_col0;
+  if (e.vec) {       // N, ldc, pitches, r_col0/r_cols multiples of 4 and 16-B aligned bases (checked by the launcher)
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias != nullptr) bias = *reinterpret_cast<const f32x4*>(e.bias + n);
+    const bool rcol_ok = e.R != nullptr && rc >= 0 && rc < e.r_cols;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 8 + (tid >> 5);
       const int m = m0 + r;
       if (m >= M) continue;
       int b, t;
@@ -167,19 +196,47 @@ __device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], int 
         b = 0;
         t = m;
       }
-      float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
-      const int tr = t * e.r_stride + e.r_off;
-      const bool r_row_ok = (unsigned)tr < (unsigned)e.r_t;
-      const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * BN + col) + bias;
+      if (e.relu) {
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) {
-        if (!nok[jn]) continue;
-        float v = acc[i][jn][reg] + bias[jn];
+        for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+      }
+      if (rcol_ok) {
+        const int tr = t * e.r_stride + e.r_off;
+        if ((unsigned)tr < (unsigned)e.r_t)
+          v += *reinterpret_cast<const f32x4*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc);
+      }
+      *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
+    }
+  } else {
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 8 + (tid >> 5);
+      const int m = m0 + r;
+      if (m >= M) continue;
+      int b, t;
+      if (HAS_TAB) {
+        b = tab_b[r];
+        t = tab_t[r];
+      } else {
+        b = 0;
+        t = m;
+      }
+      const int tr = t * e.r_stride + e.r_off;
+      const bool r_row_ok = e.R != nullptr && (unsigned)tr < (unsigned)e.r_t;
+      const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+      float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int nn = n + c;
+        if (nn >= N) continue;
+        float v = ct[r * BN + col + c] + (e.bias != nullptr ? e.bias[nn] : 0.f);
         if (e.relu) v = v < 0.f ? 0.f : v;
-        if (rok[jn] && r_row_ok) v += rrow[n[jn]];
-        crow[n[jn]] = v;
+        const int rcc = nn - e.r_col0;
+        if (r_row_ok && rcc >= 0 && rcc < e.r_cols) v += rrow[nn];
+        crow[nn] = v;
       }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -234,64 +291,73 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
   const int nkt = max(0, kt_end - kt_begin);
 
   if (FAST) {
-    // per-thread staging assignments: KC tile piece (w,i) = rows (w*4+i)*8 .. +8, lane -> (row, 16-B chunk)
-    int a_t0[4];
-    int64_t a_off[4];
+    // per-thread staging assignments: KC tile piece (w,i) = rows (w*4+i)*8 .. +8, lane -> (row, 16-B chunk).
+    // Running pointers: every K-tile advances them by a wave-uniform increment (plus a jump at tap boundaries),
+    // so the per-tile address arithmetic is one 64-bit add (+ a validity select) per LDS-DMA piece.
+    const int tap0 = (kt_begin * BK) / p.c_src;
+    int c0 = kt_begin * BK - tap0 * p.c_src;
+    int a_t[4];
+    const float* a_ptr[4];
     int zoff[4];
     const float* b_ptr[4];
-    bool b_ok[4];
+    int b_inc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (w * 4 + i) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((r >> 1) & 7);
       const int b = tab_b[r], t = tab_t[r];
-      a_t0[i] = t * p.t_stride + p.t_off;
-      a_off[i] = ((int64_t)b * p.t_src + a_t0[i]) * p.lda + chunk * 4;
+      a_t[i] = t * p.t_stride + p.t_off + tap0 * p.tap_step;
+      a_ptr[i] = p.A + ((int64_t)b * p.t_src + a_t[i]) * p.lda + c0 + chunk * 4;
       zoff[i] = chunk * 4;
       if (B_KC) {
-        b_ok[i] = (n0 + r) < p.N;          // weight rows beyond N (e.g. shrink: N = 51) come from the zero page
-        b_ptr[i] = b_ok[i] ? p.B + (int64_t)(n0 + r) * p.ldb + chunk * 4 : p.zeros + chunk * 4;
+        const bool ok = (n0 + r) < p.N;    // weight rows beyond N (e.g. shrink: N = 51) come from the zero page
+        b_ptr[i] = ok ? p.B + (int64_t)(n0 + r) * p.ldb + (int64_t)kt_begin * BK + chunk * 4 : p.zeros + chunk * 4;
+        b_inc[i] = ok ? BK : 0;
       } else {
-        b_ok[i] = true;
         const int kr = (w * 4 + i) * 2 + (lane >> 5);
-        b_ptr[i] = p.B + (int64_t)kr * p.ldb + n0 + (lane & 31) * 4;
+        b_ptr[i] = p.B + (int64_t)(c0 + kr) * p.ldb + (int64_t)tap0 * p.b_tap_stride + n0 + (lane & 31) * 4;
+        b_inc[i] = 0;
       }
     }
-    int tap = (kt_begin * BK) / p.c_src;
-    int c0 = kt_begin * BK - tap * p.c_src;
-    int64_t tap_off = (int64_t)tap * p.tap_step * p.lda;
+    const int64_t a_jump = (int64_t)p.tap_step * p.lda - p.c_src + BK;            // at a tap boundary
+    const int64_t b_step = (int64_t)BK * p.ldb;                                    // NN: next 32 k-rows
+    const int64_t b_jump = (int64_t)p.b_tap_stride - (int64_t)(p.c_src - BK) * p.ldb;
 
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage, bool live) {          // `live` = false: harmless zero-page DMA (keeps it branch-free)
       char* sA = smem + stage * STAGE_B;
       char* sB = sA + TILE_B;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int st = a_t0[i] + tap * p.tap_step;
-        const float* g = ((unsigned)st < (unsigned)p.t_src) ? (p.A + a_off[i] + tap_off + c0) : (p.zeros + zoff[i]);
+        const bool ok = live && (unsigned)a_t[i] < (unsigned)p.t_src;
+        const float* g = ok ? a_ptr[i] : (p.zeros + zoff[i]);
         glds16(g, sA + (w * 4 + i) * 1024);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float* g;
-        if (B_KC) g = b_ok[i] ? b_ptr[i] + (int64_t)tap * p.c_src + c0 : b_ptr[i];
-        else g = b_ptr[i] + (int64_t)c0 * p.ldb + (int64_t)tap * p.b_tap_stride;
+        const float* g = live ? b_ptr[i] : (p.zeros + zoff[i]);
         glds16(g, sB + (w * 4 + i) * 1024);
       }
       c0 += BK;
-      if (c0 >= p.c_src) {
-        c0 = 0;
-        ++tap;
-        tap_off += (int64_t)p.tap_step * p.lda;
+      const bool wrap = c0 >= p.c_src;                // wave-uniform
+      if (wrap) c0 = 0;
+      const int64_t a_inc = wrap ? a_jump : (int64_t)BK;
+      const int t_inc = wrap ? p.tap_step : 0;
+      const int64_t bb = B_KC ? 0 : (wrap ? b_jump : b_step);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a_ptr[i] += a_inc;
+        a_t[i] += t_inc;
+        b_ptr[i] += bb + b_inc[i];
       }
     };
 
-    if (nkt > 0) issue(0);
+    if (nkt > 0) issue(0, true);
     for (int it = 0; it < nkt; ++it) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces of tile `it` have landed
       __syncthreads();   // ... and everyone's have, and everyone left stage (it+1)&1
-      if (it + 1 < nkt) issue((it + 1) & 1);
+      issue((it + 1) & 1, it + 1 < nkt);
       const char* sA = smem + (it & 1) * STAGE_B;
-      compute_tile<true, B_KC>(sA, sA + TILE_B, acc, wm, wn, lane);
+      compute_tile<true, B_KC, true>(sA, sA + TILE_B, acc, wm, wn, lane);
     }
   } else {
     for (int it = 0; it < nkt; ++it) {
@@ -343,7 +409,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
         }
       }
       __syncthreads();
-      compute_tile<true, B_KC>(sA, sB, acc, wm, wn, lane);
+      compute_tile<true, B_KC, false>(sA, sB, acc, wm, wn, lane);
       // the next iteration writes the other stage; two stages + one barrier per tile is race-free because a
       // wave can only be one tile ahead of the slowest wave (it must pass the barrier above).
     }
@@ -362,10 +428,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     e.r_bpitch = 0;
     e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
     e.stat_sum = e.stat_m2 = nullptr;
-    epilogue<false>(e, acc, m0, n0, wm, wn, lane, p.M, p.N, nullptr, nullptr, 0);
+    e.vec = 1;                                   // workspace rows are 16-B aligned (ldp = N rounded up to 4)
+    epilogue<false>(e, acc, smem, m0, n0, wm, wn, tid, lane, p.M, ldp, nullptr, nullptr, 0);
     return;
   }
-  epilogue<true>(p.epi, acc, m0, n0, wm, wn, lane, p.M, p.N, tab_b, tab_t, tile_m * 2 + wm);
+  epilogue<true>(p.epi, acc, smem, m0, n0, wm, wn, tid, lane, p.M, p.N, tab_b, tab_t, tile_m * 2 + wm);
 }
 
 // Finish of a split-K rows GEMM: sum the partial tiles and apply the fused epilogue (bias / ReLU / residual /
@@ -503,40 +570,59 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
     const int tap = n0 / p.c_x;
     const int ci0 = n0 - tap * p.c_x;
     const int tap_t = tap * p.tap_step + p.t_off;
-    const float* gbase = p.G + m0 + colchunk * 4;
-    const float* xbase = p.X + ci0 + colchunk * 4;
     const float* zsrc = p.zeros + colchunk * 4;
-    int kt = kt_begin;
+    // running (m, t, pointers) per staged row: each K-tile advances m by 32 rows; (b,t) and the gathered x-row
+    // pointer advance by per-launch constants plus a per-lane wrap correction -> no division / 64-bit multiply
+    const int adv_b = BK / p.t_dst, adv_t = BK - adv_b * p.t_dst;
+    const int64_t x_inc = ((int64_t)adv_b * p.t_src + (int64_t)adv_t * p.t_stride) * p.ldx;
+    const int64_t x_wrap = ((int64_t)p.t_src - (int64_t)p.t_dst * p.t_stride) * p.ldx;   // extra when t wraps
+    int rm[4], rt[4];
+    const float* g_ptr[4];
+    const float* x_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = (w * 4 + i) * 2 + (lane >> 5);
+      rm[i] = kt_begin * BK + kr;
+      const int rb = rm[i] / p.t_dst;
+      rt[i] = rm[i] - rb * p.t_dst;
+      g_ptr[i] = p.G + (int64_t)rm[i] * p.ldg + m0 + colchunk * 4;
+      x_ptr[i] = p.X + ((int64_t)rb * p.t_src + (int64_t)rt[i] * p.t_stride + tap_t) * p.ldx + ci0 + colchunk * 4;
+    }
+    const int64_t g_step = (int64_t)BK * p.ldg;
 
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage, bool live) {
       char* sA = smem + stage * STAGE_B;
       char* sB = sA + TILE_B;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int kr = (w * 4 + i) * 2 + (lane >> 5);
-        const int m = kt * BK + kr;
-        const bool mok = m < p.Mred;
-        const int b = m / p.t_dst;
-        const int t = m - b * p.t_dst;
-        const int st = t * p.t_stride + tap_t;
-        const float* ga = mok ? gbase + (int64_t)m * p.ldg : zsrc;
-        const float* gb = (mok && (unsigned)st < (unsigned)p.t_src)
-                              ? xbase + ((int64_t)b * p.t_src + st) * p.ldx : zsrc;
+        const bool mok = live && rm[i] < p.Mred;
+        const int st = rt[i] * p.t_stride + tap_t;
+        const bool xok = mok && (unsigned)st < (unsigned)p.t_src;
+        const float* ga = mok ? g_ptr[i] : zsrc;
+        const float* gb = xok ? x_ptr[i] : zsrc;
         glds16(ga, sA + (w * 4 + i) * 1024);
         glds16(gb, sB + (w * 4 + i) * 1024);
       }
-      ++kt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rm[i] += BK;
+        g_ptr[i] += g_step;
+        rt[i] += adv_t;
+        const bool wrapped = rt[i] >= p.t_dst;
+        rt[i] -= wrapped ? p.t_dst : 0;
+        x_ptr[i] += x_inc + (wrapped ? x_wrap : (int64_t)0);
+      }
     };
 
     if (kt_begin < kt_end) {
-      issue(0);
+      issue(0, true);
       const int n_it = kt_end - kt_begin;
       for (int it = 0; it < n_it; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (it + 1 < n_it) issue((it + 1) & 1);
+        issue((it + 1) & 1, it + 1 < n_it);
         const char* sA = smem + (it & 1) * STAGE_B;
-        compute_tile<false, false>(sA, sA + TILE_B, acc, wm, wn, lane);
+        compute_tile<false, false, true>(sA, sA + TILE_B, acc, wm, wn, lane);
       }
     }
   } else {
@@ -569,7 +655,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
         *reinterpret_cast<f32x4*>(sB + kr * 512 + colchunk * 16) = vb;
       }
       __syncthreads();
-      compute_tile<false, false>(sA, sB, acc, wm, wn, lane);
+      compute_tile<false, false, false>(sA, sB, acc, wm, wn, lane);
     }
   }
 
@@ -583,7 +669,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
   e.r_bpitch = 0;
   e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
   e.stat_sum = e.stat_m2 = nullptr;
-  epilogue<false>(e, acc, m0, n0, wm, wn, lane, p.Mo, p.N, nullptr, nullptr, 0);
+  e.vec = (p.N % 4 == 0) ? 1 : 0;               // partial matrices are 16-B aligned allocations
+  epilogue<false>(e, acc, smem, m0, n0, wm, wn, tid, lane, p.Mo, p.N, nullptr, nullptr, 0);
 }
 
 }  // namespace
@@ -631,8 +718,16 @@ int red_gemm_splits(int Mred, int Mo, int N) {
   return best_s;
 }
 
+static int epi_vec_ok(const Epi& e, int N) {
+  return (N % 4 == 0) && (e.ldc % 4 == 0) && (e.c_bpitch % 4 == 0) && aligned16(e.C) &&
+         (e.bias == nullptr || aligned16(e.bias)) &&
+         (e.R == nullptr || (aligned16(e.R) && e.r_ld % 4 == 0 && e.r_bpitch % 4 == 0 && e.r_col0 % 4 == 0 &&
+                             e.r_cols % 4 == 0));
+}
+
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   RowsGemmArgs a = a_in;
+  a.epi.vec = epi_vec_ok(a.epi, a.N);
   const int nkt = (a.K + BK - 1) / BK;
   if (a.part == nullptr || a.splits < 1) a.splits = 1;
   a.kt_per_split = (nkt + a.splits - 1) / a.splits;
@@ -653,11 +748,7 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   int rc = check_launch("rows_gemm");
   if (rc != VP3D_OK || a.splits == 1) return rc;
   const dim3 fgrid((a.M + 63) / 64, (a.N + 63) / 64);
-  const Epi& e = a.epi;
-  const int vec = (a.N % 4 == 0) && (e.ldc % 4 == 0) && (e.c_bpitch % 4 == 0) && aligned16(e.C) &&
-                  (e.bias == nullptr || aligned16(e.bias)) &&
-                  (e.R == nullptr || (aligned16(e.R) && e.r_ld % 4 == 0 && e.r_bpitch % 4 == 0 && e.r_col0 % 4 == 0 &&
-                                      e.r_cols % 4 == 0));
+  const int vec = a.epi.vec;
   hipLaunchKernelGGL(k_splitk_finish, fgrid, dim3(256), 0, s, a.part, a.splits, a.M, a.N, (a.N + 3) & ~3, vec, a.t_dst,
                      a.epi);
   return check_launch("splitk_finish");

@@ -33,6 +33,7 @@ struct Epi {
   int32_t r_ld, r_t, r_stride, r_off, r_col0, r_cols;
   float* stat_sum;
   float* stat_m2;
+  int32_t vec;       // set by the launcher: float4 epilogue legal (sizes / pitches % 4, 16-B aligned bases)
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";
