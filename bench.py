@@ -13,7 +13,8 @@ Workload (BASELINE.json `metric`: "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 
 Extra fields in the same JSON line:
   cfg2_eval_fwd : BASELINE.json configs[1] -- TemporalModel eval forward, B=1024, T=243 (5.34 TFLOP / call)
   roofline      : dominant GEMM kernel family of the step, algorithmic FLOPs / HIP-event launch durations
-  cpu_baseline  : the numpy oracle ("port") on this host's cores, bounded sample of the same workload
+  cpu_baseline  : the reference's CPU path (ATen/oneDNN through oracle/torch_cpu_path.py, kind "port") on this
+                  host's cores, bounded sample of the same workload; mpjpe_vs_ref = HIP vs that path on the sample
 Rank 0 prints ONE JSON line on stdout.
 """
 import argparse
@@ -49,33 +50,92 @@ def mpjpe(pred, target):                                                        
     return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))
 
 
-def cpu_baseline(sample_b=48, iters=2):
-    """The oracle (kind "port": numpy restatement of the reference's algorithm) timed on the host cores."""
-    from oracle import temporal_oracle as O
-    from videopose3d_amd import TemporalModelOptimized1f
+def usable_cores():
+    """Logical CPUs this process may actually run on: min(cpu_count, affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(dev, budget_s=4.0):
+    """The reference's CPU path timed on this host's cores, next to the GPU number.
+
+    /root/reference does not exist on the GPU box, so the timed code is oracle/torch_cpu_path.py: the same
+    ATen/oneDNN kernels the reference's nn.Conv1d/BatchNorm1d/ReLU modules + autograd run on a CPU, wired as
+    model.py:187-197 (kind "port"; pinned to reference-generated goldens by tests/test_oracle_golden.py).
+    Bounded sample: the batch is sized so that one fwd+bwd takes ~budget_s seconds (CPU throughput is B-linear).
+    The same leg is the checker for the metric's "MPJPE vs ref": HIP output vs this CPU path on the sample."""
+    from oracle import torch_cpu_path as T
+    from videopose3d_amd import TemporalModelOptimized1f
+    cores = usable_cores()
     torch.manual_seed(0)
-    m = TemporalModelOptimized1f(17, 2, 17, FW, dropout=0.0, channels=C)
-    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    m = TemporalModelOptimized1f(17, 2, 17, FW, dropout=0.0, channels=C).to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     gen = torch.Generator().manual_seed(1234)
-    x, tgt = synthetic_batch(sample_b, gen)
-    x, tgt = x.numpy(), tgt.numpy()
-    times = []
-    for i in range(iters + 1):
-        t0 = time.perf_counter()
-        y, cache, _ = O.forward(sd, x, FW, kind="strided", training=True)
-        O.backward(cache, O.mpjpe_grad(y, tgt))
-        if i:
-            times.append(time.perf_counter() - t0)
-    dt = float(np.mean(times))
-    return dict(value=sample_b / dt, unit="frames/s", cores=int(threads), kind="port",
-                sample="numpy oracle, TemporalModelOptimized1f arc 3,3,3,3,3 C=1024 fwd+bwd (dropout off), "
-                       "B=%d, %d timed iters after 1 warm-up, %.2f s/iter; host has %d logical cores"
-                       % (sample_b, iters, dt, os.cpu_count() or 0))
+
+    def run(bsz, iters):
+        x, tgt = synthetic_batch(bsz, gen)
+        ts, out = [], None
+        for _ in range(iters):
+            sdi = {k: v.clone() for k, v in sd.items()}
+            t0 = time.perf_counter()
+            _, out, _ = T.train_step(sdi, x, tgt, FW, kind="strided")
+            ts.append(time.perf_counter() - t0)
+        return x, out, ts
+
+    # Thread count: the box reports more logical CPUs than the container may use; oversubscribed oneDNN threads
+    # spin on each other (measured: 256 threads -> 25 s for a batch 8 threads finish in 0.13 s).  Walk the thread
+    # count up from 8 and keep the fastest (stop at the first regression) -- `cores` reports what was used.
+    best_t, best_dt, n = None, None, 8
+    while n <= cores or best_t is None:
+        n = min(n, cores)
+        torch.set_num_threads(n)
+        _, _, ts = run(32, 2)
+        if best_dt is not None and ts[-1] > best_dt:
+            break
+        best_t, best_dt = n, ts[-1]
+        if n == cores:
+            break
+        n *= 2
+    torch.set_num_threads(best_t)
+    _, _, ts = run(32, 2)                                   # warm-up + calibration at the chosen thread count
+    bsz = int(min(B, max(32, round(32 * budget_s / ts[-1] / 32) * 32)))
+    x, y_cpu, ts = run(bsz, 4)
+    dt = float(np.mean(ts[1:]))
+    with torch.no_grad():
+        y_gpu = m(x.to(dev)).cpu()
+    err = float(mpjpe(y_gpu, y_cpu))
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except OSError:
+        cpu_name = "?"
+    base = dict(value=bsz / dt, unit="frames/s", cores=int(torch.get_num_threads()), kind="port",
+                sample="oracle/torch_cpu_path.py (ATen/oneDNN conv1d/batch_norm/relu + autograd = what the reference "
+                       "runs on CPU), TemporalModelOptimized1f arc 3,3,3,3,3 C=1024 train fwd+bwd (dropout off), "
+                       "B=%d x 243 frames, 3 timed iters after 1 warm-up, %.2f s/iter, %d threads (fastest of a 8,16,.. sweep); "
+                       "host: %d logical CPUs (%d usable by this container), %s"
+                       % (bsz, dt, best_t, os.cpu_count() or 0, cores, cpu_name))
+    return base, dict(value=err, unit="mpjpe (output units = metres) between the HIP path and the CPU reference path",
+                      sample_b=bsz, tolerance=1e-3)
 
 
 def main():
@@ -215,7 +275,7 @@ def main():
         torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"], out["mpjpe_vs_ref"] = cpu_baseline(dev)
 
     if world > 1:
         dist.barrier()

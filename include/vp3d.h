@@ -13,6 +13,10 @@
  *   vp3d_bn_bwd_reduce / vp3d_bn_bwd_finalize / vp3d_bn_bwd_apply         autograd of the above
  *   vp3d_pack_weight / vp3d_bn_fold                                       eval-mode BN folding (model.eval(), run.py:427)
  *   vp3d_project_to_2d_fwd / _bwd                                         common/camera.py:37-67, 69-90
+ *   vp3d_gather_chunks    ChunkedGenerator / UnchunkedGenerator batch assembly   common/generators.py:105-149, 216-239
+ *   vp3d_mpjpe            mpjpe / weighted_mpjpe (+ gradient)                    common/loss.py:11-25
+ *   vp3d_tta_fold         test-time-augmentation un-flip + average                run.py:677-680
+ *   vp3d_adam_step        optim.Adam(amsgrad=True).step() on flat buffers         run.py:252,264,420
  *
  * Conventions
  *   - Layout: activations are channels-last rows, x[b][t][c] ("NLC"); this IS the reference's module boundary
@@ -187,6 +191,70 @@ int vp3d_project_to_2d_fwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_
                            const float* cam, int32_t linear, float* out);
 int vp3d_project_to_2d_bwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
                            const float* cam, const float* gout, int32_t linear, float* dX);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The callers either side of the temporal stack inside one training / evaluation step.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* Batch assembly on the device: replaces the per-sample numpy loop of reference common/generators.py:105-149
+ * (ChunkedGenerator.next_epoch) and the padding + mirrored copy of :216-239 (UnchunkedGenerator.next_epoch).
+ * The dataset stays resident in HBM as concatenated fp32 frames; the host keeps the (seq, start, flip) pair list
+ * and its permutation (generators.py:39-48, 89-97) and uploads only the chunk table of one batch.
+ *   chunks   : device int32 [n_chunks][3] = (seq index, start_3d, flip)
+ *   seq_off  : device int64 [n_seq + 1]: sequence s owns frames [seq_off[s], seq_off[s+1]) of poses_2d / poses_3d
+ *   out_2d[i][f] = poses_2d[seq][clamp(start - pad - causal_shift + f, 0, len-1)],  f in [0, chunk_length + 2*pad)
+ *   out_3d[i][f] = poses_3d[seq][clamp(start + f, 0, len-1)],                        f in [0, chunk_length)
+ *   out_cam[i]   = cameras[seq]
+ *   mirrored chunks (flip != 0): coordinate 0 negated, out joint j reads joint kps_perm[j] / joints_perm[j]
+ *   (perm = the reference's kps_left+kps_right <- kps_right+kps_left assignment as a gather map), camera
+ *   entries 2 and 7 negated.  poses_3d / cameras (and their outputs) may be NULL.  Bit-exact: pure copies/negations. */
+typedef struct vp3d_gather {
+  int32_t n_chunks;
+  const int32_t* chunks;
+  const int64_t* seq_off;
+  const float* poses_2d;
+  int32_t j2, f2;
+  const int32_t* kps_perm;
+  const float* poses_3d;
+  int32_t j3, f3;
+  const int32_t* joints_perm;
+  const float* cameras;
+  int32_t cam_dim;
+  int32_t chunk_length, pad, causal_shift;
+  float* out_2d;
+  float* out_3d;
+  float* out_cam;
+} vp3d_gather;
+int vp3d_gather_chunks(vp3d_stream_t stream, const vp3d_gather* g);
+
+/* Test-time augmentation fold (reference run.py:677-680): pred [2][n_frames][n_joints][dim], copy 1 is the
+ * prediction for the mirrored input:  out = (pred[0] + unflip(pred[1])) / 2,  unflip = negate coordinate 0 and
+ * read joint joints_perm[j] (NULL: no joint swap, as for the trajectory model). */
+int vp3d_tta_fold(vp3d_stream_t stream, int64_t n_frames, int32_t n_joints, int32_t dim, const float* pred,
+                  const int32_t* joints_perm, float* out);
+
+/* reference common/loss.py:11-17 mpjpe and :19-25 weighted_mpjpe, forward and gradient in one pass:
+ *   loss[0]  = (1/n_pts) * sum_i w_i * || pred_i - target_i ||_2          (rows of `dim` floats; w NULL = 1)
+ *   grad[i]  = w_i * (pred_i - target_i) / (||.||_2 * n_pts)               (d loss / d pred; 0 where the norm is 0;
+ *                                                                           grad may be NULL: loss only)
+ * ws: workspace of vp3d_mpjpe_ws_bytes(n_pts) bytes, 8-byte aligned (0 bytes / NULL up to 65,536 points).
+ * Deterministic (no atomics; fp64 combine). */
+int64_t vp3d_mpjpe_ws_bytes(int64_t n_pts);
+int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pred, const float* target,
+               const float* w, float* loss, float* grad, void* ws);
+
+/* reference run.py:252,264,420: torch.optim.Adam(params, lr, amsgrad=True).step(), as ONE pass over flat fp32
+ * buffers (parameters, gradients and optimizer state of all tensors concatenated), torch/optim/adam.py arithmetic:
+ *   g += weight_decay*p ; m += (1-beta1)*(g-m) ; v = v*beta2 + (1-beta2)*g*g ; vmax = max(vmax, v)
+ *   p -= lr/(1-beta1^step) * m / (sqrt(amsgrad ? vmax : v)/sqrt(1-beta2^step) + eps)
+ * `step` is the 1-based index of THIS update.  max_exp_avg_sq may be NULL unless amsgrad. */
+typedef struct vp3d_adam {
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t amsgrad;
+  int64_t step;
+} vp3d_adam;
+int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* grad, float* exp_avg,
+                   float* exp_avg_sq, float* max_exp_avg_sq, const vp3d_adam* h);
 
 #ifdef __cplusplus
 }

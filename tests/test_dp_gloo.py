@@ -28,7 +28,9 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)                       # different initial weights per rank on purpose
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=32)
     sync = dp.FlatGradSync(m.parameters())
-    assert sync.world == world and sync.numel == sum(p.numel() for p in m.parameters())
+    n_par = sum(p.numel() for p in m.parameters())
+    assert sync.world == world and n_par <= sync.numel < n_par + 64 * len(list(m.parameters()))
+    assert all(off % 64 == 0 for off in sync.offsets)
     sync.broadcast_parameters(m.buffers())
     flat_w = torch.cat([p.detach().flatten() for p in m.parameters()])
     gathered = [torch.empty_like(flat_w) for _ in range(world)]

@@ -58,3 +58,27 @@ def test_oracle_camera(linear):
     assert np.abs(y - z["y_" + nm]).max() < 1e-5
     dX = O.project_to_2d_grad(z["X"], z["cam"], z["g_" + nm], linear=linear)
     assert rel_err(dX, z["dX_" + nm]) < 1e-5
+
+
+# ---- oracle/torch_cpu_path.py: the reference's CPU execution path (ATen/oneDNN via torch.nn.functional), used
+# ---- only as bench.py's cpu_baseline; pinned here against the same reference-generated fixtures ---------------
+@pytest.mark.parametrize("name", [n for n in golden_names() if "drop" not in n])
+def test_torch_cpu_path_matches_reference_golden(name):
+    import torch
+    from oracle import torch_cpu_path as T
+    g = load_golden(name)
+    m = g["meta"]
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in g["sd0"].items()}
+    x, tgt = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+    kw = dict(kind=m["kind"], causal=m["causal"], dense=m["dense"])
+    with torch.no_grad():
+        y = T.forward(sd, x, m["filter_widths"], training=False, **kw)
+    assert np.abs(y.numpy() - g["y_eval"]).max() < 1e-5
+    loss, yt, grads = T.train_step(sd, x, tgt, m["filter_widths"], momentum=m["momentum"], **kw)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert np.abs(yt.numpy() - g["y_train"]).max() < 1e-5
+    for k, v in g["sd1"].items():
+        if "num_batches" not in k:
+            assert rel_err(sd[k].numpy(), v) < 1e-5, k
+    for k, v in g["grad"].items():
+        assert rel_err(grads[k].numpy(), v) < 1e-4, k

@@ -32,6 +32,19 @@ class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32)]
 
 
+class Gather(C.Structure):
+    _fields_ = [("n_chunks", C.c_int32), ("chunks", C.c_void_p), ("seq_off", C.c_void_p), ("poses_2d", C.c_void_p),
+                ("j2", C.c_int32), ("f2", C.c_int32), ("kps_perm", C.c_void_p), ("poses_3d", C.c_void_p),
+                ("j3", C.c_int32), ("f3", C.c_int32), ("joints_perm", C.c_void_p), ("cameras", C.c_void_p),
+                ("cam_dim", C.c_int32), ("chunk_length", C.c_int32), ("pad", C.c_int32), ("causal_shift", C.c_int32),
+                ("out_2d", C.c_void_p), ("out_3d", C.c_void_p), ("out_cam", C.c_void_p)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("amsgrad", C.c_int32), ("step", C.c_int64)]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P = C.POINTER
 
@@ -60,6 +73,11 @@ SIGNATURES = {
     "vp3d_dropout_mask": (C.c_int, [_vp, _i64, _P(Dropout), _vp]),
     "vp3d_project_to_2d_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "vp3d_project_to_2d_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "vp3d_gather_chunks": (C.c_int, [_vp, _P(Gather)]),
+    "vp3d_tta_fold": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "vp3d_mpjpe_ws_bytes": (_i64, [_i64]),
+    "vp3d_mpjpe": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_adam_step": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _P(Adam)]),
 }
 
 _lib = None

@@ -46,20 +46,23 @@ __device__ __forceinline__ void drop4(const DropP& d, uint64_t q, float (&mk)[4]
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics finalize (training): merge the GEMM's 64-row slab partials in fp64.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab, const float* __restrict__ psum,
-                                                     const float* __restrict__ pm2, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, float momentum,
-                                                     float* running_mean, float* running_var, int64_t* nbt,
-                                                     float* scale, float* shift, float* save_mean,
-                                                     float* save_invstd) {
-  // 32 channels x 8 slab groups per block: C/32 blocks share the (slabs x C) partial arrays
-  __shared__ double s1[8][32], s2[8][32];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+// Geometry of the two finalize kernels: a block owns FIN_CH channels and splits the partial rows over FIN_GROUPS
+// thread groups (1024 threads), so C/16 = 64 blocks x 1024 threads keep enough loads in flight to stream the
+// [parts][C] arrays (up to ~10 MB for the M = 82,944 expand layer) in a few microseconds instead of the ~40 us a
+// 32-block x 256-thread version needed (latency-bound).
+constexpr int FIN_CH = 16, FIN_GROUPS = 64;
+
+__global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
+    int C, int64_t M, int nslab, const float* __restrict__ psum, const float* __restrict__ pm2,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean, float* save_invstd) {
+  __shared__ double s1[FIN_GROUPS][FIN_CH], s2[FIN_GROUPS][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-#pragma unroll 8
-    for (int s = g; s < nslab; s += 8) {
+#pragma unroll 4
+    for (int s = g; s < nslab; s += FIN_GROUPS) {
       const int64_t left = M - (int64_t)s * 64;
       const double cnt = (double)(left < 64 ? left : 64);
       const double sum = (double)psum[(int64_t)s * C + c];
@@ -70,13 +73,15 @@ __global__ void __launch_bounds__(256) k_bn_finalize(int C, int64_t M, int nslab
   s1[g][cl] = a1;
   s2[g][cl] = a2;
   __syncthreads();
-  if (g == 0 && c < C) {
-    double S1 = 0.0, S2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      S1 += s1[i][cl];
-      S2 += s2[i][cl];
+  for (int o = FIN_GROUPS / 2; o >= 1; o >>= 1) {      // fixed-shape tree: deterministic
+    if (g < o) {
+      s1[g][cl] += s1[g + o][cl];
+      s2[g][cl] += s2[g + o][cl];
     }
+    __syncthreads();
+  }
+  if (g == 0 && c < C) {
+    const double S1 = s1[0][cl], S2 = s2[0][cl];
     const double mean = S1 / (double)M;
     double var = (S2 - S1 * mean) / (double)M;
     if (var < 0.0) var = 0.0;
@@ -220,29 +225,15 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(int M, int C, const float
   }
 }
 
-__global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __restrict__ partials, int nparts,
-                                                         float* dgamma, float* dbeta) {
-  __shared__ double s1[8][32], s2[8][32];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+__global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize(int C, const float* __restrict__ partials,
+                                                                         int nparts, float* dgamma, float* dbeta) {
+  __shared__ double s1[FIN_GROUPS][FIN_CH], s2[FIN_GROUPS][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    // fp32 partials are summed 8 at a time (independent loads in flight) and carried in fp64
-    int p = g;
-    for (; p + 56 < nparts; p += 64) {
-      float v1[8], v2[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v1[u] = partials[((int64_t)(p + 8 * u) * 2 + 0) * C + c];
-        v2[u] = partials[((int64_t)(p + 8 * u) * 2 + 1) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        a1 += (double)v1[u];
-        a2 += (double)v2[u];
-      }
-    }
-    for (; p < nparts; p += 8) {
+#pragma unroll 4
+    for (int p = g; p < nparts; p += FIN_GROUPS) {       // fp32 partials carried in fp64
       a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
       a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
     }
@@ -250,15 +241,16 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize(int C, const float* __r
   s1[g][cl] = a1;
   s2[g][cl] = a2;
   __syncthreads();
-  if (g == 0 && c < C) {
-    double S1 = 0.0, S2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      S1 += s1[i][cl];
-      S2 += s2[i][cl];
+  for (int o = FIN_GROUPS / 2; o >= 1; o >>= 1) {
+    if (g < o) {
+      s1[g][cl] += s1[g + o][cl];
+      s2[g][cl] += s2[g + o][cl];
     }
-    dbeta[c] = (float)S1;
-    dgamma[c] = (float)S2;
+    __syncthreads();
+  }
+  if (g == 0 && c < C) {
+    dbeta[c] = (float)s1[0][cl];
+    dgamma[c] = (float)s2[0][cl];
   }
 }
 
@@ -476,7 +468,7 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd,
                "bn_finalize: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
                      stat_m2, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                      save_mean, save_invstd);
   return check_launch("bn_finalize");
@@ -554,7 +546,7 @@ int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* 
 int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials, int32_t nparts, float* dgamma,
                          float* dbeta) {
   VP3D_REQUIRE(C > 0 && nparts > 0 && partials && dgamma && dbeta, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, C, partials, nparts,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, partials, nparts,
                      dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
 }

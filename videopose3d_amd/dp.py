@@ -51,6 +51,19 @@ def shard_batch(arrays: Sequence, rank: int, world: int) -> List:
     return [None if a is None else a[lo:hi] for a in arrays]
 
 
+FLAT_ALIGN = 64          # floats (256 B): every tensor's slot in a flat buffer starts on a 256-byte boundary, so the
+#                          views satisfy the 16-byte alignment of the float4 / LDS-DMA kernel paths
+
+
+def flat_layout(params: Sequence[torch.Tensor], align: int = FLAT_ALIGN) -> Tuple[List[int], int]:
+    """Offsets (in elements) of each tensor inside a flat buffer and the padded total length."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    return offs, off
+
+
 class FlatGradSync:
     """Keeps every parameter's ``.grad`` as a view into ONE contiguous fp32 buffer so that the gradient exchange
     is a single large all-reduce (xGMI rings are per-link bound: few large messages, not many small ones)."""
@@ -64,7 +77,7 @@ class FlatGradSync:
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params)
-        self.numel = sum(p.numel() for p in self.params)
+        self.offsets, self.numel = flat_layout(self.params)      # numel includes the alignment padding (zeros)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
@@ -79,11 +92,8 @@ class FlatGradSync:
         return v if (v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr()) else None
 
     def _attach(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero_grad(self):
         """Use instead of optimizer.zero_grad(set_to_none=True), which would detach the views."""

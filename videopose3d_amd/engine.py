@@ -151,23 +151,35 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     b, t_out, _ = h_last.shape
     gout3 = gout3.contiguous()
     g2 = gout3.view(b * t_out, -1)
-    d_sb = ops.colsum(g2)
-    d_sw = ops.conv_wgrad(gout3, h_last, plan.shrink)
+    # Optional gradient sink (dp.FlatGradSync(direct_module=...)): every parameter gradient is written straight
+    # into its view of the flat all-reduce buffer instead of being returned to autograd and accumulated into the
+    # pre-existing .grad by one extra add kernel per tensor (29 launches per step for arc 3,3,3,3,3).
+    sink = mod.__dict__.get("_vp3d_grad_sink")
+    convs, bns = _convs(mod), _bns(mod)
+
+    def view(p):
+        return sink.view_for(p) if sink is not None else None
+
+    def sunk(value, out):
+        return None if out is not None else value
+
+    o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
+    d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
+    d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
     dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
     grads = [None] * (3 * len(L))
-    # Optional gradient sink (dp.FlatGradSync(direct=True)): the big conv-weight gradients are written straight
-    # into the flat all-reduce buffer instead of being returned to autograd and accumulated by an extra pass.
-    sink = mod.__dict__.get("_vp3d_grad_sink")
-    convs = _convs(mod)
 
     def act_bwd(idx, go):
         s = L[idx]
-        dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop)
-        grads[3 * idx + 1] = dgam
-        grads[3 * idx + 2] = dbet
-        out = sink.view_for(convs[idx].weight) if sink is not None else None
+        o_g, o_bt = view(bns[idx].weight), view(bns[idx].bias)
+        if o_g is None or o_bt is None:
+            o_g = o_bt = None
+        dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt)
+        grads[3 * idx + 1] = sunk(dgam, o_g)
+        grads[3 * idx + 2] = sunk(dbet, o_bt)
+        out = view(convs[idx].weight)
         dw = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad, out=out)
-        grads[3 * idx] = None if out is not None else dw
+        grads[3 * idx] = sunk(dw, out)
         return dy
 
     for i in reversed(range(plan.n_blocks)):

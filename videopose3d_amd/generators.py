@@ -1,0 +1,286 @@
+"""Device-resident batch generators: same constructor arguments, helper API and iteration order as reference
+common/generators.py (``ChunkedGenerator`` :11-166, ``UnchunkedGenerator`` :168-239), but the dataset is uploaded to
+HBM once and every batch is assembled by one HIP gather kernel (vp3d_gather_chunks) instead of the reference's
+per-sample numpy loop over float64 staging buffers followed by a 34 MB host->device copy per step.
+
+What stays on the host (bit-for-bit the reference's logic): the (seq, start, end, flip) pair list
+(generators.py:39-48), the ``np.random.RandomState(random_seed).permutation`` of it (:89-97), the ``endless`` state
+machine (:150-166).  What moves to the GPU: edge padding (:105-118, 126-135), mirroring (:120-123, 137-141) and the
+camera-parameter flip (:144-149).
+
+Differences a caller sees (INTEGRATION.md shows the two-line run.py change):
+  * ``next_epoch()`` yields ``torch.float32`` CUDA tensors (fresh per batch) instead of float64 numpy views, so
+    run.py's ``torch.from_numpy(batch.astype('float32')).cuda()`` lines become no-ops to delete;
+  * ``shard=(rank, world)`` yields only this rank's contiguous slice of every batch (data parallelism:
+    every rank builds the identical generator -> identical permutation -> no communication).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from itertools import zip_longest
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .dp import shard_bounds
+
+
+def flip_permutation(n_joints: int, left: Optional[Sequence[int]], right: Optional[Sequence[int]]) -> np.ndarray:
+    """The reference's mirrored assignment ``a[:, left + right] = a[:, right + left]`` as a gather map:
+    perm[dst] = src (identity elsewhere; later duplicates win, as numpy's fancy assignment does)."""
+    perm = np.arange(n_joints, dtype=np.int32)
+    if left is not None and right is not None:
+        for dst, src in zip(list(left) + list(right), list(right) + list(left)):
+            perm[dst] = src
+    return perm
+
+
+class _Resident:
+    """Concatenated fp32 copies of the per-video arrays in HBM + frame offsets."""
+
+    def __init__(self, cameras, poses_3d, poses_2d, device):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.Vp3dError("device generators keep the dataset in GPU memory; got device %s" % self.device)
+        lens = [int(p.shape[0]) for p in poses_2d]
+        self.lens = lens
+        off = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        self.seq_off_host = off
+        self.seq_off = torch.from_numpy(off).to(self.device)
+
+        def cat(arrs):
+            a = np.concatenate([np.asarray(x, dtype=np.float32) for x in arrs], axis=0)
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+        self.p2 = cat(poses_2d)
+        self.j2, self.f2 = int(poses_2d[0].shape[-2]), int(poses_2d[0].shape[-1])
+        self.p3 = None
+        self.j3 = self.f3 = 0
+        if poses_3d is not None and len(poses_3d):
+            for a, b in zip(poses_3d, poses_2d):
+                assert a.shape[0] == b.shape[0], "3D and 2D sequences must have the same length"
+            self.p3 = cat(poses_3d)
+            self.j3, self.f3 = int(poses_3d[0].shape[-2]), int(poses_3d[0].shape[-1])
+        self.cams = None
+        self.cam_dim = 0
+        if cameras is not None and len(cameras):
+            self.cams = torch.from_numpy(np.stack([np.asarray(c, dtype=np.float32) for c in cameras])).to(self.device)
+            self.cam_dim = int(self.cams.shape[-1])
+
+    def gather(self, chunks_dev: torch.Tensor, n: int, chunk_length: int, pad: int, causal_shift: int,
+               perm2: Optional[torch.Tensor], perm3: Optional[torch.Tensor], want_3d=True, want_cam=True):
+        """chunks_dev: device int32 [n,3] (seq, start, flip).  Returns (cam, batch_3d, batch_2d) device tensors."""
+        dev = self.device
+        o2 = torch.empty((n, chunk_length + 2 * pad, self.j2, self.f2), dtype=torch.float32, device=dev)
+        o3 = torch.empty((n, chunk_length, self.j3, self.f3), dtype=torch.float32, device=dev) \
+            if (self.p3 is not None and want_3d) else None
+        oc = torch.empty((n, self.cam_dim), dtype=torch.float32, device=dev) \
+            if (self.cams is not None and want_cam) else None
+        g = _lib.Gather()
+        g.n_chunks = n
+        g.chunks = chunks_dev.data_ptr()
+        g.seq_off = self.seq_off.data_ptr()
+        g.poses_2d = self.p2.data_ptr()
+        g.j2, g.f2 = self.j2, self.f2
+        g.kps_perm = perm2.data_ptr() if perm2 is not None else None
+        g.poses_3d = self.p3.data_ptr() if o3 is not None else None
+        g.j3, g.f3 = self.j3, self.f3
+        g.joints_perm = perm3.data_ptr() if perm3 is not None else None
+        g.cameras = self.cams.data_ptr() if oc is not None else None
+        g.cam_dim = self.cam_dim
+        g.chunk_length, g.pad, g.causal_shift = chunk_length, pad, causal_shift
+        g.out_2d = o2.data_ptr()
+        g.out_3d = o3.data_ptr() if o3 is not None else None
+        g.out_cam = oc.data_ptr() if oc is not None else None
+        with torch.cuda.device(dev):
+            check(_lib.lib().vp3d_gather_chunks(torch.cuda.current_stream().cuda_stream, C.byref(g)),
+                  "vp3d_gather_chunks")
+        return oc, o3, o2
+
+
+def _perm_dev(n, left, right, device):
+    if left is None or right is None:
+        return None
+    return torch.from_numpy(flip_permutation(n, left, right)).to(device)
+
+
+class ChunkedGenerator:
+    """Batched data generator used for training (reference generators.py:11-166): sequences are split into
+    equal-length chunks and padded as necessary; batches are assembled on the GPU."""
+
+    def __init__(self, batch_size, cameras, poses_3d, poses_2d, chunk_length, pad=0, causal_shift=0, shuffle=True,
+                 random_seed=1234, augment=False, kps_left=None, kps_right=None, joints_left=None, joints_right=None,
+                 endless=False, device=None, shard: Optional[Tuple[int, int]] = None):
+        assert poses_3d is None or len(poses_3d) == len(poses_2d), (len(poses_3d), len(poses_2d))
+        assert cameras is None or len(cameras) == len(poses_2d)
+
+        # Build lineage info (generators.py:39-48): (seq_idx, start_frame, end_frame, flip)
+        rows = []
+        for i in range(len(poses_2d)):
+            n_frames = poses_2d[i].shape[0]
+            n_chunks = (n_frames + chunk_length - 1) // chunk_length
+            offset = (n_chunks * chunk_length - n_frames) // 2
+            bounds = np.arange(n_chunks + 1) * chunk_length - offset
+            blk = np.stack([np.full(n_chunks, i, dtype=np.int64), bounds[:-1], bounds[1:],
+                            np.zeros(n_chunks, dtype=np.int64)], axis=1)
+            rows.append(blk)
+            if augment:
+                flipped = blk.copy()
+                flipped[:, 3] = 1
+                rows.append(flipped)
+        # same dtype / shape as np.array(list_of_tuples) in the reference, so RandomState.permutation takes the
+        # same code path and consumes the same random stream
+        self.pairs = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), dtype=np.int64)
+
+        self.num_batches = (len(self.pairs) + batch_size - 1) // batch_size
+        self.batch_size = batch_size
+        self.random = np.random.RandomState(random_seed)
+        self.shuffle = shuffle
+        self.pad = pad
+        self.causal_shift = causal_shift
+        self.endless = endless
+        self.state = None
+        self.chunk_length = chunk_length
+
+        self.cameras = cameras
+        self.poses_3d = poses_3d
+        self.poses_2d = poses_2d
+
+        self.augment = augment
+        self.kps_left = kps_left
+        self.kps_right = kps_right
+        self.joints_left = joints_left
+        self.joints_right = joints_right
+
+        self.shard = shard
+        self._res = _Resident(cameras, poses_3d, poses_2d, device)
+        self._perm2 = _perm_dev(self._res.j2, kps_left, kps_right, self._res.device) if augment else None
+        self._perm3 = _perm_dev(self._res.j3, joints_left, joints_right, self._res.device) \
+            if (augment and self._res.p3 is not None) else None
+        self._table = None          # (id of the host pairs array, device int32 [N,3])
+
+    def num_frames(self):
+        return self.num_batches * self.batch_size
+
+    def random_state(self):
+        return self.random
+
+    def set_random_state(self, random):
+        self.random = random
+
+    def augment_enabled(self):
+        return self.augment
+
+    def next_pairs(self):
+        if self.state is None:
+            if self.shuffle:
+                pairs = self.random.permutation(self.pairs)
+            else:
+                pairs = self.pairs
+            return 0, pairs
+        else:
+            return self.state
+
+    def _device_table(self, pairs: np.ndarray) -> torch.Tensor:
+        """One upload of the epoch's chunk table (12 B per chunk); batches then only take slices of it."""
+        if self._table is None or self._table[0] is not pairs:
+            tab = np.ascontiguousarray(pairs[:, [0, 1, 3]].astype(np.int32))
+            self._table = (pairs, torch.from_numpy(tab).to(self._res.device))
+        return self._table[1]
+
+    def next_epoch(self):
+        enabled = True
+        while enabled:
+            start_idx, pairs = self.next_pairs()
+            table = self._device_table(pairs)
+            for b_i in range(start_idx, self.num_batches):
+                lo, hi = b_i * self.batch_size, min((b_i + 1) * self.batch_size, len(pairs))
+                if self.shard is not None:
+                    s_lo, s_hi = shard_bounds(hi - lo, self.shard[0], self.shard[1])
+                    lo, hi = lo + s_lo, lo + s_hi
+                if hi > lo:
+                    cam, b3, b2 = self._res.gather(table[lo:hi], hi - lo, self.chunk_length, self.pad,
+                                                   self.causal_shift, self._perm2, self._perm3)
+                else:                                            # a rank may get nothing of a short last batch
+                    cam = b3 = None
+                    b2 = torch.empty((0, self.chunk_length + 2 * self.pad, self._res.j2, self._res.f2),
+                                     dtype=torch.float32, device=self._res.device)
+                if self.endless:
+                    self.state = (b_i + 1, pairs)
+                yield cam, b3, b2
+
+            if self.endless:
+                self.state = None
+            else:
+                enabled = False
+
+
+class UnchunkedGenerator:
+    """Non-batched data generator used for testing (reference generators.py:168-239): one sequence per batch,
+    plus its mirrored copy when augmentation (test-time augmentation) is enabled."""
+
+    def __init__(self, cameras, poses_3d, poses_2d, pad=0, causal_shift=0, augment=False, kps_left=None,
+                 kps_right=None, joints_left=None, joints_right=None, device=None):
+        assert poses_3d is None or len(poses_3d) == len(poses_2d)
+        assert cameras is None or len(cameras) == len(poses_2d)
+
+        self.augment = augment
+        self.kps_left = kps_left
+        self.kps_right = kps_right
+        self.joints_left = joints_left
+        self.joints_right = joints_right
+
+        self.pad = pad
+        self.causal_shift = causal_shift
+        self.cameras = [] if cameras is None else cameras
+        self.poses_3d = [] if poses_3d is None else poses_3d
+        self.poses_2d = poses_2d
+
+        self._res = _Resident(cameras, poses_3d, poses_2d, device)
+        dev = self._res.device
+        self._perm2 = _perm_dev(self._res.j2, kps_left, kps_right, dev)
+        self._perm3 = _perm_dev(self._res.j3, joints_left, joints_right, dev) if self._res.p3 is not None else None
+        n = len(poses_2d)
+        tab = np.zeros((n, 2, 3), dtype=np.int32)              # per sequence: (seq, 0, flip=0), (seq, 0, flip=1)
+        tab[:, :, 0] = np.arange(n)[:, None]
+        tab[:, 1, 2] = 1
+        self._table = torch.from_numpy(tab).to(dev)
+
+    def num_frames(self):
+        count = 0
+        for p in self.poses_2d:
+            count += p.shape[0]
+        return count
+
+    def augment_enabled(self):
+        return self.augment
+
+    def set_augment(self, augment):
+        self.augment = augment
+
+    def next_epoch(self):
+        for s in range(len(self.poses_2d)):
+            n = 2 if self.augment else 1
+            yield self._res.gather(self._table[s, :n], n, self._res.lens[s], self.pad, self.causal_shift,
+                                   self._perm2 if self.augment else None, self._perm3 if self.augment else None)
+
+
+def tta_average(predicted: torch.Tensor, joints_left=None, joints_right=None) -> torch.Tensor:
+    """run.py:677-680: ``predicted`` [2,T,J,3] holds the prediction for a sequence and for its mirrored copy; undo
+    the mirroring of copy 1 (negate x, swap left/right joints unless both lists are None, as for the trajectory
+    model) and average -> [1,T,J,3].  One kernel instead of five indexing / mean kernels."""
+    assert predicted.dim() == 4 and predicted.shape[0] == 2
+    if not predicted.is_cuda:
+        raise _lib.Vp3dError("tta_average runs on the GPU only")
+    p = predicted.to(torch.float32).contiguous()
+    _, t, j, d = p.shape
+    perm = _perm_dev(j, joints_left, joints_right, p.device)
+    out = torch.empty((1, t, j, d), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        check(_lib.lib().vp3d_tta_fold(torch.cuda.current_stream().cuda_stream, t, j, d, p.data_ptr(),
+                                       perm.data_ptr() if perm is not None else None, out.data_ptr()), "vp3d_tta_fold")
+    return out

@@ -283,10 +283,12 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: 
     return dw
 
 
-def colsum(g2d: torch.Tensor) -> torch.Tensor:
+def colsum(g2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(g2d, "g")
     m, n = g2d.shape
-    out = torch.empty((n,), dtype=torch.float32, device=g2d.device)
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=g2d.device)
+    assert out.shape == (n,) and out.is_contiguous() and out.dtype == torch.float32
     check(_lib.lib().vp3d_colsum(_stream(), m, n, g2d.data_ptr(), n, out.data_ptr()), "vp3d_colsum")
     return out
 
@@ -341,8 +343,10 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
     return out
 
 
-def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout]):
-    """Returns (dy, dgamma, dbeta) for a = dropout(relu(bn(y)))."""
+def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
+               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
+    """Returns (dy, dgamma, dbeta) for a = dropout(relu(bn(y))); dgamma / dbeta are written into the given
+    contiguous fp32 [C] tensors when provided (gradient sink)."""
     _chk(go, "go")
     _chk(y, "y")
     b, t, c = y.shape
@@ -357,13 +361,19 @@ def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Opti
     sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
     check(L.vp3d_bn_bwd_reduce(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
                                C.byref(nparts)), "vp3d_bn_bwd_reduce")
-    dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
-    check(L.vp3d_bn_bwd_finalize(_stream(), c, parts.data_ptr(), nparts.value, dgb[0].data_ptr(), dgb[1].data_ptr()),
+    if out_dgamma is not None and out_dbeta is not None:
+        for t in (out_dgamma, out_dbeta):
+            assert t.shape == (c,) and t.is_contiguous() and t.dtype == torch.float32 and t.device == y.device
+        dgam, dbet = out_dgamma, out_dbeta
+    else:
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        dgam, dbet = dgb[0], dgb[1]
+    check(L.vp3d_bn_bwd_finalize(_stream(), c, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr()),
           "vp3d_bn_bwd_finalize")
     dy = torch.empty_like(y)
-    check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgb[0].data_ptr(),
-                              dgb[1].data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
-    return dy, dgb[0], dgb[1]
+    check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
+                              dbet.data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
+    return dy, dgam, dbet
 
 
 def dropout_mask(n: int, drop: Optional[Dropout], device) -> torch.Tensor:
