@@ -249,9 +249,10 @@ int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pr
  *   p -= lr/(1-beta1^step) * m / (sqrt(amsgrad ? vmax : v)/sqrt(1-beta2^step) + eps)
  * `step` is the 1-based index of THIS update.  max_exp_avg_sq may be NULL unless amsgrad. */
 typedef struct vp3d_adam {
-  float lr, beta1, beta2, eps, weight_decay;
-  int32_t amsgrad;
+  double lr, beta1, beta2, eps, weight_decay; /* Python-float (double) hyper-parameters, as torch keeps them: 1-beta2
+                                                 must be formed in double before it is rounded to fp32 */
   int64_t step;
+  int32_t amsgrad;
 } vp3d_adam;
 int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* grad, float* exp_avg,
                    float* exp_avg_sq, float* max_exp_avg_sq, const vp3d_adam* h);

@@ -317,18 +317,26 @@ def backward(cache, gout, trace=None, relu_pos=None):
 # --------------------------------------------------------------------------------------
 # loss (reference common/loss.py:11-17) -- the parity metric
 # --------------------------------------------------------------------------------------
-def mpjpe(pred, target):
+def mpjpe(pred, target, w=None):
+    """loss.py:11-17 (w is None) / :19-25 weighted_mpjpe (w broadcasts over the per-joint norm tensor)."""
     assert pred.shape == target.shape
     d = np.asarray(pred, dtype=np.float64) - np.asarray(target, dtype=np.float64)
-    return float(np.mean(np.sqrt((d ** 2).sum(axis=-1))))
+    n = np.sqrt((d ** 2).sum(axis=-1))
+    if w is not None:
+        assert w.shape[0] == pred.shape[0]
+        n = np.asarray(w, dtype=np.float64) * n
+    return float(np.mean(n))
 
 
-def mpjpe_grad(pred, target):
-    """d mpjpe / d pred = (p-q)/||p-q|| / (B*T*J)."""
+def mpjpe_grad(pred, target, w=None):
+    """d mpjpe / d pred = w * (p-q)/||p-q|| / (B*T*J)   (0 where p == q, torch's sub-gradient of the norm)."""
     d = pred - target
     n = np.sqrt((d.astype(np.float64) ** 2).sum(axis=-1, keepdims=True))
     cnt = d.size // d.shape[-1]
-    return (d / np.maximum(n, 1e-30) / cnt).astype(pred.dtype)
+    g = np.where(n > 0, d / np.maximum(n, 1e-300), 0.0) / cnt
+    if w is not None:
+        g = g * np.broadcast_to(np.asarray(w, dtype=np.float64), d.shape[:-1])[..., None]
+    return g.astype(pred.dtype)
 
 
 # --------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    special = {"camera", "semi_step", "train_loop"}          # fixtures with their own layout / tests
+    special = {"camera", "semi_step", "train_loop", "step_generators", "step_loss", "step_adam"}          # fixtures with their own layout / tests
     return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
                   if n not in special)
 
@@ -58,3 +58,23 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ---- step-level fixtures (tests/golden/make_golden_step.py) -------------------------------------------------
+KPS_LEFT, KPS_RIGHT = [1, 3, 5, 7, 9, 11, 13, 15], [2, 4, 6, 8, 10, 12, 14, 16]
+JOINTS_LEFT, JOINTS_RIGHT = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+GEN_CASES = ("c1", "c3", "plain")
+
+
+def load_step_dataset():
+    """(fixture dict, cameras, poses_3d, poses_2d) of step_generators.npz."""
+    z = np.load(os.path.join(GOLDEN, "step_generators.npz"))
+    n = int(z["n_seq"])
+    return (z, [z["cam_%d" % i] for i in range(n)], [z["p3_%d" % i] for i in range(n)],
+            [z["p2_%d" % i] for i in range(n)])
+
+
+def gen_case_meta(z, name):
+    bs, cl, pad, shift, aug, shuf, cams, nb, nf = (int(v) for v in z[name + "/meta"])
+    return dict(batch_size=bs, chunk_length=cl, pad=pad, causal_shift=shift, augment=bool(aug), shuffle=bool(shuf),
+                cams=bool(cams), num_batches=nb, num_frames=nf, n=int(z[name + "/n"]))

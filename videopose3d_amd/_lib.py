@@ -41,8 +41,8 @@ class Gather(C.Structure):
 
 
 class Adam(C.Structure):
-    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("amsgrad", C.c_int32), ("step", C.c_int64)]
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("step", C.c_int64), ("amsgrad", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float

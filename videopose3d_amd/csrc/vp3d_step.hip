@@ -299,22 +299,22 @@ int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* g
                    float* exp_avg_sq, float* max_exp_avg_sq, const vp3d_adam* h) {
   VP3D_REQUIRE(n > 0 && param && grad && exp_avg && exp_avg_sq && h, "adam_step: bad argument");
   VP3D_REQUIRE(h->step >= 1, "adam_step: step must be the 1-based count of this update (got %lld)", (long long)h->step);
-  VP3D_REQUIRE(h->beta1 >= 0.f && h->beta1 < 1.f && h->beta2 >= 0.f && h->beta2 < 1.f && h->eps >= 0.f,
+  VP3D_REQUIRE(h->beta1 >= 0.0 && h->beta1 < 1.0 && h->beta2 >= 0.0 && h->beta2 < 1.0 && h->eps >= 0.0,
                "adam_step: bad hyper-parameters");
   VP3D_REQUIRE(!h->amsgrad || max_exp_avg_sq, "adam_step: amsgrad needs max_exp_avg_sq");
   VP3D_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq) &&
                    (!h->amsgrad || aligned16(max_exp_avg_sq)), "adam_step: buffers must be 16-byte aligned");
   // torch/optim/adam.py (_single_tensor_adam): python-float (double) scalars, applied to fp32 tensors
-  const double bc1 = 1.0 - pow((double)h->beta1, (double)h->step);
-  const double bc2 = 1.0 - pow((double)h->beta2, (double)h->step);
+  const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
+  const double bc2 = 1.0 - pow(h->beta2, (double)h->step);
   AdamK k;
-  k.one_minus_b1 = (float)(1.0 - (double)h->beta1);
-  k.b2 = h->beta2;
-  k.one_minus_b2 = (float)(1.0 - (double)h->beta2);
-  k.step_size = (float)((double)h->lr / bc1);
+  k.one_minus_b1 = (float)(1.0 - h->beta1);
+  k.b2 = (float)h->beta2;
+  k.one_minus_b2 = (float)(1.0 - h->beta2);
+  k.step_size = (float)(h->lr / bc1);
   k.bc2_sqrt = (float)sqrt(bc2);
-  k.eps = h->eps;
-  k.wd = h->weight_decay;
+  k.eps = (float)h->eps;
+  k.wd = (float)h->weight_decay;
   const int64_t n4 = (n + 3) / 4;
   const int blocks = grid_for(n4, 256, 256 * 8);
   if (h->amsgrad)

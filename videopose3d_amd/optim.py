@@ -71,11 +71,13 @@ class FlatAdam(torch.optim.Optimizer):
         dev = self._flat_p.device
         bufs = [torch.zeros(self._n, dtype=torch.float32, device=dev) for _ in range(3 if ams else 2)]
         self._state_bufs = bufs
-        self._step_t = torch.zeros((), dtype=torch.float32)       # torch.optim.Adam keeps `step` as a CPU fp32 tensor
-        for p, off in zip(self._ps, self._offs):
+        # torch.optim.Adam keeps `step` as one CPU fp32 0-dim tensor PER parameter (its foreach path increments each
+        # of them in place, so they must not alias); they are brought up to date in state_dict()
+        self._step_ts = [torch.zeros((), dtype=torch.float32) for _ in self._ps]
+        for p, off, step_t in zip(self._ps, self._offs, self._step_ts):
             n = p.numel()
             st = self.state[p]
-            st["step"] = self._step_t
+            st["step"] = step_t
             st["exp_avg"] = bufs[0][off:off + n].view_as(p)
             st["exp_avg_sq"] = bufs[1][off:off + n].view_as(p)
             if ams:
@@ -101,7 +103,16 @@ class FlatAdam(torch.optim.Optimizer):
         if len(steps) != 1:
             raise _lib.Vp3dError("FlatAdam: parameters carry different step counts %s" % sorted(steps))
         self._steps = steps.pop()
-        self._step_t.fill_(float(self._steps))
+        self._sync_step_tensors()
+
+    def _sync_step_tensors(self):
+        if self._state_bufs is not None:
+            for t in self._step_ts:
+                t.fill_(float(self._steps))
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = True):
         """Zeroes the flat gradient buffer; the .grad views are kept (set_to_none would detach them)."""
@@ -125,9 +136,8 @@ class FlatAdam(torch.optim.Optimizer):
                                      "optimizer.zero_grad() of this class, not set_to_none on the module)")
         self._ensure_state()
         self._steps += 1
-        self._step_t.fill_(float(self._steps))
         h = _lib.Adam(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                      float(g["weight_decay"]), 1 if g["amsgrad"] else 0, self._steps)
+                      float(g["weight_decay"]), self._steps, 1 if g["amsgrad"] else 0)
         bufs = self._state_bufs
         with torch.cuda.device(self._flat_p.device):
             check(_lib.lib().vp3d_adam_step(torch.cuda.current_stream().cuda_stream, self._n, self._flat_p.data_ptr(),
