@@ -148,6 +148,7 @@ def main():
     args = ap.parse_args()
 
     from videopose3d_amd import TemporalModel, TemporalModelOptimized1f, dp, ops
+    from videopose3d_amd import loss as vloss
     rank, world, local = dp.init_from_env("nccl")
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
@@ -164,7 +165,7 @@ def main():
 
     def step():
         sync.zero_grad()
-        loss = mpjpe(model(x), tgt)
+        loss = vloss.mpjpe(model(x), tgt)               # loss.py:11-17 on the HIP path (one kernel: value + gradient)
         loss.backward()
         sync.sync()
         return loss
@@ -232,16 +233,43 @@ def main():
         gemm_ms = sum(v["ms_per_step"] for v in kernels.values())
         out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
 
-        # ---- optimizer cost, outside the metric ---------------------------------------------------------
+        # ---- the callers either side of the stack, outside the metric -------------------------
+        def timed(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)      # run.py:252,264
-        opt.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            opt.step()
-        torch.cuda.synchronize()
-        out["adam_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        out["adam_torch_ms"] = timed(opt.step)
         del opt
+        from videopose3d_amd.optim import FlatAdam
+        from videopose3d_amd.generators import ChunkedGenerator
+        fopt = FlatAdam(model.parameters(), lr=1e-3, amsgrad=True, grad_sync=sync)
+        out["adam_ms"] = timed(fopt.step)                                       # vp3d_adam_step, one pass
+        rng = np.random.RandomState(0)
+        lens = [3000 + 517 * i for i in range(24)]                              # ~216k frames of synthetic "videos"
+        p2 = [rng.standard_normal((n, 17, 2)).astype(np.float32) for n in lens]
+        p3 = [rng.standard_normal((n, 17, 3)).astype(np.float32) for n in lens]
+        gen_dev = ChunkedGenerator(B, None, p3, p2, 1, pad=(RF - 1) // 2, shuffle=True, augment=True,
+                                   kps_left=[1, 3, 5, 7, 9, 11, 13, 15], kps_right=[2, 4, 6, 8, 10, 12, 14, 16],
+                                   joints_left=[4, 5, 6, 11, 12, 13], joints_right=[1, 2, 3, 14, 15, 16], device=dev)
+        it = gen_dev.next_epoch()
+        out["batch_gather_ms"] = timed(lambda: next(it), n=10)                  # vp3d_gather_chunks, B=1024 x 243 frames
+
+        def full_step():
+            _, b3, b2 = next(it)
+            b3[:, :, 0] = 0                                                     # run.py:407
+            fopt.zero_grad()
+            vloss.mpjpe(model(b2), b3).backward()
+            fopt.step()
+        ms_full = timed(full_step, n=10)
+        out["full_step"] = {"what": "device batch assembly + fwd + bwd + fused Adam (run.py:401-420 end to end), B=1024",
+                            "ms": ms_full, "frames_per_s": B / ms_full * 1e3}
+        del fopt, gen_dev, it
 
     del model, sync
     torch.cuda.empty_cache()

@@ -62,6 +62,43 @@ def _worker(rank, world, port, out_dir):
     sync.zero_grad()
     assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in m.parameters())
 
+    # overlapped exchange: flat layout in backward-completion order, buckets all-reduced as the engine reports groups
+    big = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=64)
+    bs = dp.FlatGradSync(big.parameters(), direct_module=big, bucket_bytes=40000)
+    groups = big.backward_param_groups()
+    assert [id(p) for p in bs.params] == [id(p) for g in groups for p in g]
+    assert len(bs.buckets) >= 2 and bs.buckets[-1][2] == bs.numel and bs.buckets[0][1] == 0
+    assert all(a[2] == b[1] for a, b in zip(bs.buckets, bs.buckets[1:]))           # contiguous cover
+    assert big.__dict__["_vp3d_grad_sink"] is bs
+    for weighted in (False, True):
+        counts = [5, 3]
+        if weighted:
+            bs.zero_grad(local_count=counts[rank], global_count=sum(counts))
+        else:
+            bs.zero_grad()
+        for k, g in enumerate(groups):                  # what engine.backward_train does: write, then report
+            for p in g:
+                bs.view_for(p).add_(float(rank + 1) * (k + 1))
+            launched_before = bs._launched
+            bs.group_done(k)
+            assert bs._launched >= launched_before
+        assert bs._launched == len(bs.buckets) and len(bs._handles) == len(bs.buckets)
+        bs.sync()
+        assert not bs._handles
+        for k, g in enumerate(groups):
+            if weighted:
+                expect = (k + 1) * sum((r_ + 1) * c for r_, c in enumerate(counts)) / sum(counts)
+            else:
+                expect = (k + 1) * sum(range(1, world + 1)) / world
+            for p in g:
+                assert torch.allclose(p.grad, torch.full_like(p, expect)), (weighted, k)
+    # a backward that never reports groups (plain autograd accumulation) still gets one whole-buffer all-reduce
+    bs.zero_grad()
+    for p in big.parameters():
+        p.grad.add_(float(rank + 1))
+    bs.sync()
+    assert torch.allclose(bs.flat[:10], torch.full((10,), sum(range(1, world + 1)) / world))
+
     # batch sharding of an identically-seeded generator permutation (generators.py:89-104)
     perm = np.random.RandomState(1234).permutation(1000)
     batch = perm[:257]                                                   # odd-sized global batch

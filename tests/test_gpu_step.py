@@ -312,3 +312,43 @@ def test_fused_training_loop_vs_reference_golden():
     with torch.no_grad():
         y = ev(_t(g["x_eval"]))
     assert mpjpe_np(_np(y), g["y_eval"]) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# overlapped gradient exchange: RCCL plumbing on one GPU (world 1: the all-reduce is the identity)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(300)
+def test_overlapped_bucket_exchange_through_rccl_single_rank():
+    import os
+    import socket
+    import torch.distributed as dist
+    import videopose3d_amd as V
+    from videopose3d_amd import dp
+    from videopose3d_amd.loss import mpjpe
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(9)
+        a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.0, channels=256).to(DEV).train()
+        b = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.0, channels=256).to(DEV).train()
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(32, 27, 17, 2, device=DEV)
+        tgt = torch.randn(32, 1, 17, 3, device=DEV)
+        mpjpe(a(x), tgt).backward()
+        sync = dp.FlatGradSync(b.parameters(), direct_module=b, bucket_bytes=1 << 20, always_reduce=True)
+        assert len(sync.buckets) >= 2
+        for _ in range(2):
+            sync.zero_grad()
+            mpjpe(b(x), tgt).backward()
+            assert len(sync._handles) == len(sync.buckets)       # every bucket was launched DURING backward
+            sync.sync()
+            torch.cuda.synchronize()
+        for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), k
+    finally:
+        dist.destroy_process_group()

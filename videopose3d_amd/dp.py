@@ -66,23 +66,59 @@ def flat_layout(params: Sequence[torch.Tensor], align: int = FLAT_ALIGN) -> Tupl
 
 class FlatGradSync:
     """Keeps every parameter's ``.grad`` as a view into ONE contiguous fp32 buffer so that the gradient exchange
-    is a single large all-reduce (xGMI rings are per-link bound: few large messages, not many small ones)."""
+    is a few large all-reduces (xGMI rings are per-link bound: few large messages, not many small ones).
+
+    With ``direct_module`` (a videopose3d_amd model) the flat buffer is laid out in the order in which the hand-written
+    backward FINISHES the gradients (shrink, last block, ..., first block, expand) and cut into buckets of
+    >= ``bucket_bytes``; the engine reports every finished group (``group_done``) and each complete bucket is
+    all-reduced asynchronously (RCCL runs it on its own stream) while backward keeps computing the earlier layers:
+    for arc 3,3,3,3,3 the last three blocks (50 MB of the 67.8 MB) are exchanged underneath the two M = 27,648
+    layers that hold 60 % of the backward FLOPs; only the expand layer's 0.4 MB is exposed."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], world: Optional[int] = None, group=None,
-                 direct_module: Optional[torch.nn.Module] = None):
-        """direct_module: a videopose3d_amd model whose backward should WRITE its conv-weight gradients straight
-        into the flat buffer (no autograd accumulation pass).  Requires zero_grad() before every backward; gradient
-        accumulation over several backward passes is then not supported for those tensors."""
-        self.params = [p for p in params if p.requires_grad]
-        assert self.params, "no trainable parameters"
+                 direct_module: Optional[torch.nn.Module] = None, bucket_bytes: int = 16 << 20,
+                 always_reduce: bool = False):
+        """direct_module: a videopose3d_amd model whose backward should WRITE its gradients straight into the flat
+        buffer (no autograd accumulation pass) and report finished groups for the overlapped exchange.  Requires
+        zero_grad() before every backward; gradient accumulation over several backward passes is then not supported.
+        always_reduce: issue the collectives even when world == 1 (tests of the RCCL plumbing on one GPU)."""
+        plist = [p for p in params if p.requires_grad]
+        assert plist, "no trainable parameters"
+        self._group_sizes: List[int] = []
+        if direct_module is not None and hasattr(direct_module, "backward_param_groups"):
+            groups = [[p for p in g if p.requires_grad] for g in direct_module.backward_param_groups()]
+            ordered = [p for g in groups for p in g]
+            if {id(p) for p in ordered} == {id(p) for p in plist} and len(ordered) == len(plist):
+                plist = ordered
+                self._group_sizes = [len(g) for g in groups]
+        self.params = plist
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params)
         self.offsets, self.numel = flat_layout(self.params)      # numel includes the alignment padding (zeros)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self._reduce = self.world > 1 or always_reduce
         self._attach()
         self._views = {id(p): p.grad for p in self.params}
+        # buckets: [first_group, last_group] -> flat range; merge consecutive backward groups up to bucket_bytes
+        self.buckets: List[Tuple[int, int, int]] = []            # (last_group, lo, hi) in flat elements
+        if self._group_sizes:
+            esz = self.flat.element_size()
+            starts, k = [], 0
+            for n in self._group_sizes:
+                starts.append(self.offsets[k])
+                k += n
+            starts.append(self.numel)
+            lo_g = 0
+            for g in range(len(self._group_sizes)):
+                if (starts[g + 1] - starts[lo_g]) * esz >= bucket_bytes or g == len(self._group_sizes) - 1:
+                    self.buckets.append((g, starts[lo_g], starts[g + 1]))
+                    lo_g = g + 1
+        self._done = 0               # groups finished in the current backward
+        self._launched = 0           # buckets already handed to the collective
+        self._handles = []
+        self._weight = None          # local_count / global_count of the current step (short last batch)
         if direct_module is not None:
             direct_module.__dict__["_vp3d_grad_sink"] = self
 
@@ -95,12 +131,18 @@ class FlatGradSync:
         for p, off in zip(self.params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
 
-    def zero_grad(self):
-        """Use instead of optimizer.zero_grad(set_to_none=True), which would detach the views."""
+    def zero_grad(self, local_count: Optional[int] = None, global_count: Optional[int] = None):
+        """Use instead of optimizer.zero_grad(set_to_none=True), which would detach the views.  Starts a new step:
+        pass the local / global sample counts of a short last batch here (each rank's mean-loss gradient is then
+        re-weighted by local_count/global_count before it is summed)."""
+        assert not self._handles, "zero_grad() while a gradient exchange is in flight: call sync() first"
         self.flat.zero_()
         if any(p.grad is None for p in self.params):
             self._attach()
             self._views = {id(p): p.grad for p in self.params}
+        self._done = self._launched = 0
+        self._weight = (float(local_count) / float(global_count)) if (local_count is not None and
+                                                                       global_count is not None) else None
 
     def broadcast_parameters(self, buffers: Iterable[torch.Tensor] = ()):
         """Make every replica start from rank 0's weights (and BN buffers)."""
@@ -108,16 +150,47 @@ class FlatGradSync:
             for t in list(self.params) + list(buffers):
                 dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=0, group=self.group)
 
+    # ---- overlapped exchange ---------------------------------------------------------------------------
+    def _launch(self, lo: int, hi: int):
+        seg = self.flat[lo:hi]
+        if self._weight is not None:
+            seg.mul_(self._weight)
+        self._handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def group_done(self, k: int):
+        """Called by the engine's backward when every gradient of backward group k has been written."""
+        if not self._reduce or not self.buckets:
+            return
+        self._done = max(self._done, k + 1)
+        while self._launched < len(self.buckets) and self.buckets[self._launched][0] < self._done:
+            _, lo, hi = self.buckets[self._launched]
+            self._launch(lo, hi)
+            self._launched += 1
+
     def sync(self, local_count: Optional[int] = None, global_count: Optional[int] = None):
-        """Sum-all-reduce the flat gradients and turn the sum into the global-batch mean.
+        """Finish the sum-all-reduce of the flat gradients and turn the sum into the global-batch mean.
 
         With equal per-rank batch sizes the result is sum/world.  For the short last batch pass the local and
-        global sample counts: each rank's mean-loss gradient is re-weighted by local_count/global_count."""
-        if self.world == 1:
+        global sample counts (here, or to zero_grad() when the overlapped exchange is used): each rank's
+        mean-loss gradient is re-weighted by local_count/global_count."""
+        if not self._reduce:
             return
         if local_count is not None and global_count is not None:
-            self.flat.mul_(float(local_count) / float(global_count))
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            w = float(local_count) / float(global_count)
+            assert self._launched == 0 or self._weight == w, \
+                "buckets were already exchanged during backward: pass the sample counts to zero_grad() instead"
+            self._weight = w
+        if self._launched == 0:
+            self._launch(0, self.numel)                      # nothing overlapped: one whole-buffer all-reduce
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            while self._launched < len(self.buckets):        # groups the backward did not report (none in practice)
+                _, lo, hi = self.buckets[self._launched]
+                self._launch(lo, hi)
+                self._launched += 1
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self._weight is None:
             self.flat.div_(self.world)
+        self._done = self._launched = 0
+        self._weight = None

@@ -168,6 +168,15 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
     dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
     grads = [None] * (3 * len(L))
+    n_done = [0]
+
+    def group_done():
+        # model.backward_param_groups() order: the sink may start exchanging a finished bucket right away
+        if sink is not None:
+            sink.group_done(n_done[0])
+        n_done[0] += 1
+
+    group_done()                                     # shrink
 
     def act_bwd(idx, go):
         s = L[idx]
@@ -189,9 +198,11 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         del dy2
         dy1 = act_bwd(i1, da1)
         del da1
+        group_done()                                 # block i: both convs' gradients are written
         dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].t_in, residual=(dh, plan.res[i]))
         del dy1
     dy0 = act_bwd(0, dh)
+    group_done()                                     # expand
     dx = None
     if need_dx:
         wt0 = L[0].wt if not L[0].kpad else ops.pack_weight(mod.expand_conv.weight.detach())

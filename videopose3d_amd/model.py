@@ -76,6 +76,17 @@ class TemporalModelBase(nn.Module):
         """Asymmetric offset for sequence padding (value reproduced as the reference computes it)."""
         return self._plan.total_causal_shift()
 
+    def backward_param_groups(self):
+        """Parameters grouped in the order in which engine.backward_train finishes their gradients (shrink, last
+        block ... first block, expand): the bucket order of dp.FlatGradSync's overlapped gradient exchange."""
+        groups = [[self.shrink.weight, self.shrink.bias]]
+        for i in reversed(range(len(self.layers_conv) // 2)):
+            groups.append([self.layers_conv[2 * i + 1].weight, self.layers_bn[2 * i + 1].weight,
+                           self.layers_bn[2 * i + 1].bias, self.layers_conv[2 * i].weight,
+                           self.layers_bn[2 * i].weight, self.layers_bn[2 * i].bias])
+        groups.append([self.expand_conv.weight, self.expand_bn.weight, self.expand_bn.bias])
+        return groups
+
     # ---- dropout stream ---------------------------------------------------------------------------------
     def _next_dropout_state(self):
         if self._drop_seed is None:

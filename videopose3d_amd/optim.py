@@ -39,6 +39,12 @@ class FlatAdam(torch.optim.Optimizer):
         ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
         if not ps:
             raise _lib.Vp3dError("FlatAdam: no trainable parameters")
+        if grad_sync is not None:
+            # the ONE elementwise pass needs parameters, gradients and state in the same flat order: adopt the
+            # gradient buffer's (backward-completion) order
+            if {id(p) for p in grad_sync.params} != {id(p) for p in ps} or len(grad_sync.params) != len(ps):
+                raise _lib.Vp3dError("FlatAdam: grad_sync was built over a different parameter set")
+            ps = list(grad_sync.params)
         dev = ps[0].device
         if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
             raise _lib.Vp3dError("FlatAdam needs fp32 parameters on one GPU (move the model with .cuda() first, "
@@ -54,8 +60,6 @@ class FlatAdam(torch.optim.Optimizer):
             self._flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self._flat_p[off:off + n].view_as(p)
         if grad_sync is not None:
-            if [id(p) for p in grad_sync.params] != [id(p) for p in ps]:
-                raise _lib.Vp3dError("FlatAdam: grad_sync was built over a different parameter list")
             self._sync = grad_sync
         else:
             self._sync = FlatGradSync(ps, world=1)
