@@ -12,6 +12,7 @@ with act = dropout(relu(bn(.))).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -143,9 +144,35 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     return out, dict(layers=saved, h_last=h, wts=ops.pack_weight(mod.shrink.weight.detach()), x3=x3)
 
 
+_side_streams = {}
+
+
+def _wgrad_stream(device) -> Optional[torch.cuda.Stream]:
+    """Second HIP stream for the weight-gradient GEMMs of backward: opt-in (VP3D_OVERLAP=1), never under bench.py's
+    per-kernel event instrumentation.  Measured on MI355X (gpurun_out b9/b10, B=1024): forking wgrad next to its own
+    dgrad is neutral (10.39 vs 10.34 ms/step: two fp32-MFMA GEMMs just split the matrix pipes), forking it under the
+    next layer's HBM-bound BN-backward kernels costs 1.3 % (10.47 ms) -- the streaming kernels and the GEMM's
+    L2-miss traffic contend for the fabric -- so the serial order stays the default."""
+    if os.environ.get("VP3D_OVERLAP", "0") != "1" or ops._prof is not None:
+        return None
+    key = torch.device(device).index
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
-    """Gradients in the order of ``param_list`` (+ optional input gradient)."""
+    """Gradients in the order of ``param_list`` (+ optional input gradient).
+
+    Optional second HIP stream (VP3D_OVERLAP=1, see _wgrad_stream): the dependent chain (BN/ReLU/dropout backward ->
+    dgrad -> next layer) stays on the caller's stream and every wgrad GEMM (+ its split reduction), which has no
+    consumer inside backward, is forked onto the second stream after its layer's dgrad has been queued."""
     plan: StackPlan = mod._plan
+    main = torch.cuda.current_stream()
+    side = _wgrad_stream(gout3.device)
+    keep = []                                        # operands the side stream still reads: alive until the join
     L: List[_Saved] = saved["layers"]
     h_last = saved["h_last"]
     b, t_out, _ = h_last.shape
@@ -171,14 +198,20 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     n_done = [0]
 
     def group_done():
-        # model.backward_param_groups() order: the sink may start exchanging a finished bucket right away
+        # model.backward_param_groups() order: the sink may start exchanging a finished bucket right away; the
+        # group's last gradients are produced on the wgrad stream, so that is the stream the collective must follow
         if sink is not None:
-            sink.group_done(n_done[0])
+            if side is not None and n_done[0] > 0:
+                with torch.cuda.stream(side):
+                    sink.group_done(n_done[0])
+            else:
+                sink.group_done(n_done[0])
         n_done[0] += 1
 
     group_done()                                     # shrink
 
     def act_bwd(idx, go):
+        """BN/ReLU/dropout backward of layer idx on the caller's stream; returns dy and the deferred wgrad launch."""
         s = L[idx]
         o_g, o_bt = view(bns[idx].weight), view(bns[idx].bias)
         if o_g is None or o_bt is None:
@@ -186,27 +219,49 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt)
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
-        out = view(convs[idx].weight)
-        dw = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad, out=out)
-        grads[3 * idx] = sunk(dw, out)
-        return dy
+
+        def wgrad():
+            # Forked AFTER this layer's dgrad has been queued on `main`: the wgrad GEMM then starts when that dgrad
+            # ends and runs underneath the next layer's HBM-bound BN-backward kernels (and shares the matrix pipes
+            # with the next dgrad, filling its under-filled tail) instead of splitting the pipes with its own dgrad.
+            out = view(convs[idx].weight)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    dw = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad, out=out)
+                if out is None:
+                    dw.record_stream(main)           # allocated on the side stream, consumed by autograd on `main`
+                keep.append((dy, s.x, dw))
+            else:
+                dw = ops.conv_wgrad(dy, s.x, plan.convs[idx], rows_kpad=s.kpad, out=out)
+            grads[3 * idx] = sunk(dw, out)
+
+        return dy, wgrad
 
     for i in reversed(range(plan.n_blocks)):
         i1, i2 = 1 + 2 * i, 2 + 2 * i
-        dy2 = act_bwd(i2, dh)
+        dy2, wgrad2 = act_bwd(i2, dh)
         da1 = ops.conv_dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].t_in)
+        wgrad2()
         del dy2
-        dy1 = act_bwd(i1, da1)
+        dy1, wgrad1 = act_bwd(i1, da1)
         del da1
-        group_done()                                 # block i: both convs' gradients are written
         dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].t_in, residual=(dh, plan.res[i]))
+        wgrad1()
+        group_done()                                 # block i: both convs' gradients are written (or queued)
         del dy1
-    dy0 = act_bwd(0, dh)
-    group_done()                                     # expand
+    dy0, wgrad0 = act_bwd(0, dh)
     dx = None
     if need_dx:
         wt0 = L[0].wt if not L[0].kpad else ops.pack_weight(mod.expand_conv.weight.detach())
         dx = ops.conv_dgrad(dy0, wt0, plan.convs[0], L[0].t_in)
+    wgrad0()
+    group_done()                                     # expand
+    if side is not None:
+        main.wait_stream(side)                       # join: every gradient is visible to the caller's stream
+        keep.clear()
     return grads + [d_sw, d_sb], dx
 
 
