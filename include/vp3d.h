@@ -102,10 +102,12 @@ const char* vp3d_last_error(void);
 
 /* number of 64-row statistic slabs a [M, *] output produces (size stat_sum / stat_m2 as slabs*N floats) */
 int64_t vp3d_stat_slabs(int64_t M);
-/* split-K factor vp3d_tconv_fwd / _dgrad would use for an [M,N,K] problem when given a workspace (1 = none):
- * small-M layers (the T_out = 1..3 tail) are K-sliced to fill the 256 CUs; size the workspace as
- * splits * M * ((N+3)&~3) floats */
+/* K-slicing vp3d_tconv_fwd / _dgrad apply to an [M,N,K] problem when given a workspace: the 128x128 tiles that do
+ * not fill a whole round of the 256 CUs (for the small-M layers of the T_out = 1..9 tail: every tile) are cut into
+ * K-slices that are dispatched last; vp3d_rows_gemm_splits returns the slice count (1 = none) and
+ * vp3d_rows_gemm_ws_floats the workspace size in floats (0 = none needed) */
 int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K);
+int64_t vp3d_rows_gemm_ws_floats(int64_t M, int32_t N, int32_t K);
 /* recommended `splits` for vp3d_tconv_wgrad (reduction over M rows into a [c_out, n_cols] matrix) */
 int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols);
 
@@ -114,7 +116,7 @@ int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols);
  *   wt : packed weights  wt[n*ldw + k*c_in + ci] == W[n][ci][k]   (vp3d_pack_weight, mode 0)
  *   y  : output rows at y[b*y_bpitch + t*ldy + n]
  *   zeros: >= 1024 B of device zeros (source for out-of-range taps / ragged tiles)
- *   splitk_ws: optional workspace (NULL = never split K), see vp3d_rows_gemm_splits */
+ *   splitk_ws: optional workspace of vp3d_rows_gemm_ws_floats(M, N, K) floats (NULL = never slice K) */
 int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t c_in,
                    const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
                    const vp3d_epilogue* epi, const float* zeros, float* splitk_ws, int64_t splitk_ws_floats);

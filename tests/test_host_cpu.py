@@ -118,5 +118,9 @@ def test_split_heuristics_bounds():
         s = h.vp3d_wgrad_splits(m, 1024, 3072)
         assert 1 <= s <= max(1, (m + 31) // 32)
     assert h.vp3d_wgrad_splits(27648, 1024, 3072) * 192 % 256 == 0      # whole 256-CU rounds on the big layer
-    assert h.vp3d_rows_gemm_splits(240640, 1024, 3072) == 1             # big forward GEMMs are never sliced
+    # big forward GEMMs: only the tiles that do not fill the last round of 2 x 256 workgroups are K-sliced
+    assert 0 < h.vp3d_rows_gemm_ws_floats(240640, 1024, 3072) <= 640 * 128 * 128
+    assert h.vp3d_rows_gemm_ws_floats(65536, 1024, 3072) == 0           # 4096 tiles = 8 whole rounds: nothing to slice
+    assert h.vp3d_rows_gemm_splits(65536, 1024, 3072) == 1
+    assert h.vp3d_rows_gemm_ws_floats(1024, 1024, 3072) == h.vp3d_rows_gemm_splits(1024, 1024, 3072) * 64 * 128 * 128
     assert h.vp3d_rows_gemm_splits(1024, 1024, 3072) > 1                # the T_out = 1 tail is

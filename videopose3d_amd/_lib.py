@@ -54,6 +54,7 @@ SIGNATURES = {
     "vp3d_last_error": (C.c_char_p, []),
     "vp3d_stat_slabs": (_i64, [_i64]),
     "vp3d_rows_gemm_splits": (C.c_int, [_i64, _i32, _i32]),
+    "vp3d_rows_gemm_ws_floats": (_i64, [_i64, _i32, _i32]),
     "vp3d_wgrad_splits": (C.c_int, [_i64, _i32, _i32]),
     "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
                                  _vp, _i64]),

@@ -57,17 +57,13 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   return VP3D_OK;
 }
 
-// split-K only when the caller handed a workspace big enough for splits*M*N partial floats
+// K-slicing only when the caller handed a workspace of vp3d_rows_gemm_ws_floats() (checked by launch_rows_gemm)
 static void set_splits(RowsGemmArgs* a, float* ws, int64_t ws_floats) {
   a->splits = 1;
   a->kt_per_split = 0;
-  a->part = nullptr;
-  if (ws == nullptr) return;
-  const int s = rows_gemm_splits(a->M, a->N, a->K);
-  if (s > 1 && ws_floats >= (int64_t)s * a->M * ((a->N + 3) & ~3) && aligned16(ws)) {
-    a->splits = s;
-    a->part = ws;
-  }
+  a->pos_full = a->tail_pos = 0;
+  a->part = ws;
+  a->part_floats = ws != nullptr ? ws_floats : 0;
 }
 
 static int check_map(const vp3d_rowmap* m, const char* who) {
@@ -91,6 +87,11 @@ int64_t vp3d_stat_slabs(int64_t M) { return (M + 63) / 64; }
 int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K) {
   if (M <= 0 || M >= ((int64_t)1 << 31) || N <= 0 || K <= 0) return 1;
   return rows_gemm_splits((int)M, N, K);
+}
+
+int64_t vp3d_rows_gemm_ws_floats(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || M >= ((int64_t)1 << 31) || N <= 0 || K <= 0) return 0;
+  return rows_gemm_ws_floats((int)M, N, K);
 }
 
 int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols) {

@@ -256,10 +256,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
 
   // XCD-aware tile order: workgroup id b runs on XCD b%8; give every XCD whole m-tiles (all their n-tiles
   // back to back) so the 8 column tiles of one activation row-panel share that XCD's L2.
-  const int split = blockIdx.y;            // split-K slice (grid.y == p.splits)
+  // Tail split: tile positions [0, pos_full) are whole tiles; the positions behind them (the last m-groups, i.e.
+  // the part of the tile count that does not fill a round of 2 workgroups x 256 CUs -- or, for the small-M layers,
+  // every tile) are cut into `splits` K-slices that are dispatched LAST and fill the CUs the whole tiles leave idle;
+  // their raw partial tiles go to the workspace and k_splitk_finish applies the epilogue.
   // Wide outputs (dgrad of a strided conv: N = 3C = 24 column tiles) are walked in groups of 8 column tiles so
   // that the ~64 workgroups an XCD runs concurrently form an 8x8 patch (8 A panels + 8 B panels in its 4 MiB L2).
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  int split = 0;
+  const bool tail = bid >= p.pos_full;     // block-uniform
+  if (tail) {
+    const int j = bid - p.pos_full;
+    split = j / p.tail_pos;                // slices of one K range are adjacent: they share operand panels in L2
+    bid = p.pos_full + (j - split * p.tail_pos);
+  }
   const int xcd = bid & 7, q = bid >> 3;
   const int gn = min(p.n_tiles, 8);
   const int m_groups = (p.m_tiles + 7) >> 3;
@@ -286,8 +296,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
   const int nkt_all = (p.K + BK - 1) / BK;
-  const int kt_begin = split * p.kt_per_split;
-  const int kt_end = min(nkt_all, kt_begin + p.kt_per_split);
+  const int kt_begin = tail ? split * p.kt_per_split : 0;
+  const int kt_end = tail ? min(nkt_all, kt_begin + p.kt_per_split) : nkt_all;
   const int nkt = max(0, kt_end - kt_begin);
 
   if (FAST) {
@@ -415,39 +425,52 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     }
   }
 
-  if (p.splits > 1) {
-    // split-K: raw partial tile to the workspace [split][M][N]; vp3d k_splitk_finish applies the epilogue
+  if (tail && p.splits > 1) {
+    // K-slice: raw 128x128 partial tile to the workspace [split][tail position][128][128]
     Epi e;
-    const int ldp = (p.N + 3) & ~3;
-    e.C = p.part + (int64_t)split * p.M * ldp;
+    e.C = p.part + ((int64_t)split * p.tail_pos + (bid - p.pos_full)) * (BM * BN);
     e.c_bpitch = 0;
-    e.ldc = ldp;
+    e.ldc = BN;
     e.bias = nullptr;
     e.relu = 0;
     e.R = nullptr;
     e.r_bpitch = 0;
     e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
     e.stat_sum = e.stat_m2 = nullptr;
-    e.vec = 1;                                   // workspace rows are 16-B aligned (ldp = N rounded up to 4)
-    epilogue<false>(e, acc, smem, m0, n0, wm, wn, tid, lane, p.M, ldp, nullptr, nullptr, 0);
+    e.vec = 1;                                   // workspace tiles are 16-B aligned
+    epilogue<false>(e, acc, smem, 0, 0, wm, wn, tid, lane, BM, BN, nullptr, nullptr, 0);
     return;
   }
   epilogue<true>(p.epi, acc, smem, m0, n0, wm, wn, tid, lane, p.M, p.N, tab_b, tab_t, tile_m * 2 + wm);
 }
 
-// Finish of a split-K rows GEMM: sum the partial tiles and apply the fused epilogue (bias / ReLU / residual /
-// 64-row-slab BatchNorm statistics).  One workgroup = one 64-row slab x 64 columns: thread (rg, cq) owns rows
-// rg, rg+16, rg+32, rg+48 of the slab and the float4 column group cq; 16-B loads, LDS reduction for the statistics.
-__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int splits, int M, int N,
-                                                       int ldp, int vec, int t_dst, const Epi e) {
+// Finish of the K-sliced tail tiles: sum the partial tiles and apply the fused epilogue (bias / ReLU / residual /
+// 64-row-slab BatchNorm statistics).  blockIdx.x = tail position, blockIdx.y = (64-row half, 64-column half) of its
+// tile: thread (rg, cq) owns rows rg, rg+16, rg+32, rg+48 of the slab and the float4 column group cq; 16-B loads,
+// LDS reduction for the statistics.
+__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int splits, int pos_full,
+                                                       int tail_pos, int m_tiles, int n_tiles, int M, int N, int vec,
+                                                       int t_dst, const Epi e) {
   __shared__ float red[16][64];
   __shared__ float mean_s[64];
-  const int slab = blockIdx.x;
+  // same position -> tile map as k_rows_gemm
+  const int bid = pos_full + blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int gn = min(n_tiles, 8);
+  const int m_groups = (m_tiles + 7) >> 3;
+  const int inner = q % gn, rest = q / gn;
+  const int tile_n = (rest / m_groups) * gn + inner;
+  const int tile_m = (rest % m_groups) * 8 + xcd;
+  if (tile_m >= m_tiles || tile_n >= n_tiles) return;
+  const int sh = blockIdx.y >> 1, ch = blockIdx.y & 1;
   const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
-  const int n = blockIdx.y * 64 + cq * 4;
-  const int m_base = slab * 64;
+  const int n = tile_n * BN + ch * 64 + cq * 4;
+  const int m_base = tile_m * BM + sh * 64;
+  const int slab = m_base >> 6;
   const int cnt = min(64, M - m_base);
-  const int64_t mat = (int64_t)M * ldp;           // ldp = N rounded up to 4: partial rows are 16-B aligned
+  if (cnt <= 0) return;
+  const int64_t mat = (int64_t)tail_pos * (BM * BN);        // floats between two K-slices
+  const float* tile = part + (int64_t)blockIdx.x * (BM * BN) + (sh * 64) * BN + ch * 64 + cq * 4;
   const bool nok = n < N;
   f32x4 raw[4];
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -456,7 +479,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
     const int r = rg + 16 * i;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (nok && r < cnt) {
-      const float* src = part + (int64_t)(m_base + r) * ldp + n;
+      const float* src = tile + r * BN;
       for (int sp = 0; sp < splits; ++sp) v += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * mat);
     }
     raw[i] = v;
@@ -471,30 +494,30 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
       mean_s[threadIdx.x] = t / (float)cnt;
-      const int nn = blockIdx.y * 64 + threadIdx.x;
+      const int nn = tile_n * BN + ch * 64 + threadIdx.x;
       if (nn < N) e.stat_sum[(int64_t)slab * N + nn] = t;
     }
     __syncthreads();
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (rg + 16 * i < cnt) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float d = raw[i][c] - mean_s[cq * 4 + c];
-          q[c] += d * d;
+          q2[c] += d * d;
         }
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = q[c];
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = q2[c];
     __syncthreads();
     if (threadIdx.x < 64) {
       float t = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
-      const int nn = blockIdx.y * 64 + threadIdx.x;
+      const int nn = tile_n * BN + ch * 64 + threadIdx.x;
       if (nn < N) e.stat_m2[(int64_t)slab * N + nn] = t;
     }
   }
@@ -675,28 +698,75 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
 
 }  // namespace
 
-int rows_gemm_splits(int M, int N, int K) {
-  // Layers whose 128x128 tile count does not fill (or badly quantises over) the 256 CUs are K-sliced.  Cost model
-  // in units of one K-tile of matrix-pipe time (~1.7 us): a CU retires its workgroups one block-time each
-  // (two co-resident workgroups share the pipe), every workgroup pays ~3 units of prologue/epilogue, and the
-  // finishing pass streams splits*M*N floats at ~4 TB/s.
-  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+// Tile positions of a rows GEMM (the k_rows_gemm order) and the K-sliced tail.
+//   slots = 512: two workgroups per CU share the matrix pipes; a tile that runs alone on its CU is ~1.6x faster
+//   than a co-resident one, so an under-filled last round costs less than its slot count suggests.
+RowsPlan plan_rows_gemm(int M, int N, int K) {
+  RowsPlan r;
+  const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+  const int gn = n_tiles < 8 ? n_tiles : 8;
+  const int m_groups = (m_tiles + 7) / 8, n_groups = (n_tiles + gn - 1) / gn;
+  const int chunk = 8 * gn;                                  // positions per m-group
+  r.positions = chunk * m_groups * n_groups;
+  r.pos_full = r.positions;
+  r.splits = 1;
+  const int64_t tiles = (int64_t)m_tiles * n_tiles;
   const int nkt = (K + BK - 1) / BK;
-  if (tiles > 1024 || nkt < 8) return 1;
-  double best = 1e30;
-  int best_s = 1;
-  for (int s = 1; s <= 8; ++s) {
-    if (s > 1 && nkt / s < 4) break;
-    const double rounds = (double)((tiles * s + 255) / 256);
-    double cost = rounds * ((double)((nkt + s - 1) / s) + 3.0);
-    if (s > 1) cost += 3.0 + (double)s * (double)M * (double)N * 4.0 / (4.0e6 * 1.7);
-    if (cost < best * 0.97) {           // prefer fewer slices unless clearly better
-      best = cost;
-      best_s = s;
+  if (nkt < 8) return r;
+  if (tiles <= 512) {
+    // the whole problem is at most one round: slice every tile (cost model in units of one K-tile of matrix-pipe
+    // time, ~1.7 us: a CU retires its workgroups one block-time each, every workgroup pays ~3 units of
+    // prologue/epilogue, the finishing pass streams splits*tiles partial tiles at ~4 TB/s)
+    double best = 1e30;
+    int best_s = 1;
+    for (int s = 1; s <= 8; ++s) {
+      if (s > 1 && nkt / s < 4) break;
+      const double rounds = (double)((tiles * s + 255) / 256);
+      double cost = rounds * ((double)((nkt + s - 1) / s) + 3.0);
+      if (s > 1) cost += 3.0 + (double)s * (double)M * (double)N * 4.0 / (4.0e6 * 1.7);
+      if (cost < best * 0.97) {           // prefer fewer slices unless clearly better
+        best = cost;
+        best_s = s;
+      }
     }
+    if (best_s > 1) {
+      r.pos_full = 0;
+      r.splits = best_s;
+    }
+    return r;
   }
-  return best_s;
+  const int rem = (int)(tiles % 512);
+  if (rem == 0) return r;
+  // tail = the last m-groups of the last column group, enough to hold the remainder
+  const int gn_last = n_tiles - (n_groups - 1) * gn;         // valid column tiles in the last column group
+  int tail_mg = 0, tail_tiles = 0;
+  for (int g = m_groups - 1; g >= 0 && tail_tiles < rem; --g) {
+    const int rows = (g == m_groups - 1) ? (m_tiles - 8 * (m_groups - 1)) : 8;
+    tail_tiles += rows * gn_last;
+    ++tail_mg;
+  }
+  int s = (512 + tail_tiles / 2) / tail_tiles;               // ~one round of slices
+  if (s > nkt / 4) s = nkt / 4;
+  if (s > 16) s = 16;
+  if (s < 2) return r;
+  // benefit: the idle share of the last round (a lone workgroup runs ~1.6x faster than a co-resident one);
+  // cost: the finishing pass (write + read of the partial tiles at ~4 TB/s) + one launch
+  const double t_tile_us = (double)nkt * 1.78 * 2.0;
+  const double benefit = 0.6 * (1.0 - (double)rem / 512.0) * t_tile_us;
+  const double cost = 8.0 + (double)tail_tiles * s * (BM * BN * 4.0) * 2.0 / 4.0e6;
+  if (benefit < 2.0 * cost) return r;
+  r.pos_full = r.positions - tail_mg * chunk;
+  r.splits = s;
+  return r;
 }
+
+int64_t rows_gemm_ws_floats(int M, int N, int K) {
+  const RowsPlan r = plan_rows_gemm(M, N, K);
+  if (r.splits <= 1) return 0;
+  return (int64_t)r.splits * (r.positions - r.pos_full) * (BM * BN);
+}
+
+int rows_gemm_splits(int M, int N, int K) { return plan_rows_gemm(M, N, K).splits; }
 
 int red_gemm_splits(int Mred, int Mo, int N) {
   // wgrad reduces over M rows into a [Mo, N] matrix (192 tiles for a 3-tap 1024x1024 conv): slice the reduction so
@@ -729,12 +799,19 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   RowsGemmArgs a = a_in;
   a.epi.vec = epi_vec_ok(a.epi, a.N);
   const int nkt = (a.K + BK - 1) / BK;
-  if (a.part == nullptr || a.splits < 1) a.splits = 1;
-  a.kt_per_split = (nkt + a.splits - 1) / a.splits;
-  const int m_groups = (a.m_tiles + 7) / 8;
-  const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
-  const int n_groups = (a.n_tiles + gn - 1) / gn;
-  const dim3 grid(8 * gn * m_groups * n_groups, a.splits), block(NTHREADS);
+  const RowsPlan plan = plan_rows_gemm(a.M, a.N, a.K);
+  a.pos_full = plan.positions;
+  a.tail_pos = 0;
+  a.splits = 1;
+  a.kt_per_split = nkt;
+  if (plan.splits > 1 && a.part != nullptr && aligned16(a.part) &&
+      a.part_floats >= (int64_t)plan.splits * (plan.positions - plan.pos_full) * (BM * BN)) {
+    a.pos_full = plan.pos_full;
+    a.tail_pos = plan.positions - plan.pos_full;
+    a.splits = plan.splits;
+    a.kt_per_split = (nkt + plan.splits - 1) / plan.splits;
+  }
+  const dim3 grid(a.pos_full + a.tail_pos * a.splits), block(NTHREADS);
   bool fast = (a.c_src % BK == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && aligned16(a.A) && aligned16(a.B) &&
               aligned16(a.zeros);
   if (!b_kcontig) fast = fast && (a.N % BN == 0) && (a.b_tap_stride % 4 == 0);
@@ -747,10 +824,8 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   }
   int rc = check_launch("rows_gemm");
   if (rc != VP3D_OK || a.splits == 1) return rc;
-  const dim3 fgrid((a.M + 63) / 64, (a.N + 63) / 64);
-  const int vec = a.epi.vec;
-  hipLaunchKernelGGL(k_splitk_finish, fgrid, dim3(256), 0, s, a.part, a.splits, a.M, a.N, (a.N + 3) & ~3, vec, a.t_dst,
-                     a.epi);
+  hipLaunchKernelGGL(k_splitk_finish, dim3(a.tail_pos, 4), dim3(256), 0, s, a.part, a.splits, a.pos_full, a.tail_pos,
+                     a.m_tiles, a.n_tiles, a.M, a.N, a.epi.vec, a.t_dst, a.epi);
   return check_launch("splitk_finish");
 }
 

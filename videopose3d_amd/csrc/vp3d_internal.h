@@ -47,8 +47,11 @@ struct RowsGemmArgs {
   int32_t ldb, b_tap_stride;   // NT: B[n*ldb + k];  NN: B[(k % c_src)*ldb + (k / c_src)*b_tap_stride + n]
   int32_t t_dst, t_src, t_stride, tap_step, t_off, taps;
   int32_t m_tiles, n_tiles;
-  int32_t splits, kt_per_split;   // split-K (rows GEMM): partial tiles go to `part`, k_splitk_finish sums them
+  // K-sliced tail (set by launch_rows_gemm from plan_rows_gemm): tile positions >= pos_full are cut into `splits`
+  // slices whose raw partial tiles go to `part` ([split][tail position][128][128]); k_splitk_finish sums them
+  int32_t pos_full, tail_pos, splits, kt_per_split;
   float* part;
+  int64_t part_floats;
   Epi epi;
 };
 
@@ -65,6 +68,13 @@ struct RedGemmArgs {
   int32_t m_tiles, n_tiles, splits, kt_per_split;
 };
 
+struct RowsPlan {
+  int positions;   // tile positions of the launch order (valid tiles + the padding of ragged m-/n-groups)
+  int pos_full;    // positions [0, pos_full) run as whole tiles
+  int splits;      // K-slices of the positions behind (1 = none)
+};
+RowsPlan plan_rows_gemm(int M, int N, int K);
+int64_t rows_gemm_ws_floats(int M, int N, int K);
 int rows_gemm_splits(int M, int N, int K);
 int red_gemm_splits(int Mred, int Mo, int N);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);

@@ -153,11 +153,11 @@ def im2row(x: torch.Tensor, spec: ConvSpec, kpad: int) -> torch.Tensor:
 
 
 def _splitk_ws(m, n, k, device):
-    s = _lib.lib().vp3d_rows_gemm_splits(m, n, k)
-    if s <= 1:
+    n_ws = _lib.lib().vp3d_rows_gemm_ws_floats(m, n, k)
+    if n_ws <= 0:
         return None, 0
-    ws = torch.empty((s * m * ((n + 3) // 4 * 4),), dtype=torch.float32, device=device)
-    return ws, ws.numel()
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=device)
+    return ws, n_ws
 
 
 def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, relu=False,
