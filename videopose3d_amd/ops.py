@@ -27,8 +27,8 @@ def set_profiler(records):
 
 
 class _Timed:
-    def __init__(self, family, flops):
-        self.family, self.flops = family, flops
+    def __init__(self, family, flops, nbytes=0.0):
+        self.family, self.flops, self.nbytes = family, flops, nbytes
 
     def __enter__(self):
         if _prof is not None:
@@ -40,7 +40,7 @@ class _Timed:
     def __exit__(self, *exc):
         if _prof is not None:
             self.e1.record()
-            _prof.append((self.family, self.flops, self.e0, self.e1))
+            _prof.append((self.family, self.flops, self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -111,8 +111,9 @@ def stat_buffers(m_rows: int, c: int, device) -> Tuple[torch.Tensor, torch.Tenso
 # --------------------------------------------------------------------------------------------------------
 # convolutions
 # --------------------------------------------------------------------------------------------------------
-def _timed_call(family, flops, fn, *args):
-    with _Timed(family, flops):
+def _timed_call(family, flops, fn, *args, nbytes=0.0):
+    """nbytes: algorithmic HBM bytes of the launch (every operand read once, the result written once)."""
+    with _Timed(family, flops, nbytes):
         check(fn(*args), fn.__name__)
 
 
@@ -190,7 +191,8 @@ def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, re
     _timed_call("tconv_fwd", 2.0 * m * spec.c_out * k, _lib.lib().vp3d_tconv_fwd,
                 _stream(), C.byref(rm), x.data_ptr(), c_in, c_src, wt.data_ptr(), wt.shape[1], spec.c_out,
                 out.data_ptr(), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
-                zeros_page(x.device).data_ptr(), _p(ws), ws_n)
+                zeros_page(x.device).data_ptr(), _p(ws), ws_n,
+                nbytes=4.0 * (x.numel() + wt.numel() + out.numel() + (out.numel() if residual is not None else 0)))
     return out
 
 
@@ -219,7 +221,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
         ws, ws_n = _splitk_ws(b * t_out, taps * c_in, c_out, dy.device)
         _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
                     _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0, taps * c_in,
-                    dx.data_ptr(), t_in * c_in, taps * c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n)
+                    dx.data_ptr(), t_in * c_in, taps * c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n,
+                    nbytes=4.0 * (dy.numel() + wt.numel() + dx.numel() + (residual[0].numel() if residual else 0)))
         return dx
     if spec.stride != 1:
         raise _lib.Vp3dError("conv_dgrad: stride %d with %d taps is not a configuration of the temporal model"
@@ -236,7 +239,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
     ws, ws_n = _splitk_ws(b * t_in, c_in, taps * c_out, dy.device)
     _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
                 _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in, c_in, dx.data_ptr(),
-                t_in * c_in, c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n)
+                t_in * c_in, c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n,
+                nbytes=4.0 * (dy.numel() + wt.numel() + dx.numel() + (residual[0].numel() if residual else 0)))
     return dx
 
 
@@ -276,7 +280,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: 
     part = dw if direct else torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dy.device)
     _timed_call("tconv_wgrad", 2.0 * m_rows * c_out * taps * c_in, _lib.lib().vp3d_tconv_wgrad,
                 _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, x.data_ptr(), ldx, c_x, part.data_ptr(), splits,
-                zeros_page(dy.device).data_ptr())
+                zeros_page(dy.device).data_ptr(), nbytes=4.0 * (dy.numel() + x.numel() + dw.numel()))
     if not direct:
         check(_lib.lib().vp3d_wgrad_reduce(_stream(), part.data_ptr(), n_cols, splits, c_out, c_in, taps,
                                            dw.data_ptr()), "vp3d_wgrad_reduce")
