@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 100
+#define VP3D_VERSION 101
 
 #define VP3D_OK 0
 #define VP3D_E_INVALID (-1)   /* bad argument (null pointer, size, alignment) */
@@ -66,6 +66,39 @@ typedef struct vp3d_rowmap {
   int32_t taps;
 } vp3d_rowmap;
 
+/* Counter-based dropout (Philox4x32-10): element e of layer `layer` is kept iff
+ * uniform(Philox(key=seed, counter=(e>>2, layer, offset))[e&3]) >= p; kept values are scaled by 1/(1-p).
+ * The mask is never stored: backward regenerates it from the same (seed, offset, layer). */
+typedef struct vp3d_dropout {
+  float p;
+  uint64_t seed;
+  uint64_t offset;
+  uint32_t layer;
+} vp3d_dropout;
+
+/* Backward of the UPSTREAM layer's activation a = dropout(relu(bn(y_up))) fused into the dgrad epilogue (vp3d_tconv_dgrad
+ * only; N % 128 == 0, c_stat % 4 == 0, 16-byte aligned float4 epilogue).  The value the epilogue would store,
+ * v = acc (+ residual scatter), IS that activation's incoming gradient, so the kernel also produces what
+ * vp3d_bn_bwd_reduce would compute in a separate pass over (v, y_up):
+ *   g = (y_up*scale + shift > 0) ? v * keep_scale : 0           -> g_out   (same addressing as the dgrad output)
+ *   per 64-row slab s of the output rows and column n:  sum g,  sum g*xhat,  xhat = (y_up - mean)*invstd
+ *     -> partials[((s * (N / c_stat) + n / c_stat) * 2 + {0,1}) * c_stat + n % c_stat]
+ *        = vp3d_bn_bwd_finalize's [nparts][2][C] layout with nparts = ceil(M/64) * (N / c_stat)
+ * (c_stat = channels of the upstream BatchNorm; N = taps*c_stat for the strided dgrad whose rows are 3 frames wide).
+ * store_v = 0: nobody else needs the raw gradient, it is not written (dx may then be NULL). */
+typedef struct vp3d_act_bwd {
+  const float* y_up;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const vp3d_dropout* drop; /* NULL: no dropout */
+  float* g_out;
+  float* partials;
+  int32_t c_stat;
+  int32_t store_v;
+} vp3d_act_bwd;
+
 /* Fused epilogue of the GEMM kernels (all parts optional; NULL / 0 = off).
  *   v = acc (+ bias[n]) ; if relu: v = max(v,0) ; v += residual ; C[b*c_bpitch + t*ldc + n] = v
  * residual row for output row (b,t): tr = t*r_stride + r_off, used iff 0 <= tr < r_t and
@@ -85,17 +118,8 @@ typedef struct vp3d_epilogue {
   int32_t r_cols;
   float* stat_sum;
   float* stat_m2;
+  const vp3d_act_bwd* act_bwd; /* dgrad only; NULL = off */
 } vp3d_epilogue;
-
-/* Counter-based dropout (Philox4x32-10): element e of layer `layer` is kept iff
- * uniform(Philox(key=seed, counter=(e>>2, layer, offset))[e&3]) >= p; kept values are scaled by 1/(1-p).
- * The mask is never stored: backward regenerates it from the same (seed, offset, layer). */
-typedef struct vp3d_dropout {
-  float p;
-  uint64_t seed;
-  uint64_t offset;
-  uint32_t layer;
-} vp3d_dropout;
 
 int vp3d_version(void);
 const char* vp3d_last_error(void);
@@ -181,6 +205,14 @@ int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials,
 int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                       const float* scale, const float* shift, const float* mean, const float* invstd,
                       const vp3d_dropout* drop, const float* dgamma, const float* dbeta, float* dy);
+
+/* the same with g = go*keep*[z>0] already formed (by the fused dgrad epilogue, vp3d_act_bwd):
+ * dy = scale*(g - dbeta/M - xhat*dgamma/M) */
+int vp3d_bn_bwd_apply_g(vp3d_stream_t stream, int64_t M, int32_t C, const float* g, const float* y,
+                        const float* scale, const float* mean, const float* invstd, const float* dgamma,
+                        const float* dbeta, float* dy);
+/* number of [2][c_stat] partial rows a fused vp3d_act_bwd epilogue writes for an [M, N] dgrad output */
+int64_t vp3d_act_bwd_parts(int64_t M, int32_t N, int32_t c_stat);
 
 /* out[n] = sum_m g[m*ld + n]   (bias gradient of the shrink conv) */
 int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int32_t ld, float* out);

@@ -22,14 +22,21 @@ class RowMap(C.Structure):
                 ("tap_step", C.c_int32), ("t_off", C.c_int32), ("taps", C.c_int32)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32)]
+
+
+class ActBwd(C.Structure):
+    _fields_ = [("y_up", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("drop", C.POINTER(Dropout)), ("g_out", C.c_void_p), ("partials", C.c_void_p),
+                ("c_stat", C.c_int32), ("store_v", C.c_int32)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("relu", C.c_int32), ("residual", C.c_void_p), ("r_bpitch", C.c_int64),
                 ("r_ld", C.c_int32), ("r_t", C.c_int32), ("r_stride", C.c_int32), ("r_off", C.c_int32),
-                ("r_col0", C.c_int32), ("r_cols", C.c_int32), ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p)]
-
-
-class Dropout(C.Structure):
-    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32)]
+                ("r_col0", C.c_int32), ("r_cols", C.c_int32), ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p),
+                ("act_bwd", C.POINTER(ActBwd))]
 
 
 class Gather(C.Structure):
@@ -70,6 +77,8 @@ SIGNATURES = {
     "vp3d_bn_bwd_reduce": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _P(_i32)]),
     "vp3d_bn_bwd_finalize": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "vp3d_bn_bwd_apply": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp]),
+    "vp3d_bn_bwd_apply_g": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_act_bwd_parts": (_i64, [_i64, _i32, _i32]),
     "vp3d_colsum": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
     "vp3d_dropout_mask": (C.c_int, [_vp, _i64, _P(Dropout), _vp]),
     "vp3d_project_to_2d_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp]),
@@ -104,8 +113,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 100:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (100); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 101:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (101); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

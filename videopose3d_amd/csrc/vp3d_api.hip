@@ -35,6 +35,11 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->r_ld = e->r_t = e->r_stride = e->r_off = e->r_col0 = e->r_cols = 0;
   e->stat_sum = e->stat_m2 = nullptr;
   e->vec = 0;
+  e->ab_y = e->ab_scale = e->ab_shift = e->ab_mean = e->ab_invstd = nullptr;
+  e->ab_g = e->ab_part = nullptr;
+  e->ab_c = 0;
+  e->ab_store_v = 1;
+  e->ab_drop = make_drop(nullptr);
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -54,6 +59,28 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   VP3D_REQUIRE((u->stat_sum == nullptr) == (u->stat_m2 == nullptr), "epilogue: stat_sum and stat_m2 go together");
   e->stat_sum = u->stat_sum;
   e->stat_m2 = u->stat_m2;
+  if (u->act_bwd != nullptr) {
+    const vp3d_act_bwd* ab = u->act_bwd;
+    VP3D_REQUIRE(ab->y_up && ab->scale && ab->shift && ab->mean && ab->invstd && ab->g_out && ab->partials,
+                 "epilogue: act_bwd has a null pointer");
+    VP3D_REQUIRE(ab->c_stat > 0 && ab->c_stat % 4 == 0 && n_cols % ab->c_stat == 0 && n_cols % 128 == 0,
+                 "epilogue: act_bwd needs c_stat %% 4 == 0, N %% c_stat == 0 and N %% 128 == 0 (c_stat=%d N=%d)",
+                 ab->c_stat, n_cols);
+    VP3D_REQUIRE(aligned16(ab->y_up) && aligned16(ab->g_out) && aligned16(ab->scale) && aligned16(ab->shift) &&
+                     aligned16(ab->mean) && aligned16(ab->invstd), "epilogue: act_bwd buffers must be 16-byte aligned");
+    VP3D_REQUIRE(ab->store_v == 0 || C != nullptr, "epilogue: act_bwd.store_v needs an output buffer");
+    if (ab->drop) VP3D_REQUIRE(ab->drop->p >= 0.f && ab->drop->p < 1.f, "epilogue: act_bwd dropout p=%f", ab->drop->p);
+    e->ab_y = ab->y_up;
+    e->ab_scale = ab->scale;
+    e->ab_shift = ab->shift;
+    e->ab_mean = ab->mean;
+    e->ab_invstd = ab->invstd;
+    e->ab_g = ab->g_out;
+    e->ab_part = ab->partials;
+    e->ab_c = ab->c_stat;
+    e->ab_store_v = ab->store_v;
+    e->ab_drop = make_drop(ab->drop);
+  }
   return VP3D_OK;
 }
 
@@ -94,6 +121,11 @@ int64_t vp3d_rows_gemm_ws_floats(int64_t M, int32_t N, int32_t K) {
   return rows_gemm_ws_floats((int)M, N, K);
 }
 
+int64_t vp3d_act_bwd_parts(int64_t M, int32_t N, int32_t c_stat) {
+  if (M <= 0 || N <= 0 || c_stat <= 0 || N % c_stat != 0) return 0;
+  return ((M + 63) / 64) * (N / c_stat);
+}
+
 int vp3d_wgrad_splits(int64_t M, int32_t c_out, int32_t n_cols) {
   if (M <= 0 || M >= ((int64_t)1 << 31) || c_out <= 0 || n_cols <= 0) return 1;
   return red_gemm_splits((int)M, c_out, n_cols);
@@ -126,6 +158,7 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
   a.taps = map->taps;
   a.m_tiles = (a.M + 127) / 128;
   a.n_tiles = (a.N + 127) / 128;
+  VP3D_REQUIRE(epi == nullptr || epi->act_bwd == nullptr, "tconv_fwd: act_bwd is a dgrad-only epilogue");
   rc = fill_epi(&a.epi, epi, y, y_bpitch, ldy, c_out);
   if (rc) return rc;
   set_splits(&a, splitk_ws, splitk_ws_floats);
@@ -138,7 +171,8 @@ int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* 
                      int64_t splitk_ws_floats) {
   int rc = check_map(map, "tconv_dgrad");
   if (rc) return rc;
-  VP3D_REQUIRE(dy && wt && dx && zeros, "tconv_dgrad: null pointer");
+  const bool g_only = epi != nullptr && epi->act_bwd != nullptr && epi->act_bwd->store_v == 0;
+  VP3D_REQUIRE(dy && wt && (dx || g_only) && zeros, "tconv_dgrad: null pointer");
   VP3D_REQUIRE(c_out > 0 && n_out > 0 && lddy >= c_out && ldw >= n_out && lddx >= n_out,
                "tconv_dgrad: bad sizes (c_out=%d n_out=%d lddy=%d ldw=%d lddx=%d)", c_out, n_out, lddy, ldw, lddx);
   RowsGemmArgs a;

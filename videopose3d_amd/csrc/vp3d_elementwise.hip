@@ -2,46 +2,12 @@
 // weight packing / BN folding, split-K reduction of wgrad, column sums, camera projection.
 // All streaming kernels move 16 B per lane (float4) when the channel count allows it (C % 4 == 0).
 #include "vp3d_internal.h"
+#include "vp3d_dropout.h"
 
 namespace vp3d {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011), counter-based: the dropout mask is a pure function of
-// (seed, offset, layer, element index) and is regenerated in backward instead of being stored.
-// ---------------------------------------------------------------------------------------------------------
-struct DropP {
-  float p, inv_keep;
-  uint32_t k0, k1, off_lo, layer;
-  int on;
-};
-
-__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                        uint32_t (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// keep*scale factors of the 4 elements 4*q .. 4*q+3
-__device__ __forceinline__ void drop4(const DropP& d, uint64_t q, float (&mk)[4]) {
-  uint32_t r[4];
-  philox4((uint32_t)q, (uint32_t)(q >> 32), d.layer, d.off_lo, d.k0, d.k1, r);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float u = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
-    mk[e] = (u >= d.p) ? d.inv_keep : 0.f;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics finalize (training): merge the GEMM's 64-row slab partials in fp64.
@@ -301,6 +267,46 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int M, int C, const float*
   }
 }
 
+// dy = scale*(g - dbeta/M - xhat*dgamma/M) with g already formed by the fused dgrad epilogue (no mask / ReLU work)
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_g(int M, int C, const float* __restrict__ g,
+                                                        const float* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                        float* __restrict__ dy, int lanes_per_row, int rows_per_block) {
+  const int lr = threadIdx.x % lanes_per_row;
+  const int rsub = threadIdx.x / lanes_per_row;
+  const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
+  if (rsub >= rows_per_block || c >= C) return;
+  const float inv_m = 1.0f / (float)M;
+  float sc[VEC], mu[VEC], is[VEC], kb[VEC], kg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc[e] = scale[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
+    kb[e] = dbeta[c + e] * inv_m;
+    kg[e] = dgamma[c + e] * inv_m;
+  }
+  const int row_step = gridDim.y * rows_per_block;
+#pragma unroll 2
+  for (int m = blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+    const int64_t e0 = (int64_t)m * C + c;
+    if (VEC == 4) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e0);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (yv[e] - mu[e]) * is[e];
+        o[e] = sc[e] * (gv[e] - kb[e] - xh * kg[e]);
+      }
+      *reinterpret_cast<f32x4*>(dy + e0) = o;
+    } else {
+      const float xh = (y[e0] - mu[0]) * is[0];
+      dy[e0] = sc[0] * (g[e0] - kb[0] - xh * kg[0]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------------------------------------
@@ -433,18 +439,6 @@ __global__ void __launch_bounds__(256) k_project_bwd(int64_t n_cam, int64_t ppc,
   }
 }
 
-inline DropP make_drop(const vp3d_dropout* d) {
-  DropP r;
-  r.on = (d != nullptr && d->p > 0.f) ? 1 : 0;
-  r.p = r.on ? d->p : 0.f;
-  r.inv_keep = r.on ? 1.0f / (1.0f - d->p) : 1.f;
-  r.k0 = r.on ? (uint32_t)d->seed : 0u;
-  r.k1 = r.on ? (uint32_t)(d->seed >> 32) : 0u;
-  r.off_lo = r.on ? (uint32_t)d->offset : 0u;
-  r.layer = r.on ? d->layer : 0u;
-  return r;
-}
-
 inline int stream_grid(int64_t work_items, int threads = 256) {
   int64_t blocks = (work_items + threads - 1) / threads;
   const int64_t cap = 256 * 8;   // 256 CUs x 8 blocks, grid-stride beyond
@@ -568,6 +562,23 @@ int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* g
     hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, dgamma, dbeta, dy, lpr, rpb);
   return check_launch("bn_bwd_apply");
+}
+
+int vp3d_bn_bwd_apply_g(vp3d_stream_t stream, int64_t M, int32_t C, const float* g, const float* y,
+                        const float* scale, const float* mean, const float* invstd, const float* dgamma,
+                        const float* dbeta, float* dy) {
+  VP3D_REQUIRE(M > 0 && C > 0 && g && y && scale && mean && invstd && dgamma && dbeta && dy, "bn_bwd_apply_g: bad argument");
+  VP3D_REQUIRE(M < ((int64_t)1 << 31), "bn_bwd_apply_g: more than 2^31 rows");
+  const bool vec = (C % 4 == 0) && aligned16(g) && aligned16(y) && aligned16(dy);
+  int lpr, rpb, gx, gy;
+  col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
+  if (vec)
+    hipLaunchKernelGGL((k_bn_bwd_apply_g<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
+                       invstd, dgamma, dbeta, dy, lpr, rpb);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply_g<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
+                       invstd, dgamma, dbeta, dy, lpr, rpb);
+  return check_launch("bn_bwd_apply_g");
 }
 
 int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,

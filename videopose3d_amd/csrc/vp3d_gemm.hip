@@ -177,36 +177,132 @@ __device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], char
 
   const int col = (tid & 31) * 4;
   const int n = n0 + col;
-  if (n >= N) return;
+  const bool fused = e.ab_y != nullptr;          // launcher guarantees: vec, N % 128 == 0 (no ragged columns, so
+  if (n >= N) return;                            // nobody leaves before the barriers of the fused reduction)
   const int rc = n - e.r_col0;
   if (e.vec) {       // N, ldc, pitches, r_col0/r_cols multiples of 4 and 16-B aligned bases (checked by the launcher)
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (e.bias != nullptr) bias = *reinterpret_cast<const f32x4*>(e.bias + n);
     const bool rcol_ok = e.R != nullptr && rc >= 0 && rc < e.r_cols;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int r = it * 8 + (tid >> 5);
-      const int m = m0 + r;
-      if (m >= M) continue;
-      int b, t;
-      if (HAS_TAB) {
-        b = tab_b[r];
-        t = tab_t[r];
-      } else {
-        b = 0;
-        t = m;
-      }
-      f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * BN + col) + bias;
-      if (e.relu) {
+    // fused activation backward of the upstream layer: per-column BN coefficients, per-half-tile partial sums
+    f32x4 a_sc, a_sh, a_mu, a_is;
+    f32x4 sg[2], sgx[2];
+    if (fused) {
+      const int ch = n % e.ab_c;
+      a_sc = *reinterpret_cast<const f32x4*>(e.ab_scale + ch);
+      a_sh = *reinterpret_cast<const f32x4*>(e.ab_shift + ch);
+      a_mu = *reinterpret_cast<const f32x4*>(e.ab_mean + ch);
+      a_is = *reinterpret_cast<const f32x4*>(e.ab_invstd + ch);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+      for (int hh = 0; hh < 2; ++hh) {
+        sg[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sgx[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (rcol_ok) {
-        const int tr = t * e.r_stride + e.r_off;
-        if ((unsigned)tr < (unsigned)e.r_t)
-          v += *reinterpret_cast<const f32x4*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc);
+    }
+    if (fused) {
+      // The 8 upstream-activation loads (and residual loads) of each 64-row half are issued up front: the fused
+      // epilogue is latency-bound otherwise (16 dependent global loads per thread), and an epilogue is only hidden
+      // while the co-resident workgroup is still in its main loop.  (8, not 16: 16 in flight spill registers.)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4 yv[8], rv[8];
+        int64_t offs[8];
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+          const int r = (hh * 8 + i8) * 8 + (tid >> 5);
+          const bool live = m0 + r < M;
+          const int b = HAS_TAB ? tab_b[r] : 0;
+          const int t = HAS_TAB ? tab_t[r] : m0 + r;
+          offs[i8] = live ? (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n : (int64_t)-1;
+          yv[i8] = f32x4{0.f, 0.f, 0.f, 0.f};
+          rv[i8] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (live) {
+            yv[i8] = *reinterpret_cast<const f32x4*>(e.ab_y + offs[i8]);
+            if (rcol_ok) {
+              const int tr = t * e.r_stride + e.r_off;
+              if ((unsigned)tr < (unsigned)e.r_t)
+                rv[i8] = *reinterpret_cast<const f32x4*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc);
+            }
+          }
+        }
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+          if (offs[i8] < 0) continue;
+          const int r = (hh * 8 + i8) * 8 + (tid >> 5);
+          f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * BN + col) + bias;
+          if (e.relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+          }
+          v += rv[i8];
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (e.ab_drop.on) drop4(e.ab_drop, (uint64_t)(offs[i8] >> 2), mk);
+          f32x4 g;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float z = fmaf(yv[i8][c], a_sc[c], a_sh[c]);
+            g[c] = z > 0.f ? v[c] * mk[c] : 0.f;
+            sg[hh][c] += g[c];
+            sgx[hh][c] += g[c] * ((yv[i8][c] - a_mu[c]) * a_is[c]);
+          }
+          *reinterpret_cast<f32x4*>(e.ab_g + offs[i8]) = g;
+          if (e.ab_store_v) *reinterpret_cast<f32x4*>(e.C + offs[i8]) = v;
+        }
       }
-      *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
+    } else {
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 8 + (tid >> 5);
+        const int m = m0 + r;
+        if (m >= M) continue;
+        int b, t;
+        if (HAS_TAB) {
+          b = tab_b[r];
+          t = tab_t[r];
+        } else {
+          b = 0;
+          t = m;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * BN + col) + bias;
+        if (e.relu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+        }
+        if (rcol_ok) {
+          const int tr = t * e.r_stride + e.r_off;
+          if ((unsigned)tr < (unsigned)e.r_t)
+            v += *reinterpret_cast<const f32x4*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc);
+        }
+        *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
+      }
+    }
+    if (fused) {
+      // column sums over the 8 row groups of each 64-row slab: LDS tree in the (now consumed) staging tile
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);   // [2 slabs][2 sums][8 row groups][128 cols]
+      const int rgp = tid >> 5;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          red[((hh * 2 + 0) * 8 + rgp) * BN + col + c] = sg[hh][c];
+          red[((hh * 2 + 1) * 8 + rgp) * BN + col + c] = sgx[hh][c];
+        }
+      __syncthreads();
+      const int hh = tid >> 7, cc = tid & (BN - 1);
+      if (m0 + hh * 64 < M) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+          t0 += red[((hh * 2 + 0) * 8 + g8) * BN + cc];
+          t1 += red[((hh * 2 + 1) * 8 + g8) * BN + cc];
+        }
+        const int nn = n0 + cc;
+        const int64_t slab = (int64_t)(m0 >> 6) + hh;
+        const int64_t p = slab * (N / e.ab_c) + nn / e.ab_c;
+        e.ab_part[(p * 2 + 0) * e.ab_c + nn % e.ab_c] = t0;
+        e.ab_part[(p * 2 + 1) * e.ab_c + nn % e.ab_c] = t1;
+      }
     }
   } else {
     for (int it = 0; it < 16; ++it) {
@@ -437,6 +533,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     e.r_bpitch = 0;
     e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
     e.stat_sum = e.stat_m2 = nullptr;
+    e.ab_y = nullptr;
     e.vec = 1;                                   // workspace tiles are 16-B aligned
     epilogue<false>(e, acc, smem, 0, 0, wm, wn, tid, lane, BM, BN, nullptr, nullptr, 0);
     return;
@@ -521,7 +618,17 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
       if (nn < N) e.stat_m2[(int64_t)slab * N + nn] = t;
     }
   }
+  const bool fused = e.ab_y != nullptr;          // launcher guarantees vec and N % 128 == 0 -> nok for everyone
   if (!nok) return;
+  f32x4 a_sc, a_sh, a_mu, a_is;
+  f32x4 sgv = {0.f, 0.f, 0.f, 0.f}, sgxv = {0.f, 0.f, 0.f, 0.f};
+  if (fused) {
+    const int chn = n % e.ab_c;
+    a_sc = *reinterpret_cast<const f32x4*>(e.ab_scale + chn);
+    a_sh = *reinterpret_cast<const f32x4*>(e.ab_shift + chn);
+    a_mu = *reinterpret_cast<const f32x4*>(e.ab_mean + chn);
+    a_is = *reinterpret_cast<const f32x4*>(e.ab_invstd + chn);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = rg + 16 * i;
@@ -542,7 +649,24 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
       }
       const int rc = n - e.r_col0;
       if (r_row_ok && rc >= 0 && rc < e.r_cols) v += *reinterpret_cast<const f32x4*>(rrow + n);
-      *reinterpret_cast<f32x4*>(crow + n) = v;
+      if (fused) {
+        const int64_t off = (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(e.ab_y + off);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (e.ab_drop.on) drop4(e.ab_drop, (uint64_t)(off >> 2), mk);
+        f32x4 g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float z = fmaf(yv[c], a_sc[c], a_sh[c]);
+          g[c] = z > 0.f ? v[c] * mk[c] : 0.f;
+          sgv[c] += g[c];
+          sgxv[c] += g[c] * ((yv[c] - a_mu[c]) * a_is[c]);
+        }
+        *reinterpret_cast<f32x4*>(e.ab_g + off) = g;
+        if (e.ab_store_v) *reinterpret_cast<f32x4*>(crow + n) = v;
+      } else {
+        *reinterpret_cast<f32x4*>(crow + n) = v;
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -554,6 +678,29 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
         if (r_row_ok && rc >= 0 && rc < e.r_cols) v += rrow[nn];
         crow[nn] = v;
       }
+    }
+  }
+  if (fused) {                                   // per-slab column sums over the 16 row groups (fixed order)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = sgv[c];
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t0 += red[g][threadIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = sgxv[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t1 += red[g][threadIdx.x];
+      const int nn = tile_n * BN + ch * 64 + threadIdx.x;
+      const int64_t p = (int64_t)slab * (N / e.ab_c) + nn / e.ab_c;
+      e.ab_part[(p * 2 + 0) * e.ab_c + nn % e.ab_c] = t0;
+      e.ab_part[(p * 2 + 1) * e.ab_c + nn % e.ab_c] = t1;
     }
   }
 }
@@ -692,6 +839,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
   e.r_bpitch = 0;
   e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
   e.stat_sum = e.stat_m2 = nullptr;
+  e.ab_y = nullptr;
   e.vec = (p.N % 4 == 0) ? 1 : 0;               // partial matrices are 16-B aligned allocations
   epilogue<false>(e, acc, smem, m0, n0, wm, wn, tid, lane, p.Mo, p.N, nullptr, nullptr, 0);
 }
@@ -798,6 +946,18 @@ static int epi_vec_ok(const Epi& e, int N) {
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
   RowsGemmArgs a = a_in;
   a.epi.vec = epi_vec_ok(a.epi, a.N);
+  if (a.epi.ab_y != nullptr) {
+    // with store_v == 0 the output pointer is unused (may be NULL): alignment is then judged on g_out
+    const bool ok = (a.epi.ab_store_v ? a.epi.vec : ((a.N % 4 == 0) && (a.epi.ldc % 4 == 0) && (a.epi.c_bpitch % 4 == 0) &&
+                                                     (a.epi.R == nullptr || (aligned16(a.epi.R) && a.epi.r_ld % 4 == 0 &&
+                                                                             a.epi.r_bpitch % 4 == 0 && a.epi.r_col0 % 4 == 0 &&
+                                                                             a.epi.r_cols % 4 == 0))));
+    if (!ok || a.N % BN != 0) {
+      set_error("rows_gemm: the fused act_bwd epilogue needs the float4 epilogue (N, pitches %% 4, 16-B aligned) and N %% 128 == 0");
+      return VP3D_E_UNSUPPORTED;
+    }
+    a.epi.vec = 1;
+  }
   const int nkt = (a.K + BK - 1) / BK;
   const RowsPlan plan = plan_rows_gemm(a.M, a.N, a.K);
   a.pos_full = plan.positions;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "vp3d.h"
+#include "vp3d_dropout.h"
 
 namespace vp3d {
 
@@ -34,6 +35,17 @@ struct Epi {
   float* stat_sum;
   float* stat_m2;
   int32_t vec;       // set by the launcher: float4 epilogue legal (sizes / pitches % 4, 16-B aligned bases)
+  // fused backward of the upstream activation (vp3d_act_bwd; ab_y == nullptr: off).  Addressing of ab_y / ab_g is
+  // that of C.  Partials per 64-row slab: ab_part[((slab * (N / ab_c) + n / ab_c) * 2 + which) * ab_c + n % ab_c].
+  const float* ab_y;
+  const float* ab_scale;
+  const float* ab_shift;
+  const float* ab_mean;
+  const float* ab_invstd;
+  float* ab_g;
+  float* ab_part;
+  int32_t ab_c, ab_store_v;
+  DropP ab_drop;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";

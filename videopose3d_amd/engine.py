@@ -190,10 +190,30 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     def sunk(value, out):
         return None if out is not None else value
 
+    # Optional (VP3D_FUSE_ACT_BWD=1 wherever legal, =auto on launches of >= 6 rounds of tiles): the dgrad epilogue that
+    # produces an activation's incoming gradient also runs that activation's backward reduction (vp3d_act_bwd):
+    # g = go*keep*[z>0] and the per-slab sums of g / g*xhat come out of the GEMM and the separate HBM pass of
+    # vp3d_bn_bwd_reduce disappears.  Measured on MI355X (B=1024 step): the pass it removes (0.27 ms) comes back as
+    # epilogue time of the compute-bound GEMM (+0.21 ms everywhere, +0.10 / -0.11 ms in auto mode): 10.19 / 10.17 vs
+    # 10.18 ms -- no gain, so the separate kernels stay the default.
+    fuse_mode = os.environ.get("VP3D_FUSE_ACT_BWD", "0")
+
+    def upstream(idx):
+        return (L[idx].y, L[idx].coef, L[idx].drop)
+
+    def dgrad(dy, wt, spec, t_in, up_idx, residual=None, need_raw=True):
+        """Returns (dx or None, FusedActBwd or None)."""
+        ok = fuse_mode != "0" and up_idx is not None and (
+            ops.can_fuse_act_bwd(spec, t_in) if fuse_mode == "1" else ops.should_fuse_act_bwd(spec, dy.shape[0], t_in))
+        if ok:
+            return ops.conv_dgrad(dy, wt, spec, t_in, residual=residual, act_bwd=upstream(up_idx), store_v=need_raw)
+        return ops.conv_dgrad(dy, wt, spec, t_in, residual=residual), None
+
     o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
     d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
     d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
-    dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
+    last = 2 * plan.n_blocks if plan.n_blocks else 0             # layer whose activation is the stack output
+    dh, f_dh = dgrad(gout3, saved["wts"], plan.shrink, t_out, last, need_raw=plan.n_blocks > 0)
     grads = [None] * (3 * len(L))
     n_done = [0]
 
@@ -210,20 +230,21 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
 
     group_done()                                     # shrink
 
-    def act_bwd(idx, go):
+    def act_bwd(idx, go, fused):
         """BN/ReLU/dropout backward of layer idx on the caller's stream; returns dy and the deferred wgrad launch."""
         s = L[idx]
         o_g, o_bt = view(bns[idx].weight), view(bns[idx].bias)
         if o_g is None or o_bt is None:
             o_g = o_bt = None
-        dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt)
+        if fused is not None:
+            dy, dgam, dbet = ops.bn_act_bwd_fused(fused, s.y, s.coef, out_dgamma=o_g, out_dbeta=o_bt)
+        else:
+            dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt)
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
 
         def wgrad():
-            # Forked AFTER this layer's dgrad has been queued on `main`: the wgrad GEMM then starts when that dgrad
-            # ends and runs underneath the next layer's HBM-bound BN-backward kernels (and shares the matrix pipes
-            # with the next dgrad, filling its under-filled tail) instead of splitting the pipes with its own dgrad.
+            # (optional second stream) forked AFTER this layer's dgrad has been queued on `main`
             out = view(convs[idx].weight)
             if side is not None:
                 ev = torch.cuda.Event()
@@ -242,17 +263,20 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
 
     for i in reversed(range(plan.n_blocks)):
         i1, i2 = 1 + 2 * i, 2 + 2 * i
-        dy2, wgrad2 = act_bwd(i2, dh)
-        da1 = ops.conv_dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].t_in)
+        dy2, wgrad2 = act_bwd(i2, dh, f_dh)
+        # gradient of u = act(i1): no residual joins it and nobody else reads it -> g only
+        da1, f1 = dgrad(dy2, L[i2].wt, plan.convs[i2], L[i2].t_in, i1, need_raw=False)
         wgrad2()
         del dy2
-        dy1, wgrad1 = act_bwd(i1, da1)
-        del da1
-        dh = ops.conv_dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].t_in, residual=(dh, plan.res[i]))
+        dy1, wgrad1 = act_bwd(i1, da1, f1)
+        del da1, f1
+        # gradient of the block input = output of block i-1 (activation of its second conv; layer 0 for i == 0);
+        # block i-1 also needs it raw, as the residual of its own dgrad
+        dh, f_dh = dgrad(dy1, L[i1].wt, plan.convs[i1], L[i1].t_in, 2 * i, residual=(dh, plan.res[i]), need_raw=i > 0)
         wgrad1()
         group_done()                                 # block i: both convs' gradients are written (or queued)
         del dy1
-    dy0, wgrad0 = act_bwd(0, dh)
+    dy0, wgrad0 = act_bwd(0, dh, f_dh)
     dx = None
     if need_dx:
         wt0 = L[0].wt if not L[0].kpad else ops.pack_weight(mod.expand_conv.weight.detach())

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import Dropout, Epilogue, RowMap, check
+from ._lib import ActBwd, Dropout, Epilogue, RowMap, check
 from .plan import ConvSpec, ResSpec
 
 _zero_pages = {}
@@ -196,9 +196,66 @@ def conv_fwd(x: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, *, bias=None, re
     return out
 
 
+def can_fuse_act_bwd(spec: ConvSpec, t_in: int) -> bool:
+    """The fused activation-backward epilogue of vp3d_tconv_dgrad needs full 128-column tiles of 16-B aligned rows
+    and, for the strided (plain-GEMM) form, windows that tile the input exactly (every dx row is written)."""
+    if spec.c_in % 128 != 0:
+        return False
+    if spec.stride == spec.taps and spec.dil == 1 and spec.taps > 1:
+        return spec.taps * spec.t_out(t_in) == t_in
+    return spec.stride == 1
+
+
+def should_fuse_act_bwd(spec: ConvSpec, batch: int, t_in: int) -> bool:
+    """Measured on MI355X (tools/fuse_bench.py): the fused epilogue is ~8 us per tile instead of ~2.5 us, which is
+    hidden while the co-resident workgroup is in its main loop -- but the two workgroups of a CU start together and
+    run in lockstep for the first rounds, so on launches of <= 3.4 rounds of tiles (1,728 tiles: +35 us) the fusion
+    costs what the separate reduction pass takes (41 us), while on the 5,184-tile dgrad that feeds the expand layer's
+    activation (85 M elements) it is free and removes a 121 us pass.  Fuse from 6 rounds of 512 tiles up."""
+    if not can_fuse_act_bwd(spec, t_in):
+        return False
+    strided = spec.stride == spec.taps and spec.dil == 1 and spec.taps > 1
+    m = batch * (spec.t_out(t_in) if strided else t_in)
+    n = spec.taps * spec.c_in if strided else spec.c_in
+    return ((m + 127) // 128) * ((n + 127) // 128) >= 3072
+
+
+class FusedActBwd:
+    """Result of a dgrad whose epilogue also ran the upstream activation's backward reduction (vp3d_act_bwd)."""
+    __slots__ = ("g", "parts")
+
+    def __init__(self, g, parts):
+        self.g, self.parts = g, parts
+
+
+def _act_bwd_struct(act_bwd, like_shape, n_cols, m_rows, device, store_v, keep):
+    """act_bwd = (y_up [B,T_in,C], coef [4,C], drop).  Returns (ActBwd struct, FusedActBwd)."""
+    y_up, coef, drop = act_bwd
+    _chk(y_up, "y_up")
+    assert tuple(y_up.shape) == tuple(like_shape), (y_up.shape, like_shape)
+    c = y_up.shape[2]
+    g = torch.empty_like(y_up)
+    nparts = _lib.lib().vp3d_act_bwd_parts(m_rows, n_cols, c)
+    parts = torch.empty((nparts, 2, c), dtype=torch.float32, device=device)
+    ab = ActBwd()
+    ab.y_up = y_up.data_ptr()
+    ab.scale, ab.shift, ab.mean, ab.invstd = (coef[i].data_ptr() for i in range(4))
+    ab.drop = C.pointer(drop) if drop is not None else None
+    ab.g_out = g.data_ptr()
+    ab.partials = parts.data_ptr()
+    ab.c_stat = c
+    ab.store_v = 1 if store_v else 0
+    keep.append(ab)
+    return ab, FusedActBwd(g, parts)
+
+
 def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
-               residual: Optional[Tuple[torch.Tensor, ResSpec]] = None) -> torch.Tensor:
-    """dx [B,T_in,C_in] = conv^T(dy) (+ scatter of the block's residual gradient).  wt is the forward pack."""
+               residual: Optional[Tuple[torch.Tensor, ResSpec]] = None, act_bwd=None, store_v: bool = True):
+    """dx [B,T_in,C_in] = conv^T(dy) (+ scatter of the block's residual gradient).  wt is the forward pack.
+
+    act_bwd = (y_up, coef, drop) of the layer whose activation produced this conv's input: the epilogue then also
+    forms g = dx*keep*[bn(y_up) > 0] and the per-slab sums of g and g*xhat (what vp3d_bn_bwd_reduce would do in a
+    separate pass) and the call returns (dx or None, FusedActBwd).  store_v=False: dx itself is not needed."""
     _chk(dy, "dy")
     _chk(wt, "wt")
     b, t_out, c_out = dy.shape
@@ -207,10 +264,18 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
     ldw = wt.shape[1]
     z = zeros_page(dy.device).data_ptr()
     flops = 2.0 * b * t_out * c_out * taps * c_in
+    keep = []
+    fused = None
+    want_dx = store_v or act_bwd is None
     if spec.stride == taps and spec.dil == 1 and taps > 1:
         # windows do not overlap: dx viewed as [B*T_out, taps*C_in] = dy @ Wt   (plain GEMM)
         covered = taps * t_out
-        dx = (torch.empty if covered == t_in else torch.zeros)((b, t_in, c_in), dtype=torch.float32, device=dy.device)
+        if act_bwd is not None and covered != t_in:
+            raise _lib.Vp3dError("conv_dgrad: the fused activation backward needs windows that tile the input exactly")
+        dx = None
+        if want_dx:
+            dx = (torch.empty if covered == t_in else torch.zeros)((b, t_in, c_in), dtype=torch.float32,
+                                                                    device=dy.device)
         rm = RowMap(b, t_out, t_out, 1, 0, 0, 1)
         res = None
         if residual is not None:
@@ -218,17 +283,21 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
             assert rs.step == taps and 0 <= rs.start < taps and r.shape == (b, t_out, c_in)
             res = (r, 1, 0, rs.start * c_in)
         e = _epi(residual=res, n_cols=taps * c_in)
+        if act_bwd is not None:
+            e = e if e is not None else Epilogue()
+            ab, fused = _act_bwd_struct(act_bwd, (b, t_in, c_in), taps * c_in, b * t_out, dy.device, want_dx, keep)
+            e.act_bwd = C.pointer(ab)
         ws, ws_n = _splitk_ws(b * t_out, taps * c_in, c_out, dy.device)
         _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
                     _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, 0, taps * c_in,
-                    dx.data_ptr(), t_in * c_in, taps * c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n,
-                    nbytes=4.0 * (dy.numel() + wt.numel() + dx.numel() + (residual[0].numel() if residual else 0)))
-        return dx
+                    _p(dx), t_in * c_in, taps * c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n,
+                    nbytes=4.0 * (dy.numel() + wt.numel() + b * t_in * c_in + (residual[0].numel() if residual else 0)))
+        return dx if act_bwd is None else (dx, fused)
     if spec.stride != 1:
         raise _lib.Vp3dError("conv_dgrad: stride %d with %d taps is not a configuration of the temporal model"
                              % (spec.stride, taps))
     # gather form: dx[b,s] = sum_k dy[b, s - k*dil] @ W_k^T
-    dx = torch.empty((b, t_in, c_in), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((b, t_in, c_in), dtype=torch.float32, device=dy.device) if want_dx else None
     rm = RowMap(b, t_in, t_out, 1, -spec.dil, 0, taps)
     res = None
     if residual is not None:
@@ -236,12 +305,16 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, spec: ConvSpec, t_in: int, *,
         assert rs.step == 1 and r.shape[0] == b and r.shape[2] == c_in
         res = (r, 1, -rs.start, 0)
     e = _epi(residual=res, n_cols=c_in)
+    if act_bwd is not None:
+        e = e if e is not None else Epilogue()
+        ab, fused = _act_bwd_struct(act_bwd, (b, t_in, c_in), c_in, b * t_in, dy.device, want_dx, keep)
+        e.act_bwd = C.pointer(ab)
     ws, ws_n = _splitk_ws(b * t_in, c_in, taps * c_out, dy.device)
     _timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tconv_dgrad,
-                _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in, c_in, dx.data_ptr(),
+                _stream(), C.byref(rm), dy.data_ptr(), c_out, c_out, wt.data_ptr(), ldw, c_in, c_in, _p(dx),
                 t_in * c_in, c_in, C.byref(e) if e is not None else None, z, _p(ws), ws_n,
-                nbytes=4.0 * (dy.numel() + wt.numel() + dx.numel() + (residual[0].numel() if residual else 0)))
-    return dx
+                nbytes=4.0 * (dy.numel() + wt.numel() + b * t_in * c_in + (residual[0].numel() if residual else 0)))
+    return dx if act_bwd is None else (dx, fused)
 
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, spec: ConvSpec, *, rows_kpad: int = 0,
@@ -377,6 +450,28 @@ def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Opti
     dy = torch.empty_like(y)
     check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
                               dbet.data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
+    return dy, dgam, dbet
+
+
+def bn_act_bwd_fused(fused: "FusedActBwd", y: torch.Tensor, coef: torch.Tensor,
+                     out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
+    """Second half of bn_act_bwd when the dgrad epilogue already produced g and the partial sums: finalize
+    (dgamma, dbeta) and apply dy = scale*(g - dbeta/M - xhat*dgamma/M).  Returns (dy, dgamma, dbeta)."""
+    _chk(y, "y")
+    b, t, c = y.shape
+    m = b * t
+    L = _lib.lib()
+    if out_dgamma is not None and out_dbeta is not None:
+        dgam, dbet = out_dgamma, out_dbeta
+    else:
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        dgam, dbet = dgb[0], dgb[1]
+    check(L.vp3d_bn_bwd_finalize(_stream(), c, fused.parts.data_ptr(), fused.parts.shape[0], dgam.data_ptr(),
+                                 dbet.data_ptr()), "vp3d_bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    check(L.vp3d_bn_bwd_apply_g(_stream(), m, c, fused.g.data_ptr(), y.data_ptr(), coef[0].data_ptr(),
+                                coef[2].data_ptr(), coef[3].data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+                                dy.data_ptr()), "vp3d_bn_bwd_apply_g")
     return dy, dgam, dbet
 
 
