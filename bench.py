@@ -176,9 +176,12 @@ def main():
 
     from videopose3d_amd import TemporalModel, TemporalModelOptimized1f, dp, ops
     from videopose3d_amd import loss as vloss
-    rank, world, local = dp.init_from_env("nccl")
+    # VP3D_DIST_BACKEND / VP3D_BENCH_DEVICE are test hooks: "gloo" + device 0 let the N > 1 control flow (matched
+    # collectives on every rank, no deadlock) be exercised on a box with a single GPU; the driver never sets them.
+    rank, world, local = dp.init_from_env(os.environ.get("VP3D_DIST_BACKEND", "nccl"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    local = int(os.environ.get("VP3D_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -229,7 +232,9 @@ def main():
         "step_frac_of_mfma_peak": FLOP_TRAIN_PER_FRAME * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
     }
 
-    if rank == 0:
+    # Everything below that runs training steps is executed by EVERY rank: a step contains collectives (the bucketed
+    # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.
+    if True:
         # ---- per-kernel-family roofline, measured live with HIP events on the launch stream -------------
         recs = []
         ops.set_profiler(recs)
@@ -297,6 +302,7 @@ def main():
             b3[:, :, 0] = 0                                                     # run.py:407
             fopt.zero_grad()
             vloss.mpjpe(model(b2), b3).backward()
+            sync.sync()                                                         # no-op for one GPU
             fopt.step()
         ms_full = timed(full_step, n=10)
         out["full_step"] = {"what": "device batch assembly + fwd + bwd + fused Adam (run.py:401-420 end to end), B=1024",
