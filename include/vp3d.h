@@ -145,6 +145,50 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
                    const float* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
                    const vp3d_epilogue* epi, const float* zeros, float* splitk_ws, int64_t splitk_ws_floats);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Split-fp16 ("S16") GEMM path: fp32-class results on the fp16 matrix cores.
+ * An S16 tensor keeps an fp32 value v as two fp16 numbers hi = fp16(v*2^-e), lo = fp16(v*2^-e - hi) (22+ significant
+ * bits; e = per-tensor exponent held in a device int32, NULL = 0).  8 consecutive elements of a row are stored as 16 B
+ * of hi followed by 16 B of lo: an S16 row has the byte geometry of the fp32 row it replaces (ld* stay in 4-byte
+ * units).  a*b is evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with fp32 accumulation.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* Extra arguments of the S16 GEMM.
+ *   x_bound / w_bound : device floats, guaranteed bounds of max|.| of the two operand tensors; their S16 exponent is
+ *                       e = frexp-exponent(bound) - 15 (so |v * 2^-e| < 2^15); NULL = exponent 0.  The accumulator is
+ *                       scaled by 2^(e_x + e_w) before the epilogue.
+ *   amax_out          : optional device float, atomically max-ed with |stored value| (the bound of the result for a
+ *                       consumer that re-splits it; zero it before the launch)
+ *   cfg               : tile configuration (0: 128x128 tiles / 4 waves, 4: 256x256 tiles / 8 waves, -1: planned)
+ *   splits            : K slices (1 = none, 0 = planned: vp3d_nt_s16_plan); > 1 needs ws of splits*M*N floats.
+ *                       The slices write raw scaled partial matrices [splits][M][N]; a finishing pass sums them and
+ *                       applies the epilogue -- unless raw_partials, where the partials ARE the result (wgrad:
+ *                       vp3d_wgrad_reduce sums them; y may be NULL). */
+typedef struct vp3d_s16 {
+  const float* x_bound;
+  const float* w_bound;
+  float* amax_out;
+  int32_t cfg;
+  int32_t splits;
+  float* ws;
+  int64_t ws_floats;
+  int32_t raw_partials;
+} vp3d_s16;
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t* cfg, int32_t* splits);
+/* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form
+ * (c_in % 32 == 0, 16-byte aligned rows, ldx / ldw in 4-byte units).  Every GEMM of the model runs through it:
+ *   forward : wt = S16 of the packed rows Wt[co][k*c_in+ci]
+ *   dgrad   : x = dy, wt = S16 of the transposed pack Wd[(k,ci)][co] (strided: plain GEMM; dilated: gather with
+ *             tap_step = -dil and Wd[ci][k*c_out+co])
+ *   wgrad   : x = dy^T [c_out][M], wt = x^T [(k,ci)][M] (written by the producers of dy / x), K = M, raw_partials. */
+int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* x, int32_t ldx, int32_t c_in,
+                      const void* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
+                      const vp3d_epilogue* epi, const float* zeros, const vp3d_s16* opts);
+/* fp32 rows [M][C] (pitch ld_src floats) -> S16 rows (pitch ld_dst 4-byte units) with the exponent of *bound */
+int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, void* dst,
+                    int64_t ld_dst, const float* bound);
+/* *bound = max(*bound, max|src[0..n)|)   (atomic; zero *bound first) */
+int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound);
+
 /* dx[b,s,:] = sum_k dy[b, map(s,k), :] @ W_k^T (+ epilogue: the residual-gradient scatter).
  *   M = B*t_dst rows of dx, N = n_out columns, K = taps*c_out.
  *   wt: the SAME forward-packed weights; column n of tap k is read at wt[co*ldw + k*w_tap_stride + n]. */

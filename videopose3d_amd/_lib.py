@@ -39,6 +39,11 @@ class Epilogue(C.Structure):
                 ("act_bwd", C.POINTER(ActBwd))]
 
 
+class S16Opts(C.Structure):
+    _fields_ = [("x_bound", C.c_void_p), ("w_bound", C.c_void_p), ("amax_out", C.c_void_p), ("cfg", C.c_int32),
+                ("splits", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("raw_partials", C.c_int32)]
+
+
 class Gather(C.Structure):
     _fields_ = [("n_chunks", C.c_int32), ("chunks", C.c_void_p), ("seq_off", C.c_void_p), ("poses_2d", C.c_void_p),
                 ("j2", C.c_int32), ("f2", C.c_int32), ("kps_perm", C.c_void_p), ("poses_3d", C.c_void_p),
@@ -65,6 +70,11 @@ SIGNATURES = {
     "vp3d_wgrad_splits": (C.c_int, [_i64, _i32, _i32]),
     "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
                                  _vp, _i64]),
+    "vp3d_nt_s16_plan": (C.c_int, [_i64, _i32, _i32, _P(_i32), _P(_i32)]),
+    "vp3d_tconv_nt_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
+                                    _P(S16Opts)]),
+    "vp3d_split_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "vp3d_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
     "vp3d_tconv_dgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32,
                                    _P(Epilogue), _vp, _vp, _i64]),
     "vp3d_tconv_wgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),

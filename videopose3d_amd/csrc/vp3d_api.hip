@@ -40,6 +40,8 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->ab_c = 0;
   e->ab_store_v = 1;
   e->ab_drop = make_drop(nullptr);
+  e->bound_a = e->bound_b = nullptr;
+  e->amax_out = nullptr;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -163,6 +165,73 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
   if (rc) return rc;
   set_splits(&a, splitk_ws, splitk_ws_floats);
   return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/true);
+}
+
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t* cfg, int32_t* splits) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && cfg && splits, "nt_s16_plan: bad argument");
+  int c, sp;
+  plan_nt_s16((int)M, N, K, 1, &c, &sp);
+  *cfg = c;
+  *splits = sp;
+  return VP3D_OK;
+}
+
+int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* x, int32_t ldx, int32_t c_in,
+                      const void* wt, int32_t ldw, int32_t c_out, float* y, int64_t y_bpitch, int32_t ldy,
+                      const vp3d_epilogue* epi, const float* zeros, const vp3d_s16* o) {
+  int rc = check_map(map, "tconv_nt_s16");
+  if (rc) return rc;
+  VP3D_REQUIRE(x && wt && zeros && o, "tconv_nt_s16: null pointer");
+  VP3D_REQUIRE(y || (o->raw_partials && o->ws), "tconv_nt_s16: no output buffer");
+  VP3D_REQUIRE(c_in > 0 && c_out > 0 && ldx >= 1 && ldw >= map->taps * c_in && (o->raw_partials || ldy >= c_out),
+               "tconv_nt_s16: bad sizes (c_in=%d c_out=%d ldx=%d ldw=%d ldy=%d)", c_in, c_out, ldx, ldw, ldy);
+  RowsGemmArgs a;
+  a.A = (const float*)x;
+  a.B = (const float*)wt;
+  a.zeros = zeros;
+  a.M = map->batch * map->t_dst;
+  a.N = c_out;
+  a.K = map->taps * c_in;
+  a.lda = ldx;
+  a.c_src = c_in;
+  a.ldb = ldw;
+  a.b_tap_stride = 0;
+  a.t_dst = map->t_dst;
+  a.t_src = map->t_src;
+  a.t_stride = map->t_stride;
+  a.tap_step = map->tap_step;
+  a.t_off = map->t_off;
+  a.taps = map->taps;
+  a.m_tiles = a.n_tiles = 0;
+  VP3D_REQUIRE(epi == nullptr || epi->act_bwd == nullptr, "tconv_nt_s16: act_bwd is not supported by the split-fp16 GEMM");
+  VP3D_REQUIRE(!o->raw_partials || epi == nullptr, "tconv_nt_s16: raw partial output takes no epilogue");
+  if (o->raw_partials) {
+    // the partial matrices [splits][M][N] in ws are the result (splits == 1: a single plain matrix)
+    VP3D_REQUIRE(o->ws && o->splits >= 1 && o->ws_floats >= (int64_t)o->splits * a.M * a.N,
+                 "tconv_nt_s16: raw partial output needs ws of splits*M*N floats and an explicit split count");
+    rc = fill_epi(&a.epi, nullptr, o->ws, 0, a.N, c_out);
+  } else {
+    rc = fill_epi(&a.epi, epi, y, y_bpitch, ldy, c_out);
+  }
+  if (rc) return rc;
+  a.epi.bound_a = o->x_bound;
+  a.epi.bound_b = o->w_bound;
+  a.epi.amax_out = o->amax_out;
+  set_splits(&a, nullptr, 0);
+  return launch_nt_s16((hipStream_t)stream, a, o->cfg, o->splits, o->ws, o->ws_floats, o->raw_partials != 0);
+}
+
+int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, void* dst,
+                    int64_t ld_dst, const float* bound) {
+  VP3D_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && src && dst && ld_src >= C && ld_dst >= C && ld_src % 4 == 0 && ld_dst % 8 == 0 &&
+                   aligned16(src) && aligned16(dst),
+               "split_rows: needs C %% 8 == 0 and 16-byte aligned rows");
+  return launch_split_rows((hipStream_t)stream, M, C, src, ld_src, (float*)dst, ld_dst, bound);
+}
+
+int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound) {
+  VP3D_REQUIRE(n > 0 && src && bound, "amax: bad argument");
+  return launch_amax((hipStream_t)stream, n, src, bound);
 }
 
 int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,

@@ -1,0 +1,609 @@
+// Split-fp16 ("S16", see vp3d_s16.h) implicit-GEMM kernel for the temporal convolutions (gfx950 / CDNA4):
+//   C[m][n] = 2^(ea+eb) * sum_k (Ah + Al)[gather(m,k)] * (Bh + Bl)[n][k]      "NT": both operands k-contiguous
+// with a*b evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 (fp32 accumulate): fp32-class results
+// (22+ significant operand bits, exact fp16 products) at 3/16 of the fp32-MFMA matrix-pipe time.
+//
+// Because an S16 row has the byte geometry of the fp32 row it replaces, the staging is the fp32 kernel's: K in
+// 32-element (128-B) tiles, DMA'd HBM/L2 -> LDS with global_load_lds (16 B per lane) into an NSTAGE ring of
+// [rows][128 B] images whose 16-B chunks are XOR-swizzled by ((row>>1)&7) on the SOURCE address; chunk 2g / 2g+1
+// of a row = hi / lo halves of elements 8g..8g+7 = one MFMA A/B fragment each (ds_read_b128, conflict-free).
+// Per 32-element K-tile a wave with an (RB x CB)-block sub-tile issues 4(RB+CB) fragment reads and 6*RB*CB
+// MFMAs of 32 matrix-pipe cycles: the kernel needs ~5x the operand bandwidth of the fp32 one per unit time, hence
+// the larger workgroup tiles (template) and the 3-stage ring with counted vmcnt.
+//
+// All GEMM forms of the model are expressed as NT: forward (B = packed weight rows), dgrad (B = the transposed
+// pack [(tap,ci)][co]), wgrad (both operands pre-transposed by their producers).
+#include "vp3d_internal.h"
+#include "vp3d_s16.h"
+
+namespace vp3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;   // elements per K-tile (= 128 B per row)
+
+template <int WM_, int WN_, int RB_, int CB_, int NSTAGE_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, RB = RB_, CB = CB_, NSTAGE = NSTAGE_;
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int BM = WM * RB * 32, BN = WN * CB * 32;
+  static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;   // 1-KiB LDS-DMA pieces per wave per K-tile
+  static constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;
+  static constexpr int TAB_OFF = NSTAGE * STAGE_B;
+  static constexpr int SMEM_B = TAB_OFF + 2 * BM * 4;
+  static constexpr int OCC = (SMEM_B * 2 <= 160 * 1024 && NT * 2 <= 1024) ? 2 : 1;   // workgroups per CU aimed at
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
+  static_assert(NW * 32 * CB * 32 * 4 <= NSTAGE * STAGE_B, "epilogue staging must fit in the operand ring");
+  static_assert(RB % 2 == 0, "64-row statistic slabs need an even number of 32-row blocks per wave");
+};
+
+__device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One 32-element K-tile of this wave's sub-tile: 2 MFMA k-steps x 3 products.
+template <int RB, int CB>
+__device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
+                                             f32x16 (&acc)[RB][CB], int off0, int off1) {
+  f16x8 ah[2][RB], al[2][RB], bh[2][CB], bl[2][CB];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int off = s == 0 ? off0 : off1;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * 4096 + off);
+      al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * 4096 + (off ^ 16));
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      bh[s][j] = *reinterpret_cast<const f16x8*>(sB + j * 4096 + off);
+      bl[s][j] = *reinterpret_cast<const f16x8*>(sB + j * 4096 + (off ^ 16));
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// position in the launch order -> tile (the fp32 kernel's XCD-aware order: workgroup id b runs on XCD b%8; every
+// XCD walks whole m-tiles with up to 8 column tiles back to back, so its ~64 concurrent tiles form an 8x8 patch)
+__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int& tile_m, int& tile_n) {
+  const int xcd = bid & 7, q = bid >> 3;
+  const int gn = min(n_tiles, 8);
+  const int m_groups = (m_tiles + 7) >> 3;
+  const int inner = q % gn, rest = q / gn;
+  tile_n = (rest / m_groups) * gn + inner;
+  tile_m = (rest % m_groups) * 8 + xcd;
+  return tile_m < m_tiles && tile_n < n_tiles;
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const RowsGemmArgs p) {
+  constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE, PA = C::PA, PB = C::PB;
+  __shared__ __attribute__((aligned(16))) char smem[C::SMEM_B];
+  int* tab_b = reinterpret_cast<int*>(smem + C::TAB_OFF);
+  int* tab_t = tab_b + BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / C::WN, wn = w % C::WN;
+  const int h = lane >> 5, cl = lane & 31;
+
+  // uniform split-K: blockIdx = split * positions + position (the tiles of one K range are dispatched together and
+  // share operand panels in L2); every split writes its raw, scaled partial matrix [M][N] at part + split*part_stride
+  const int split = blockIdx.x / p.pos_full;
+  const int bid = blockIdx.x - split * p.pos_full;
+  int tile_m, tile_n;
+  if (!tile_of(bid, p.m_tiles, p.n_tiles, tile_m, tile_n)) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  for (int r = tid; r < BM; r += C::NT) {
+    const int m = min(m0 + r, p.M - 1);
+    const int b = m / p.t_dst;
+    tab_b[r] = b;
+    tab_t[r] = m - b * p.t_dst;
+  }
+  __syncthreads();
+
+  f32x16 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt_all = p.K / BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(nkt_all, kt_begin + p.kt_per_split);
+  const int nkt = max(0, kt_end - kt_begin);
+
+  // ---- LDS-DMA staging: running pointers, one 64-bit add per piece per K-tile (as the fp32 kernel) ----
+  const int tap0 = (kt_begin * BK) / p.c_src;
+  int c0 = kt_begin * BK - tap0 * p.c_src;
+  int a_t[PA];
+  const float* a_ptr[PA];
+  const float* b_ptr[PB];
+  int b_inc[PB];
+  const int zoff = (lane & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int r = (w * PA + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const int b = tab_b[r], t = tab_t[r];
+    a_t[i] = t * p.t_stride + p.t_off + tap0 * p.tap_step;
+    a_ptr[i] = p.A + ((int64_t)b * p.t_src + a_t[i]) * p.lda + c0 + chunk * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int r = (w * PB + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const bool ok = (n0 + r) < p.N;
+    b_ptr[i] = ok ? p.B + (int64_t)(n0 + r) * p.ldb + (int64_t)kt_begin * BK + chunk * 4 : p.zeros + chunk * 4;
+    b_inc[i] = ok ? BK : 0;
+  }
+  const int64_t a_jump = (int64_t)p.tap_step * p.lda - p.c_src + BK;   // at a tap boundary
+
+  auto issue = [&](int stage, bool live) {          // `live` = false: harmless zero-page DMA (keeps vmcnt uniform)
+    char* sA = smem + stage * C::STAGE_B;
+    char* sB = sA + C::A_B;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bool ok = live && (unsigned)a_t[i] < (unsigned)p.t_src;
+      const float* g = ok ? a_ptr[i] : (p.zeros + zoff);
+      glds16(g, sA + (w * PA + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const float* g = live ? b_ptr[i] : (p.zeros + zoff);
+      glds16(g, sB + (w * PB + i) * 1024);
+    }
+    c0 += BK;
+    const bool wrap = c0 >= p.c_src;                // wave-uniform
+    if (wrap) c0 = 0;
+    const int64_t a_inc = wrap ? a_jump : (int64_t)BK;
+    const int t_inc = wrap ? p.tap_step : 0;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      a_ptr[i] += a_inc;
+      a_t[i] += t_inc;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_ptr[i] += b_inc[i];
+  };
+
+  // fragment addressing: row = block base + cl, swizzle term ((row>>1)&7) depends on cl only
+  const int sw = (cl >> 1) & 7;
+  const int off0 = ((2 * (0 + h)) ^ sw) * 16;
+  const int off1 = ((2 * (2 + h)) ^ sw) * 16;
+  const int a_row = (wm * RB * 32 + cl) * 128;
+  const int b_row = (wn * CB * 32 + cl) * 128;
+
+  if (nkt > 0) {
+    issue(0, true);
+    if (NSTAGE == 3) issue(1, nkt > 1);
+    for (int it = 0; it < nkt; ++it) {
+      if (NSTAGE == 3) {
+        wait_vmcnt<PA + PB>();                       // tile `it` landed (this wave's pieces); tile it+1 stays in flight
+        __builtin_amdgcn_s_barrier();                // ... everyone's did, and everyone left stage (it+2)%3
+        issue((it + 2) % 3, it + 2 < nkt);
+      } else {
+        wait_vmcnt<0>();
+        __syncthreads();
+        issue((it + 1) & 1, it + 1 < nkt);
+      }
+      const char* sA = smem + (it % NSTAGE) * C::STAGE_B;
+      compute_tile<RB, CB>(sA + a_row, sA + C::A_B + b_row, acc, off0, off1);
+    }
+  }
+  wait_vmcnt<0>();                                   // the trailing zero-page DMAs must not land in the staging below
+
+  // ---- epilogue -------------------------------------------------------------------------------------------
+  const bool partial = p.splits > 1;
+  const Epi& e = p.epi;
+  {
+    int ex = 0;
+    if (e.bound_a != nullptr) ex += s16_exp_for_bound(*e.bound_a);
+    if (e.bound_b != nullptr) ex += s16_exp_for_bound(*e.bound_b);
+    if (ex != 0) {
+      const float scale = s16_pow2(ex);
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= scale;
+    }
+  }
+  if (!partial) {
+    if (e.stat_sum != nullptr) {                     // BatchNorm slab statistics of the raw conv output
+#pragma unroll
+      for (int sb = 0; sb < RB / 2; ++sb) {
+        const int row0 = m0 + (wm * RB + sb * 2) * 32;
+        const int cnt = min(64, p.M - row0);         // wave-uniform
+        if (cnt > 0) {
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            const int n = n0 + (wn * CB + j) * 32 + cl;
+            float s = 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                const int r = i2 * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                s += (r < cnt) ? acc[sb * 2 + i2][j][reg] : 0.f;
+              }
+            s += __shfl_xor(s, 32);
+            const float mean = s / (float)cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                const int r = i2 * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const float d = acc[sb * 2 + i2][j][reg] - mean;
+                q += (r < cnt) ? d * d : 0.f;
+              }
+            q += __shfl_xor(q, 32);
+            if (h == 0 && n < p.N) {
+              e.stat_sum[(int64_t)(row0 >> 6) * p.N + n] = s;
+              e.stat_m2[(int64_t)(row0 >> 6) * p.N + n] = q;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  __syncthreads();                                   // every wave is done reading the operand ring
+  // Each wave stages one 32-row block of its sub-tile at a time through its own [32][CB*32] fp32 LDS region and
+  // writes it out with 16-B stores (a row of the region = CB*128 B contiguous in C).
+  constexpr int WCOLS = CB * 32, LPR = WCOLS / 4, RPP = 64 / LPR;   // lanes per row, rows per pass
+  float* wreg = reinterpret_cast<float*>(smem) + w * (32 * WCOLS);
+  const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+  float* Cbase = partial ? p.part + (int64_t)split * p.part_floats : e.C;
+  const int n = n0 + wn * WCOLS + c4;
+  const int Nlim = p.N;
+  const bool vec = partial ? (p.N % 4 == 0) : (e.vec != 0);
+  float amax = 0.f;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (!partial && e.bias != nullptr && vec && n < Nlim) bias = *reinterpret_cast<const f32x4*>(e.bias + n);
+  const int rc = n - e.r_col0;
+  const bool rcol_ok = !partial && e.R != nullptr && rc >= 0 && rc < e.r_cols;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
+      }
+    __syncthreads();
+#pragma unroll 4
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+      const int r = ps * RPP + rr;
+      const int lr = (wm * RB + i) * 32 + r;         // row inside the tile
+      if (m0 + lr >= p.M || n >= Nlim) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
+      if (partial) {
+        float* prow = Cbase + (int64_t)(m0 + lr) * p.N + n;
+        if (vec) {
+          *reinterpret_cast<f32x4*>(prow) = v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (n + c < p.N) prow[c] = v[c];
+        }
+        continue;
+      }
+      const int b = tab_b[lr], t = tab_t[lr];
+      float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
+      const int tr = t * e.r_stride + e.r_off;
+      const bool r_row_ok = e.R != nullptr && (unsigned)tr < (unsigned)e.r_t;
+      const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+      if (vec) {
+        v += bias;
+        if (e.relu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+        }
+        if (rcol_ok && r_row_ok) v += *reinterpret_cast<const f32x4*>(rrow + n);
+        *reinterpret_cast<f32x4*>(crow + n) = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int nn = n + c;
+          if (nn >= p.N) continue;
+          float x = v[c] + (e.bias != nullptr ? e.bias[nn] : 0.f);
+          if (e.relu) x = x < 0.f ? 0.f : x;
+          const int rcc = nn - e.r_col0;
+          if (r_row_ok && rcc >= 0 && rcc < e.r_cols) x += rrow[nn];
+          crow[nn] = x;
+          amax = fmaxf(amax, fabsf(x));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!partial && e.amax_out != nullptr) {             // max|stored value| of the whole launch (S16 exponent of the result)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) atomicMax(reinterpret_cast<int*>(e.amax_out), __float_as_int(amax));
+  }
+}
+
+// Finish of a split-K launch whose result needs the fused epilogue (forward / dgrad of the small-M layers): sums the
+// partial matrices [splits][M][N] and applies bias / ReLU / residual / 64-row-slab BatchNorm statistics / amax.
+// blockIdx.x = 64-row slab, blockIdx.y = 64-column strip; thread (rg, cq) owns rows rg + 16 i and one float4 column.
+__global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ part, int splits, int64_t part_stride, int M,
+                                                    int N, int vec, int t_dst, const Epi e) {
+  __shared__ float red[16][64];
+  __shared__ float mean_s[64];
+  const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int m_base = blockIdx.x * 64;
+  const int n = blockIdx.y * 64 + cq * 4;
+  const int cnt = min(64, M - m_base);
+  const bool nok = n < N;
+  f32x4 raw[4];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rg + 16 * i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nok && r < cnt) {
+      const float* src = part + (int64_t)(m_base + r) * N + n;
+      if (vec) {
+        for (int sp = 0; sp < splits; ++sp) v += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * part_stride);
+      } else {
+        for (int sp = 0; sp < splits; ++sp)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (n + c < N) v[c] += src[(int64_t)sp * part_stride + c];
+      }
+    }
+    raw[i] = v;
+    s += v;
+  }
+  if (e.stat_sum != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = s[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      mean_s[threadIdx.x] = t / (float)cnt;
+      const int nn = blockIdx.y * 64 + threadIdx.x;
+      if (nn < N) e.stat_sum[(int64_t)blockIdx.x * N + nn] = t;
+    }
+    __syncthreads();
+    f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (rg + 16 * i < cnt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = raw[i][c] - mean_s[cq * 4 + c];
+          q2[c] += d * d;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rg][cq * 4 + c] = q2[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      const int nn = blockIdx.y * 64 + threadIdx.x;
+      if (nn < N) e.stat_m2[(int64_t)blockIdx.x * N + nn] = t;
+    }
+  }
+  float amax = 0.f;
+  if (nok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rg + 16 * i;
+      if (r >= cnt) continue;
+      const int m = m_base + r;
+      const int b = m / t_dst;
+      const int t = m - b * t_dst;
+      const int tr = t * e.r_stride + e.r_off;
+      const bool r_row_ok = e.R != nullptr && (unsigned)tr < (unsigned)e.r_t;
+      float* crow = e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc;
+      const float* rrow = e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0;
+      if (vec) {
+        f32x4 v = raw[i];
+        if (e.bias != nullptr) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+        if (e.relu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+        }
+        const int rc = n - e.r_col0;
+        if (r_row_ok && rc >= 0 && rc < e.r_cols) v += *reinterpret_cast<const f32x4*>(rrow + n);
+        *reinterpret_cast<f32x4*>(crow + n) = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int nn = n + c;
+          if (nn >= N) continue;
+          float v = raw[i][c] + (e.bias != nullptr ? e.bias[nn] : 0.f);
+          if (e.relu) v = v < 0.f ? 0.f : v;
+          const int rc = nn - e.r_col0;
+          if (r_row_ok && rc >= 0 && rc < e.r_cols) v += rrow[nn];
+          crow[nn] = v;
+          amax = fmaxf(amax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (e.amax_out != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(e.amax_out), __float_as_int(amax));
+  }
+}
+
+// fp32 rows -> S16 rows (elementwise; one thread per 8-element group)
+__global__ void __launch_bounds__(256) k_split_rows(int64_t groups, int groups_per_row, const float* __restrict__ src,
+                                                    int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
+                                                    const float* __restrict__ bound) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const int64_t row = g / groups_per_row;
+  const int gc = (int)(g - row * groups_per_row);
+  const float inv = bound != nullptr ? s16_pow2(-s16_exp_for_bound(*bound)) : 1.f;
+  const float* s = src + row * ld_src + gc * 8;
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(s);
+  const f32x4 v1 = *reinterpret_cast<const f32x4*>(s + 4);
+  const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  f16x8 hi, lo;
+  s16_split8(v, inv, hi, lo);
+  f16x8* d = reinterpret_cast<f16x8*>(dst + row * ld_dst + gc * 8);
+  d[0] = hi;
+  d[1] = lo;
+}
+
+// *bound = max(*bound, max|src|)   (the caller zeroes *bound; non-negative floats order like their bit patterns)
+__global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict__ src, float* __restrict__ bound) {
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(bound), __float_as_int(m));
+}
+
+template <class C>
+int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
+  a.m_tiles = (a.M + C::BM - 1) / C::BM;
+  a.n_tiles = (a.N + C::BN - 1) / C::BN;
+  const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
+  const int m_groups = (a.m_tiles + 7) / 8, n_groups = (a.n_tiles + gn - 1) / gn;
+  const int positions = 8 * gn * m_groups * n_groups;
+  const int nkt = a.K / BK;
+  a.pos_full = positions;
+  a.tail_pos = 0;
+  a.splits = splits;
+  a.kt_per_split = (nkt + splits - 1) / splits;
+  hipLaunchKernelGGL((k_nt_s16<C>), dim3(positions * splits), dim3(C::NT), 0, s, a);
+  return check_launch("nt_s16");
+}
+
+}  // namespace
+
+// Tile configuration and split-K factor of an [M,N,K] S16 GEMM.  Cost model in units of one 32-element K-tile of a
+// 128x128 tile on one CU (measured on MI355X: the 256x256 / 8-wave configuration sustains ~420 TF-equivalent on large
+// problems, the 128x128 / 4-wave one ~360 but fills the chip from 4x fewer rows), the finishing pass of a split
+// launch streams the partial matrices once each way.
+void plan_nt_s16(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out) {
+  const int nkt = K / BK;
+  double best = 1e30;
+  int best_cfg = 0, best_s = 1;
+  for (int cfg = 0; cfg < 2; ++cfg) {
+    const int bm = cfg == 0 ? 128 : 256, bn = cfg == 0 ? 128 : 256;
+    const double tile_cost = cfg == 0 ? 1.0 : 4.0 * 364.0 / 422.0;      // per K-tile, relative to a 128x128 tile
+    const double fixed = cfg == 0 ? 4.0 : 10.0;                          // prologue + epilogue, in K-tiles of its own size
+    const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    for (int s = 1; s <= (allow_split ? 64 : 1); ++s) {
+      if (s > 1 && nkt / s < 8) break;
+      const double rounds = (double)((tiles * s + 255) / 256);
+      double cost = rounds * ((double)((nkt + s - 1) / s) + fixed) * tile_cost;
+      // finish: s*M*N floats written + read at ~4 TB/s; one K-tile of a 128x128 tile ~ 0.27 us on this path
+      if (s > 1) cost += (3.0 + (double)s * (double)M * (double)N * 8.0 / 4.0e6) / 0.27;
+      if (cost < best * 0.97) {
+        best = cost;
+        best_cfg = cfg == 0 ? 0 : 4;
+        best_s = s;
+      }
+    }
+  }
+  *cfg_out = best_cfg;
+  *splits_out = best_s;
+}
+
+// cfg < 0: planned.  splits > 1 needs `ws` (splits*M*N floats): forward/dgrad launches then run k_s16_finish for the fused
+// epilogue; with raw_partials the partial matrices ARE the result (wgrad: vp3d_wgrad_reduce sums them).
+int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, float* ws, int64_t ws_floats,
+                  bool raw_partials) {
+  RowsGemmArgs a = a_in;
+  VP3D_REQUIRE(a.K % BK == 0 && a.c_src % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && aligned16(a.A) && aligned16(a.B) &&
+                   aligned16(a.zeros),
+               "nt_s16: the split-fp16 GEMM needs channel counts %% 32 == 0 and 16-byte aligned S16 rows");
+  if (cfg < 0) {
+    int pc, ps;
+    plan_nt_s16(a.M, a.N, a.K, ws != nullptr, &pc, &ps);
+    cfg = pc;
+    if (splits <= 0) splits = ps;
+  }
+  if (splits <= 0) splits = 1;
+  VP3D_REQUIRE(splits <= a.K / BK, "nt_s16: splits=%d exceeds the %d K-tiles", splits, a.K / BK);
+  if (splits > 1) {
+    VP3D_REQUIRE(ws != nullptr && aligned16(ws) && ws_floats >= (int64_t)splits * a.M * a.N,
+                 "nt_s16: split-K needs a workspace of splits*M*N floats");
+    a.part = ws;
+    a.part_floats = (int64_t)a.M * a.N;            // stride between the partial matrices
+  }
+  a.epi.vec = (a.N % 4 == 0) && (a.epi.ldc % 4 == 0) && (a.epi.c_bpitch % 4 == 0) && aligned16(a.epi.C) &&
+              (a.epi.bias == nullptr || aligned16(a.epi.bias)) &&
+              (a.epi.R == nullptr || (aligned16(a.epi.R) && a.epi.r_ld % 4 == 0 && a.epi.r_bpitch % 4 == 0 &&
+                                      a.epi.r_col0 % 4 == 0 && a.epi.r_cols % 4 == 0));
+  int rc;
+  switch (cfg) {
+    case 0: rc = launch_cfg<Cfg<2, 2, 2, 2, 2>>(s, a, splits); break;     // 128x128, 4 waves, 2 stages, 2 WG/CU
+    case 1: rc = launch_cfg<Cfg<2, 2, 2, 2, 3>>(s, a, splits); break;     // 128x128, 4 waves, 3 stages
+    case 2: rc = launch_cfg<Cfg<4, 2, 2, 2, 2>>(s, a, splits); break;     // 256x128, 8 waves, 2 stages
+    case 3: rc = launch_cfg<Cfg<4, 2, 2, 2, 3>>(s, a, splits); break;     // 256x128, 8 waves, 3 stages
+    case 4: rc = launch_cfg<Cfg<2, 4, 4, 2, 2>>(s, a, splits); break;     // 256x256, 8 waves (128x64 each), 2 stages
+    default:
+      set_error("nt_s16: unknown tile configuration %d", cfg);
+      return VP3D_E_INVALID;
+  }
+  if (rc != VP3D_OK || splits == 1 || raw_partials) return rc;
+  hipLaunchKernelGGL(k_s16_finish, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(256), 0, s, ws, splits, a.part_floats, a.M,
+                     a.N, (int)(a.epi.vec && a.N % 4 == 0), a.t_dst, a.epi);
+  return check_launch("s16_finish");
+}
+
+int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                      const float* bound) {
+  const int64_t groups = M * (C / 8);
+  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, groups, C / 8, src, ld_src,
+                     dst, ld_dst, bound);
+  return check_launch("split_rows");
+}
+
+int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound) {
+  const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, n, src, bound);
+  return check_launch("amax");
+}
+
+}  // namespace vp3d

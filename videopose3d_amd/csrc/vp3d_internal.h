@@ -46,6 +46,12 @@ struct Epi {
   float* ab_part;
   int32_t ab_c, ab_store_v;
   DropP ab_drop;
+  // split-fp16 GEMMs (vp3d_gemm_s16.hip): per-tensor magnitude bounds of the two S16 operands (device floats, NULL =
+  // exponent 0); the accumulator is scaled by 2^(exp(*bound_a) + exp(*bound_b)) before anything else.
+  // amax_out: atomicMax of |stored value| over the launch (the bound of the result; zeroed by the caller), or NULL
+  const float* bound_a;
+  const float* bound_b;
+  float* amax_out;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";
@@ -91,5 +97,12 @@ int rows_gemm_splits(int M, int N, int K);
 int red_gemm_splits(int Mred, int Mo, int N);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
+// split-fp16 NT GEMM (vp3d_gemm_s16.hip); cfg selects the tile configuration
+void plan_nt_s16(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out);
+int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, float* ws, int64_t ws_floats,
+                  bool raw_partials);
+int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                      const float* bound);
+int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound);
 
 }  // namespace vp3d

@@ -1,0 +1,48 @@
+// "S16" split-fp16 operand format shared by the split-precision GEMM kernels and the streaming kernels that
+// produce their operands (not part of the C ABI; the format itself is documented in include/vp3d.h).
+//
+// An fp32 value v of a tensor with per-tensor exponent e is kept as two fp16 numbers
+//     hi = fp16(v * 2^-e),   lo = fp16(v * 2^-e - hi)          v ~= 2^e * (hi + lo)
+// i.e. 22-23 significant bits.  Eight consecutive elements of a row are stored as 16 B of hi followed by 16 B
+// of lo, so an S16 row has exactly the byte geometry of the fp32 row it replaces (4 B per element, 32-B groups)
+// and every 16-B chunk is one MFMA operand fragment (8 consecutive k of one row).
+// The GEMMs evaluate a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with fp32 accumulation: every
+// fp16 product is exact in fp32 and the dropped al*bl term is <= 2^-22 |a*b|: fp32-class results at the fp16
+// matrix rate (3 MFMAs per 16-deep step instead of 8 fp32 MFMAs).
+// The exponent keeps the tensor inside fp16's range: producers choose it from a guaranteed bound of max|v| so
+// that |v * 2^-e| < 2^15; elements below 2^-14 relative to that carry an absolute error <= 2^-25 (scaled units).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp3d {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// exponent e such that |v| <= bound  =>  |v * 2^-e| < 2^15   (bound = 0 or non-finite -> 0)
+__device__ __forceinline__ int s16_exp_for_bound(float bound) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 0;
+  int ex;
+  frexpf(bound, &ex);            // bound = m * 2^ex, m in [0.5, 1)  ->  bound < 2^ex
+  return ex - 15;
+}
+
+__device__ __forceinline__ void s16_split8(const float (&v)[8], float inv_scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * inv_scale;
+    const _Float16 h = (_Float16)x;
+    hi[j] = h;
+    lo[j] = (_Float16)(x - (float)h);
+  }
+}
+
+__device__ __forceinline__ void s16_join8(const f16x8& hi, const f16x8& lo, float scale, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = ((float)hi[j] + (float)lo[j]) * scale;
+}
+
+__device__ __forceinline__ float s16_pow2(int e) { return ldexpf(1.0f, e); }
+
+}  // namespace vp3d
