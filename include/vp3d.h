@@ -189,6 +189,38 @@ int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src
 /* *bound = max(*bound, max|src[0..n)|)   (atomic; zero *bound first) */
 int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound);
 
+/* Producers of S16 operands (streaming kernels; C % 64 == 0).  "t_out" is the optional TRANSPOSED copy the weight-
+ * gradient GEMM reduces over: t_out[(tap*C + c)*ld_t + m/taps] = value(m, c), tap = m % taps (taps = stride of the
+ * strided conv that consumes the tensor, 1 otherwise; M % taps == 0), S16 rows along m, ld_t >= roundup(M/taps, 64)
+ * 4-byte units, columns [M/taps, roundup(M/taps, 64)) zero-filled.  Bounds are device floats (see vp3d_s16). */
+/* out = [res +] dropout(relu(y*scale + shift)) as S16 with the exponent of *out_bound; res (S16, exponent of *res_bound)
+ * is addressed as in vp3d_bn_act_fwd */
+int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
+                        const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
+                        int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
+                        const float* out_bound, void* out, void* t_out, int64_t ld_t, int32_t taps);
+/* dy of vp3d_bn_bwd_apply as S16 rows (+ transposed copy, taps = 1) */
+int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
+                          void* dy, void* t_out, int64_t ld_t);
+/* fp32 rows -> S16 rows (out, may be NULL) and / or the transposed S16 copy (t_out, may be NULL; taps = 1) */
+int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,
+                 void* out, int64_t ld_out, void* t_out, int64_t ld_t);
+/* reference Conv1d.weight [c_out][c_in][taps] -> S16 packs with the exponent of *bound (c_out, c_in % 64 == 0, taps <= 3):
+ *   wf (may be NULL): Wt[co*ld_f + k*c_in + ci]                    (forward)
+ *   wd (may be NULL): strided form  Wd[(k*c_in + ci)*ld_d + co]     (dgrad of a stride == taps conv, plain GEMM)
+ *                     dilated form  Wd[ci*ld_d + k*c_out + co]      (dgrad of a dilated conv, gather with -dil) */
+int vp3d_pack_weight_s16(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
+                         const float* bound, void* wf, int64_t ld_f, void* wd, int64_t ld_d, int32_t dilated_form);
+/* *out = max_c(|gamma_c|*sqrt(M-1) + |beta_c|)/(1-p) + (res_bound ? *res_bound : 0): a guaranteed bound of
+ * |[res +] dropout(relu(bn(y)))| for batch statistics over M rows (Samuelson's inequality) */
+int vp3d_act_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* gamma, const float* beta, float p,
+                   const float* res_bound, float* out);
+/* *out = max_c |scale_c|*(g + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M), g = *go_bound/(1-p): bound of vp3d_bn_bwd_apply's dy */
+int vp3d_dy_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* scale, const float* dgamma,
+                  const float* dbeta, const float* go_bound, float p, float* out);
+
 /* dx[b,s,:] = sum_k dy[b, map(s,k), :] @ W_k^T (+ epilogue: the residual-gradient scatter).
  *   M = B*t_dst rows of dx, N = n_out columns, K = taps*c_out.
  *   wt: the SAME forward-packed weights; column n of tap k is read at wt[co*ldw + k*w_tap_stride + n]. */

@@ -75,6 +75,14 @@ SIGNATURES = {
                                     _P(S16Opts)]),
     "vp3d_split_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vp3d_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "vp3d_bn_act_fwd_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                      _vp, _vp, _vp, _i64, _i32]),
+    "vp3d_bn_bwd_apply_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp, _vp, _vp,
+                                        _i64]),
+    "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
+    "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
+    "vp3d_act_bound": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _f32, _vp, _vp]),
+    "vp3d_dy_bound": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _vp]),
     "vp3d_tconv_dgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32,
                                    _P(Epilogue), _vp, _vp, _i64]),
     "vp3d_tconv_wgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),

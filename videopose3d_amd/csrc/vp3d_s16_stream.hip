@@ -1,0 +1,419 @@
+// Streaming (HBM-bound) producers of the S16 operands of the split-fp16 GEMMs (format: vp3d_s16.h):
+//   k_bn_act_fwd_s16    y (fp32 conv output) -> a = [res +] dropout(relu(bn(y))) as S16 rows (+ transposed copy)
+//   k_bn_bwd_apply_s16  (go, y) -> dy = BN/ReLU/dropout backward as S16 rows (+ transposed copy)
+//   k_split_t           fp32 rows -> S16 rows and/or transposed S16 (expand-conv input staging)
+//   k_pack_weight_s16   reference Conv1d.weight -> forward pack Wt[co][k*C_in+ci] and dgrad pack Wd[(k,ci)][co] in S16
+//   bound kernels       guaranteed magnitude bounds (Samuelson: |x - mean| <= std*sqrt(M-1)) -> exponents, on the device
+// "Transposed copy": the weight-gradient GEMM reduces over the rows m, and the fp16 MFMA wants 8 consecutive reduction
+// indices per lane, so the producers of dy and of the layer inputs also emit  T[(tap*C + c)][m / taps]  (taps = the
+// stride of the consuming strided conv: its input rows 3t..3t+2 are the taps of output row t), as S16 rows along m.
+// A block owns taps*64 consecutive rows x 64 channels: phase 1 computes the values (16/32-B accesses along the
+// channels), stores the S16 rows and parks the scaled fp32 values in an LDS tile [rows][65]; phase 2 walks the tile
+// column-wise (conflict-free with the 65-float pitch) and writes 256-B runs of the transposed rows.
+#include "vp3d_internal.h"
+#include "vp3d_s16.h"
+
+namespace vp3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TCH = 64;       // channels per block
+constexpr int TPITCH = 65;    // LDS tile row pitch (floats)
+
+struct TOut {                 // transposed output (ptr == nullptr: off)
+  float* ptr;                 // S16, rows of ld 4-byte units
+  int64_t ld;                 // >= roundup(M / taps, 64)
+  int taps;                   // 1 or 3 (M % taps == 0)
+};
+
+// phase 2: tile[rows = taps*64][TPITCH] (scaled fp32, zero beyond M) -> T[(tap*C + c0 + ch)][col0 + 0..63]
+__device__ __forceinline__ void tile_store_t(const float* tile, const TOut& t, int C, int c0, int64_t col0) {
+  const int items = t.taps * 512;
+  for (int idx = threadIdx.x; idx < items; idx += 256) {
+    const int cg = idx & 7, ch = (idx >> 3) & 63, tap = idx >> 9;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[((cg * 8 + j) * t.taps + tap) * TPITCH + ch];
+    f16x8 hi, lo;
+    s16_split8(v, 1.f, hi, lo);
+    f16x8* d = reinterpret_cast<f16x8*>(t.ptr + ((int64_t)tap * C + c0 + ch) * t.ld + col0 + cg * 8);
+    d[0] = hi;
+    d[1] = lo;
+  }
+}
+
+struct ResS16 {
+  const float* res;           // S16 rows
+  const float* bound;
+  int t_dst, r_t, r_stride, r_off, r_ld;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// a = [res +] dropout(relu(y*scale + shift))  ->  S16 rows out[m][c] (+ transposed)
+// grid.x = C/64, grid.y = row tiles of taps*64 rows; thread (r = tid>>3, g8 = tid&7) owns 8 channels
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const float* __restrict__ y,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        DropP d, ResS16 rm, const float* __restrict__ out_bound,
+                                                        float* __restrict__ out, TOut t) {
+  extern __shared__ float tile[];
+  const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
+  const int taps = t.ptr != nullptr ? t.taps : 1;
+  const int R = taps * 64;
+  const int64_t m0 = (int64_t)blockIdx.y * R;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[c + e];
+    sh[e] = shift[c + e];
+  }
+  const float inv = s16_pow2(-s16_exp_for_bound(*out_bound));
+  const float rscale = rm.res != nullptr ? s16_pow2(s16_exp_for_bound(*rm.bound)) : 0.f;
+  for (int r = rsub; r < R; r += 32) {
+    const int64_t m = m0 + r;
+    float v[8];
+    if (m < M) {
+      const int64_t e0 = m * C + c;
+      const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + e0);
+      const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
+      float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (d.on) {
+        float a[4], b[4];
+        drop4(d, (uint64_t)(e0 >> 2), a);
+        drop4(d, (uint64_t)(e0 >> 2) + 1, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mk[e] = a[e];
+          mk[4 + e] = b[e];
+        }
+      }
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (rm.res != nullptr) {
+        const int b = (int)(m / rm.t_dst);
+        const int tt = (int)(m - (int64_t)b * rm.t_dst);
+        const f16x8* rp = reinterpret_cast<const f16x8*>(
+            rm.res + ((int64_t)b * rm.r_t + (int64_t)tt * rm.r_stride + rm.r_off) * rm.r_ld + c);
+        s16_join8(rp[0], rp[1], rscale, rv);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = e < 4 ? y0[e] : y1[e - 4];
+        const float z = fmaf(yy, sc[e], sh[e]);
+        v[e] = (rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f))) * inv;
+      }
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      f16x8* o = reinterpret_cast<f16x8*>(out + e0);
+      o[0] = hi;
+      o[1] = lo;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (t.ptr != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+    }
+  }
+  if (t.ptr == nullptr) return;
+  __syncthreads();
+  tile_store_t(tile, t, C, c0, (int64_t)blockIdx.y * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dy = scale*(g - dbeta/M - xhat*dgamma/M),  g = go*keep*[z>0]   ->  S16 rows (+ transposed, taps = 1)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const float* __restrict__ go,
+                                                          const float* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, DropP d,
+                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                          const float* __restrict__ out_bound, float* __restrict__ dy,
+                                                          TOut t) {
+  extern __shared__ float tile[];
+  const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
+  const int64_t m0 = (int64_t)blockIdx.y * 64;
+  const float inv_m = 1.0f / (float)M;
+  float sc[8], sh[8], mu[8], is[8], kb[8], kg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
+    kb[e] = dbeta[c + e] * inv_m;
+    kg[e] = dgamma[c + e] * inv_m;
+  }
+  const float inv = s16_pow2(-s16_exp_for_bound(*out_bound));
+  for (int r = rsub; r < 64; r += 32) {
+    const int64_t m = m0 + r;
+    float v[8];
+    if (m < M) {
+      const int64_t e0 = m * C + c;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(go + e0);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(go + e0 + 4);
+      const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + e0);
+      const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
+      float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (d.on) {
+        float a[4], b[4];
+        drop4(d, (uint64_t)(e0 >> 2), a);
+        drop4(d, (uint64_t)(e0 >> 2) + 1, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mk[e] = a[e];
+          mk[4 + e] = b[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = e < 4 ? y0[e] : y1[e - 4];
+        const float gg = e < 4 ? g0[e] : g1[e - 4];
+        const float z = fmaf(yy, sc[e], sh[e]);
+        const float g = z > 0.f ? gg * mk[e] : 0.f;
+        const float xh = (yy - mu[e]) * is[e];
+        v[e] = sc[e] * (g - kb[e] - xh * kg[e]) * inv;
+      }
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      f16x8* o = reinterpret_cast<f16x8*>(dy + e0);
+      o[0] = hi;
+      o[1] = lo;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (t.ptr != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+    }
+  }
+  if (t.ptr == nullptr) return;
+  __syncthreads();
+  tile_store_t(tile, t, C, c0, (int64_t)blockIdx.y * 64);
+}
+
+// fp32 rows [M][C] (pitch ld_src) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
+__global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __restrict__ src, int64_t ld_src,
+                                                 const float* __restrict__ bound, float* __restrict__ out, int64_t ld_out,
+                                                 TOut t) {
+  extern __shared__ float tile[];
+  const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
+  const int64_t m0 = (int64_t)blockIdx.y * 64;
+  const float inv = bound != nullptr ? s16_pow2(-s16_exp_for_bound(*bound)) : 1.f;
+  for (int r = rsub; r < 64; r += 32) {
+    const int64_t m = m0 + r;
+    float v[8];
+    if (m < M) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? a0[e] : a1[e - 4]) * inv;
+      if (out != nullptr) {
+        f16x8 hi, lo;
+        s16_split8(v, 1.f, hi, lo);
+        f16x8* o = reinterpret_cast<f16x8*>(out + m * ld_out + c);
+        o[0] = hi;
+        o[1] = lo;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (t.ptr != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+    }
+  }
+  if (t.ptr == nullptr) return;
+  __syncthreads();
+  tile_store_t(tile, t, C, c0, (int64_t)blockIdx.y * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weights: W[co][ci][k] (reference layout) -> S16 packs.  Block = 64 co x 64 ci (all taps) through LDS.
+//   fwd  : Wt[co][k*C_in + ci]                    (rows of ld_f 4-byte units; columns beyond taps*C_in untouched)
+//   dgr  : strided: Wd[(k*C_in + ci)][co]         (rows of ld_d)
+//          dilated: Wd[ci][k*C_out + co]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_weight_s16(int c_out, int c_in, int taps, const float* __restrict__ w,
+                                                         const float* __restrict__ bound, float* __restrict__ wf,
+                                                         int64_t ld_f, float* __restrict__ wd, int64_t ld_d,
+                                                         int dilated_form) {
+  extern __shared__ float tile[];                 // [taps][64 co][TPITCH] (ci fastest)
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const float inv = s16_pow2(-s16_exp_for_bound(*bound));
+  const int row_f = 64 * taps;                    // contiguous floats per co row of the tile
+  for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
+    const int co = idx / row_f, q = idx - co * row_f;     // q = ci_local*taps + k
+    const int ci = q / taps, k = q - ci * taps;
+    tile[(k * 64 + co) * TPITCH + ci] = w[((int64_t)(co0 + co) * c_in + ci0) * taps + q] * inv;
+  }
+  __syncthreads();
+  if (wf != nullptr) {
+    for (int idx = threadIdx.x; idx < taps * 512; idx += 256) {      // (k, co, ci-group)
+      const int g = idx & 7, co = (idx >> 3) & 63, k = idx >> 9;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[(k * 64 + co) * TPITCH + g * 8 + j];
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      f16x8* d = reinterpret_cast<f16x8*>(wf + (int64_t)(co0 + co) * ld_f + (int64_t)k * c_in + ci0 + g * 8);
+      d[0] = hi;
+      d[1] = lo;
+    }
+  }
+  if (wd != nullptr) {
+    for (int idx = threadIdx.x; idx < taps * 512; idx += 256) {      // (k, ci, co-group)
+      const int g = idx & 7, ci = (idx >> 3) & 63, k = idx >> 9;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[(k * 64 + g * 8 + j) * TPITCH + ci];
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      float* row = dilated_form ? wd + (int64_t)(ci0 + ci) * ld_d + (int64_t)k * c_out
+                                : wd + ((int64_t)k * c_in + ci0 + ci) * ld_d;
+      f16x8* d = reinterpret_cast<f16x8*>(row + co0 + g * 8);
+      d[0] = hi;
+      d[1] = lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bounds
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max_1024(float m, float* red) {
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// |dropout(relu(bn(y)))| <= (|gamma|*sqrt(M-1) + |beta|) / (1-p)   (Samuelson), plus the residual's bound
+__global__ void __launch_bounds__(1024) k_act_bound(int C, float sqrt_m1, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float inv_keep,
+                                                    const float* __restrict__ res_bound, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 1024) m = fmaxf(m, fabsf(gamma[c]) * sqrt_m1 + fabsf(beta[c]));
+  m = block_max_1024(m, red);
+  if (threadIdx.x == 0) out[0] = m * inv_keep + (res_bound != nullptr ? res_bound[0] : 0.f);
+}
+
+// |dy_c| <= |scale_c| * (gmax + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M),  gmax = go_bound / (1-p)
+__global__ void __launch_bounds__(1024) k_dy_bound(int C, float inv_m, float sqrt_m1, const float* __restrict__ scale,
+                                                   const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                   const float* __restrict__ go_bound, float inv_keep,
+                                                   float* __restrict__ out) {
+  __shared__ float red[1024];
+  const float gmax = go_bound[0] * inv_keep;
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 1024)
+    m = fmaxf(m, fabsf(scale[c]) * (gmax + fabsf(dbeta[c]) * inv_m + sqrt_m1 * fabsf(dgamma[c]) * inv_m));
+  m = block_max_1024(m, red);
+  if (threadIdx.x == 0) out[0] = m;
+}
+
+}  // namespace
+}  // namespace vp3d
+
+using namespace vp3d;
+
+static int check_t(const char* who, void* t_out, int64_t ld_t, int32_t taps, int64_t M) {
+  if (t_out == nullptr) return VP3D_OK;
+  VP3D_REQUIRE(taps >= 1 && M % taps == 0 && ld_t % 8 == 0 && ld_t >= (M / taps + 63) / 64 * 64 && aligned16(t_out),
+               "%s: transposed output needs M %% taps == 0 and ld_t >= roundup(M/taps, 64) (M=%lld taps=%d ld_t=%lld)", who,
+               (long long)M, taps, (long long)ld_t);
+  return VP3D_OK;
+}
+
+extern "C" {
+
+int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
+                        const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
+                        int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
+                        const float* out_bound, void* out, void* t_out, int64_t ld_t, int32_t taps) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && y && scale && shift && out && out_bound,
+               "bn_act_fwd_s16: bad argument (needs C %% 64 == 0)");
+  VP3D_REQUIRE(aligned16(y) && aligned16(out) && (res == nullptr || (aligned16(res) && res_bound && r_ld % 8 == 0)),
+               "bn_act_fwd_s16: 16-byte aligned buffers required");
+  int rc = check_t("bn_act_fwd_s16", t_out, ld_t, taps, M);
+  if (rc) return rc;
+  if (drop) VP3D_REQUIRE(drop->p >= 0.f && drop->p < 1.f, "bn_act_fwd_s16: dropout p=%f", drop->p);
+  const DropP d = make_drop(drop);
+  ResS16 rm{(const float*)res, res_bound, t_dst > 0 ? t_dst : 1, r_t, r_stride, r_off, r_ld};
+  TOut t{(float*)t_out, ld_t, t_out ? taps : 1};
+  const int R = 64 * t.taps;
+  const size_t lds = t_out ? (size_t)R * TPITCH * 4 : 0;
+  hipLaunchKernelGGL(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
+                     (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, t);
+  return check_launch("bn_act_fwd_s16");
+}
+
+int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
+                          void* dy, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && y && scale && shift && mean && invstd &&
+                   dgamma && dbeta && out_bound && dy,
+               "bn_bwd_apply_s16: bad argument (needs C %% 64 == 0)");
+  VP3D_REQUIRE(aligned16(go) && aligned16(y) && aligned16(dy), "bn_bwd_apply_s16: 16-byte aligned buffers required");
+  int rc = check_t("bn_bwd_apply_s16", t_out, ld_t, 1, M);
+  if (rc) return rc;
+  const DropP d = make_drop(drop);
+  TOut t{(float*)t_out, ld_t, 1};
+  const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
+  hipLaunchKernelGGL(k_bn_bwd_apply_s16, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream,
+                     (int)M, C, go, y, scale, shift, mean, invstd, d, dgamma, dbeta, out_bound, (float*)dy, t);
+  return check_launch("bn_bwd_apply_s16");
+}
+
+int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,
+                 void* out, int64_t ld_out, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && src && (out || t_out) && ld_src % 4 == 0 &&
+                   aligned16(src) && (out == nullptr || (aligned16(out) && ld_out % 8 == 0)),
+               "split_t: bad argument (needs C %% 64 == 0, 16-byte aligned rows)");
+  int rc = check_t("split_t", t_out, ld_t, 1, M);
+  if (rc) return rc;
+  TOut t{(float*)t_out, ld_t, 1};
+  const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
+  hipLaunchKernelGGL(k_split_t, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
+                     src, ld_src, bound, (float*)out, ld_out, t);
+  return check_launch("split_t");
+}
+
+int vp3d_pack_weight_s16(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
+                         const float* bound, void* wf, int64_t ld_f, void* wd, int64_t ld_d, int32_t dilated_form) {
+  VP3D_REQUIRE(w && bound && (wf || wd) && c_out > 0 && c_in > 0 && taps >= 1 && taps <= 8 && c_out % 64 == 0 && c_in % 64 == 0,
+               "pack_weight_s16: bad argument (needs c_out, c_in %% 64 == 0)");
+  VP3D_REQUIRE((wf == nullptr || (aligned16(wf) && ld_f % 8 == 0 && ld_f >= (int64_t)taps * c_in)) &&
+                   (wd == nullptr || (aligned16(wd) && ld_d % 8 == 0 && ld_d >= (dilated_form ? (int64_t)taps * c_out : c_out))),
+               "pack_weight_s16: bad pitches");
+  const size_t lds = (size_t)taps * 64 * TPITCH * 4;
+  hipLaunchKernelGGL(k_pack_weight_s16, dim3(c_in / 64, c_out / 64), dim3(256), lds, (hipStream_t)stream, c_out, c_in, taps,
+                     w, bound, (float*)wf, ld_f, (float*)wd, ld_d, dilated_form);
+  return check_launch("pack_weight_s16");
+}
+
+int vp3d_act_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* gamma, const float* beta, float p,
+                   const float* res_bound, float* out) {
+  VP3D_REQUIRE(C > 0 && M > 0 && gamma && beta && out && p >= 0.f && p < 1.f, "act_bound: bad argument");
+  hipLaunchKernelGGL(k_act_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, sqrtf((float)(M > 1 ? M - 1 : 1)), gamma,
+                     beta, 1.0f / (1.0f - p), res_bound, out);
+  return check_launch("act_bound");
+}
+
+int vp3d_dy_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* scale, const float* dgamma,
+                  const float* dbeta, const float* go_bound, float p, float* out) {
+  VP3D_REQUIRE(C > 0 && M > 0 && scale && dgamma && dbeta && go_bound && out && p >= 0.f && p < 1.f, "dy_bound: bad argument");
+  hipLaunchKernelGGL(k_dy_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, 1.0f / (float)M,
+                     sqrtf((float)(M > 1 ? M - 1 : 1)), scale, dgamma, dbeta, go_bound, 1.0f / (1.0f - p), out);
+  return check_launch("dy_bound");
+}
+
+}  // extern "C"

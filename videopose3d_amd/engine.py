@@ -289,12 +289,23 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     return grads + [d_sw, d_sb], dx
 
 
+def use_s16(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
+    """True when this call runs on the split-fp16 GEMM path (module attribute ``math`` == "f16x3", see model.py) and the
+    configuration is one engine_s16 implements; everything else runs on the fp32-MFMA kernels."""
+    if getattr(mod, "math", "f32") != "f16x3":
+        return False
+    from . import engine_s16
+    return engine_s16.supported(mod, t_in, training, need_dx)
+
+
 class TemporalStackFn(torch.autograd.Function):
     """Whole-stack training step: forward saves raw conv outputs + BN coefficients; backward is hand-written."""
 
     @staticmethod
     def forward(ctx, mod, x3, *params):
-        out, saved = forward_train(mod, x3, save=True)
+        from . import engine_s16
+        ctx.s16 = use_s16(mod, x3.shape[1], True, x3.requires_grad)
+        out, saved = (engine_s16.forward_train if ctx.s16 else forward_train)(mod, x3, save=True)
         ctx.mod = mod
         ctx.saved = saved
         ctx.need_dx = x3.requires_grad
@@ -304,6 +315,10 @@ class TemporalStackFn(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.saved is None:
             raise RuntimeError("vp3d: backward called twice on the same graph (activations were freed)")
-        grads, dx = backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
+        if ctx.s16:
+            from . import engine_s16
+            grads, dx = engine_s16.backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
+        else:
+            grads, dx = backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
         ctx.saved = None
         return (None, dx) + tuple(grads)

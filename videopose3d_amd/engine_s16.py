@@ -1,0 +1,248 @@
+"""The temporal stack on the split-fp16 ("S16") GEMM path: every 1024-channel contraction runs on
+v_mfma_f32_32x32x16_f16 with fp32-class results (see csrc/vp3d_s16.h), ~3x the fp32-MFMA rate.
+
+Same wiring as ``engine`` (reference common/model.py:126-138 / :187-197); what changes is the form of the GEMM
+operands.  GEMMs read S16, write fp32; the streaming kernels between them read fp32 and write S16:
+
+  training forward   y = conv(a_prev; Wt)            S16 x S16 -> fp32 y + BatchNorm slab statistics
+                     a = [res +] drop(relu(bn(y)))   vp3d_bn_act_fwd_s16: S16 rows (next conv, residual) and the
+                                                     transposed S16 copy the next conv's wgrad reduces over
+  training backward  dy = bn/relu/drop backward      vp3d_bn_bwd_apply_s16: S16 rows (dgrad) + transposed (wgrad)
+                     da = dy @ Wd  (+ residual)      NT GEMM with the transposed weight pack -> fp32 + its max
+                     dW = dy^T @ a_prev^T            NT GEMM over the transposed copies, K = rows, split-K partials
+  eval forward       h = relu(conv(a; W*scale)+shift) [+ res]  -> fp32 + max, then vp3d_split_rows -> S16
+
+Per-tensor exponents come from guaranteed bounds computed on the device (vp3d_act_bound / vp3d_dy_bound: Samuelson's
+inequality on the batch statistics; vp3d_amax or the GEMM epilogue's amax where no bound exists), never from the host.
+The 3*J-column shrink conv and its gradients stay on the fp32-MFMA kernels (0.03 % of the FLOPs).
+
+Supported: channels % 64 == 0 and filter widths <= 3; training additionally needs the strided model on windows that
+tile exactly (T == receptive field, what run.py trains on).  ``supported()`` tells; everything else runs in fp32.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import engine, ops, ops_s16 as S
+from ._lib import RowMap
+from .plan import ConvSpec, StackPlan
+
+
+def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
+    plan: StackPlan = mod._plan
+    c = plan.convs[0].c_out
+    if c % 64 != 0 or plan.convs[0].c_in * plan.convs[0].taps > 128:
+        return False
+    if not training:
+        return True
+    if need_dx or plan.kind != "strided" or max(plan.filter_widths) > 3:
+        return False
+    t = t_in
+    for spec in plan.convs:
+        if spec.taps > 1 and spec.taps * spec.t_out(t) != t:
+            return False
+        t = spec.t_out(t)
+    return True
+
+
+# --------------------------------------------------------------------------------------------------------
+# eval
+# --------------------------------------------------------------------------------------------------------
+def folded_weights(mod):
+    key = engine._eval_key(mod)
+    cache = mod.__dict__.get("_fold_cache_s16")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    packs = [(S.split(wt), shift) for wt, shift in engine.folded_weights(mod)]
+    mod.__dict__["_fold_cache_s16"] = (key, packs)
+    return packs
+
+
+def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+    plan: StackPlan = mod._plan
+    plan.lengths(x3.shape[1])
+    packs = folded_weights(mod)
+    dev = x3.device
+    bounds = torch.zeros((1 + 2 * plan.n_blocks, 1), dtype=torch.float32, device=dev)
+    xin, spec0, _ = engine._expand_input(plan, x3)
+    wt, bias = packs[0]
+    h = S.conv_nt(S.split(xin), wt, spec0, bias=bias, relu=True, amax_out=bounds[0])
+    del xin
+    hs = S.split(h, bounds[0])
+    for i in range(plan.n_blocks):
+        wt, bias = packs[1 + 2 * i]
+        u = S.conv_nt(hs, wt, plan.convs[1 + 2 * i], bias=bias, relu=True, amax_out=bounds[1 + 2 * i])
+        us = S.split(u, bounds[1 + 2 * i])
+        del u, hs
+        wt, bias = packs[2 + 2 * i]
+        h = S.conv_nt(us, wt, plan.convs[2 + 2 * i], bias=bias, relu=True, residual=(h, plan.res[i]),
+                      amax_out=bounds[2 + 2 * i])
+        del us
+        hs = S.split(h, bounds[2 + 2 * i]) if i + 1 < plan.n_blocks else None
+    return engine._shrink(mod, h)
+
+
+# --------------------------------------------------------------------------------------------------------
+# training (strided model)
+# --------------------------------------------------------------------------------------------------------
+class _Saved:
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad")
+
+    def __init__(self, x_t, y, coef, drop, wd, t_in, kpad):
+        self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
+
+
+def forward_train(mod, x3: torch.Tensor, save: bool):
+    plan: StackPlan = mod._plan
+    plan.lengths(x3.shape[1])
+    convs, bns = engine._convs(mod), engine._bns(mod)
+    p = float(mod.drop.p)
+    seed, offset = mod._next_dropout_state() if p > 0 else (0, 0)
+    mod._stats_epoch += 1
+    dev = x3.device
+    n_layers = len(plan.convs)
+    bounds = torch.zeros((2 * n_layers + 2, 1), dtype=torch.float32, device=dev)   # [0,n): activations, [n,2n): weights, 2n: input
+    saved: List[_Saved] = []
+    b = x3.shape[0]
+
+    # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
+    xin, spec0, kpad = engine._expand_input(plan, x3)
+    assert kpad, "the S16 path stages the expand conv through im2row"
+    m0 = xin.shape[0] * xin.shape[1]
+    xb = S.amax(xin, out=bounds[2 * n_layers])
+    x_rows, x_t = S.split_t(xin.view(m0, kpad), xb, want_rows=True, want_t=save)
+    x_rows = S.S16(x_rows.data.view(xin.shape), xb)
+    t_in0 = x3.shape[1]
+    del xin
+
+    def next_taps(idx):
+        """taps of the conv that consumes the activation of layer idx (its wgrad reduces over the transposed copy)."""
+        return plan.convs[idx + 1].taps if idx + 1 < n_layers else 0
+
+    h_prev = None          # S16 block input (residual source)
+    a = x_rows
+    a_t = x_t
+    t_in = t_in0
+    for idx in range(n_layers):
+        spec = spec0 if idx == 0 else plan.convs[idx]
+        w = convs[idx].weight.detach()
+        wb = S.amax(w, out=bounds[n_layers + idx])
+        if idx == 0:
+            wf = S.split(ops.pack_weight(w, ld_out=kpad), wb)
+            wd = None
+        else:
+            wf, wd = S.pack_weight(w, wb, want_fwd=True, want_dgrad=save)
+        t_cur = a.data.shape[1]
+        m_rows = b * spec.t_out(t_cur)
+        stats = ops.stat_buffers(m_rows, spec.c_out, dev)
+        y = S.conv_nt(a, wf, spec, stats=stats)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats)
+        drop = ops.make_dropout(p, seed, offset, idx)
+        residual = None
+        if idx >= 2 and idx % 2 == 0:
+            residual = (h_prev, plan.res[idx // 2 - 1])
+        S.act_bound(bns[idx], m_rows, p, residual[0].bound if residual is not None else None, bounds[idx])
+        if save:
+            saved.append(_Saved(a_t, y, coef, drop, wd, t_in if idx == 0 else t_cur, kpad if idx == 0 else 0))
+        a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0)
+        if idx % 2 == 0:
+            h_prev = a
+    h_last = S.join(a)                       # [B, 1, C] fp32 for the 3*J-column shrink conv (fp32-MFMA path)
+    out = engine._shrink(mod, h_last)
+    if not save:
+        return out, None
+    return out, dict(layers=saved, h_last=h_last, wts=ops.pack_weight(mod.shrink.weight.detach()), bounds=bounds)
+
+
+def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
+    assert not need_dx
+    plan: StackPlan = mod._plan
+    L: List[_Saved] = saved["layers"]
+    h_last = saved["h_last"]
+    b, t_out, _ = h_last.shape
+    dev = gout3.device
+    gout3 = gout3.contiguous()
+    g2 = gout3.view(b * t_out, -1)
+    p = float(mod.drop.p)
+    sink = mod.__dict__.get("_vp3d_grad_sink")
+    convs, bns = engine._convs(mod), engine._bns(mod)
+    n_layers = len(L)
+    bounds = torch.zeros((2 * n_layers + 1, 1), dtype=torch.float32, device=dev)   # [0,n): go of layer i, [n,2n): dy of layer i
+
+    def view(prm):
+        return sink.view_for(prm) if sink is not None else None
+
+    def sunk(value, out):
+        return None if out is not None else value
+
+    o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
+    d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
+    d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
+    dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
+    last = n_layers - 1
+    S.amax(dh, out=bounds[last])
+    grads = [None] * (3 * n_layers)
+    n_done = [0]
+
+    def group_done():
+        if sink is not None:
+            sink.group_done(n_done[0])
+        n_done[0] += 1
+
+    group_done()                                     # shrink
+
+    def act_bwd(idx, go):
+        s = L[idx]
+        o_g, o_bt = view(bns[idx].weight), view(bns[idx].bias)
+        if o_g is None or o_bt is None:
+            o_g = o_bt = None
+        dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
+                                            out_dgamma=o_g, out_dbeta=o_bt)
+        grads[3 * idx + 1] = sunk(dgam, o_g)
+        grads[3 * idx + 2] = sunk(dbet, o_bt)
+        return dy, dy_t
+
+    def wgrad(idx, dy_t):
+        spec = plan.convs[idx]
+        out = view(convs[idx].weight)
+        n_cols = L[idx].kpad if L[idx].kpad else spec.taps * spec.c_in
+        m_rows = L[idx].y.shape[0] * L[idx].y.shape[1]
+        dw = S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
+        grads[3 * idx] = sunk(dw, out)
+
+    def dgrad(idx, dy, residual, amax_out):
+        """dx of conv idx (strided: plain GEMM dy @ Wd into [B*T_out, taps*C_in] == [B, T_in, C_in])."""
+        spec: ConvSpec = plan.convs[idx]
+        bb, t_o, c_out = dy.data.shape
+        taps, c_in = spec.taps, spec.c_in
+        t_i = L[idx].t_in
+        assert taps * t_o == t_i
+        dx = torch.empty((bb, t_i, c_in), dtype=torch.float32, device=dev)
+        rm = RowMap(bb, t_o, t_o, 1, 0, 0, 1)
+        e = None
+        if residual is not None:
+            r, rs = residual                          # dx[b, start + step*t] += r[b, t],  step == taps
+            assert rs.step == taps and r.shape == (bb, t_o, c_in)
+            e = ops._epi(residual=(r, 1, 0, rs.start * c_in), n_cols=taps * c_in)
+        S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, taps * c_in, dx, t_i * c_in, taps * c_in, epi=e, amax_out=amax_out,
+                    family="tconv_dgrad")
+        return dx
+
+    for i in reversed(range(plan.n_blocks)):
+        i1, i2 = 1 + 2 * i, 2 + 2 * i
+        dy2, dy2_t = act_bwd(i2, dh)
+        da1 = dgrad(i2, dy2, None, bounds[i1])
+        wgrad(i2, dy2_t)
+        del dy2, dy2_t
+        dy1, dy1_t = act_bwd(i1, da1)
+        del da1
+        dh = dgrad(i1, dy1, (dh, plan.res[i]), bounds[2 * i])
+        wgrad(i1, dy1_t)
+        group_done()
+        del dy1, dy1_t
+    dy0, dy0_t = act_bwd(0, dh)
+    wgrad(0, dy0_t)
+    group_done()
+    return grads + [d_sw, d_sb], None

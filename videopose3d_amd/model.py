@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import engine
+from . import engine, engine_s16
 from ._lib import Vp3dError
 from .plan import make_plan
 
@@ -43,6 +43,10 @@ class TemporalModelBase(nn.Module):
         self._stats_epoch = 0
         self._drop_calls = 0
         self._drop_seed = None
+        # GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products), "f16x3" = split-fp16 operands on
+        # v_mfma_f32_32x32x16_f16 (fp32-class: 22+ operand bits, fp32 accumulation; ~3x faster).  Not part of the
+        # reference API / state_dict; default from VP3D_MATH.
+        self.math = os.environ.get("VP3D_MATH", "f32")
 
     # ---- construction helper shared by the two concrete classes -------------------------------------
     def _build(self, channels, causal, dense, strided):
@@ -116,13 +120,15 @@ class TemporalModelBase(nn.Module):
                     out3 = engine.TemporalStackFn.apply(self, x3, *engine.param_list(self))
                 else:
                     with torch.no_grad():
-                        out3, _ = engine.forward_train(self, x3, save=False)
+                        fwd = engine_s16.forward_train if engine.use_s16(self, t, True) else engine.forward_train
+                        out3, _ = fwd(self, x3, save=False)
             else:
                 if torch.is_grad_enabled() and x.requires_grad:
                     raise Vp3dError("gradients through the eval-mode (folded BatchNorm) path are not implemented; "
                                     "call model.train() or wrap evaluation in torch.no_grad() as run.py does")
                 with torch.no_grad():
-                    out3 = engine.forward_eval(self, x3)
+                    fwd = engine_s16.forward_eval if engine.use_s16(self, t, False) else engine.forward_eval
+                    out3 = fwd(self, x3)
         return out3.view(b, -1, self.num_joints_out, 3)
 
 

@@ -109,3 +109,146 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
                     nbytes=4.0 * (xd.numel() + wd.numel() + out.numel() + (out.numel() if residual is not None else 0)))
     return out
+
+
+def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: torch.Tensor, y_bpitch: int, ldy: int,
+              *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0):
+    """Raw form of conv_nt: out[b*y_bpitch + t*ldy + n] = sum_k x[gather] * wt[n][k] (+ epilogue)."""
+    xd, wd = x.data, wt.data
+    m, k = rm.batch * rm.t_dst, rm.taps * c_in
+    o, ws = _opts(x, wt, m, n, k, xd.device, amax_out, cfg, splits)
+    ops._timed_call(family, 2.0 * m * n * k, _lib.lib().vp3d_tconv_nt_s16,
+                    ops._stream(), C.byref(rm), xd.data_ptr(), xd.shape[-1], c_src, wd.data_ptr(), wd.shape[-1], n,
+                    out.data_ptr(), y_bpitch, ldy, C.byref(epi) if epi is not None else None,
+                    ops.zeros_page(xd.device).data_ptr(), C.byref(o),
+                    nbytes=4.0 * (xd.numel() + wd.numel() + m * n))
+    return out
+
+
+def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, out: Optional[torch.Tensor] = None,
+          flops_rows: int = 0) -> torch.Tensor:
+    """dW [c_out, c_in, taps] (reference layout) from the transposed operands dy_t [c_out][Mp], x_t [n_cols][Mp]
+    (S16 rows along the reduction index m; n_cols >= taps*c_in): one NT GEMM with K = Mp into raw split-K partial
+    matrices, summed and un-packed by vp3d_wgrad_reduce."""
+    mp = dy_t.data.shape[-1]
+    assert dy_t.data.shape == (c_out, mp) and x_t.data.shape == (n_cols, mp), (dy_t.data.shape, x_t.data.shape)
+    dev = dy_t.data.device
+    cfg, splits = plan(c_out, n_cols, mp)
+    o, ws = _opts(dy_t, x_t, c_out, n_cols, mp, dev, None, cfg, splits, raw=True)
+    rm = RowMap(1, c_out, c_out, 1, 0, 0, 1)
+    ops._timed_call("tconv_wgrad", 2.0 * (flops_rows or mp) * c_out * taps * c_in, _lib.lib().vp3d_tconv_nt_s16,
+                    ops._stream(), C.byref(rm), dy_t.data.data_ptr(), mp, mp, x_t.data.data_ptr(), mp, n_cols,
+                    None, 0, n_cols, None, ops.zeros_page(dev).data_ptr(), C.byref(o),
+                    nbytes=4.0 * (dy_t.data.numel() + x_t.data.numel() + c_out * n_cols))
+    if out is None:
+        out = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dev)
+    check(_lib.lib().vp3d_wgrad_reduce(ops._stream(), ws.data_ptr(), n_cols, splits, c_out, c_in, taps, out.data_ptr()),
+          "vp3d_wgrad_reduce")
+    return out
+
+
+def t_pitch(m_rows: int, taps: int = 1) -> int:
+    return (m_rows // taps + 63) // 64 * 64
+
+
+def split_t(t2d: torch.Tensor, bound: torch.Tensor, want_rows=True, want_t=True):
+    """fp32 [M, C] -> (S16 rows or None, S16 transposed [C][roundup(M,64)] or None)."""
+    ops._chk(t2d, "t")
+    m, c = t2d.shape
+    rows = torch.empty_like(t2d) if want_rows else None
+    tt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=t2d.device) if want_t else None
+    check(_lib.lib().vp3d_split_t(ops._stream(), m, c, t2d.data_ptr(), c, bound.data_ptr(), ops._p(rows), c, ops._p(tt),
+                                  tt.shape[1] if tt is not None else 0), "vp3d_split_t")
+    return (S16(rows, bound) if rows is not None else None), (S16(tt, bound) if tt is not None else None)
+
+
+def pack_weight(w: torch.Tensor, bound: torch.Tensor, want_fwd=True, want_dgrad=True, dilated_form=False):
+    """Conv1d.weight [C_out, C_in, taps] -> (S16 forward pack [C_out, taps*C_in], S16 dgrad pack)."""
+    ops._chk(w, "weight")
+    c_out, c_in, taps = w.shape
+    wf = torch.empty((c_out, taps * c_in), dtype=torch.float32, device=w.device) if want_fwd else None
+    wd = None
+    if want_dgrad:
+        wd = torch.empty((c_in, taps * c_out) if dilated_form else (taps * c_in, c_out), dtype=torch.float32, device=w.device)
+    check(_lib.lib().vp3d_pack_weight_s16(ops._stream(), w.data_ptr(), c_out, c_in, taps, bound.data_ptr(), ops._p(wf),
+                                          taps * c_in, ops._p(wd), wd.shape[1] if wd is not None else 0,
+                                          1 if dilated_form else 0), "vp3d_pack_weight_s16")
+    return (S16(wf, bound) if wf is not None else None), (S16(wd, bound) if wd is not None else None)
+
+
+def act_bound(bn: torch.nn.BatchNorm1d, m_rows: int, p: float, res_bound: Optional[torch.Tensor], out: torch.Tensor):
+    check(_lib.lib().vp3d_act_bound(ops._stream(), bn.num_features, m_rows, bn.weight.data_ptr(), bn.bias.data_ptr(), float(p),
+                                    ops._p(res_bound), out.data_ptr()), "vp3d_act_bound")
+    return out
+
+
+def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tuple[S16, ResSpec]], out_bound: torch.Tensor,
+               t_taps: int = 0):
+    """a = [res +] dropout(relu(bn(y))) as S16 rows [B,T,C] (+ the transposed copy for the consuming conv's wgrad when
+    t_taps > 0: [t_taps*C][roundup(M/t_taps, 64)])."""
+    ops._chk(y, "y")
+    b, t, c = y.shape
+    m = b * t
+    out = torch.empty_like(y)
+    tt = None
+    if t_taps:
+        assert m % t_taps == 0
+        tt = torch.empty((t_taps * c, t_pitch(m, t_taps)), dtype=torch.float32, device=y.device)
+    if residual is not None:
+        r, rs = residual
+        rd = r.data
+        assert rd.shape[0] == b and rd.shape[2] == c and rs.start + rs.step * (t - 1) < rd.shape[1]
+        rargs = (rd.data_ptr(), r.bound.data_ptr(), t, rd.shape[1], rs.step, rs.start, c)
+    else:
+        rargs = (None, None, t, 0, 0, 0, c)
+    check(_lib.lib().vp3d_bn_act_fwd_s16(ops._stream(), m, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                         C.byref(drop) if drop is not None else None, *rargs, out_bound.data_ptr(),
+                                         out.data_ptr(), ops._p(tt), tt.shape[1] if tt is not None else 0, max(t_taps, 1)),
+          "vp3d_bn_act_fwd_s16")
+    return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
+
+
+def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
+               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None):
+    """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows, dy S16 transposed, dgamma, dbeta)."""
+    ops._chk(go, "go")
+    ops._chk(y, "y")
+    b, t, c = y.shape
+    assert go.shape == y.shape
+    m = b * t
+    L = _lib.lib()
+    dref = C.byref(drop) if drop is not None else None
+    nparts = C.c_int32(0)
+    check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, None, None, None, None, None, None, None, None, C.byref(nparts)),
+          "vp3d_bn_bwd_reduce(query)")
+    parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
+    sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
+    check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
+                               C.byref(nparts)), "vp3d_bn_bwd_reduce")
+    if out_dgamma is not None and out_dbeta is not None:
+        dgam, dbet = out_dgamma, out_dbeta
+    else:
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        dgam, dbet = dgb[0], dgb[1]
+    check(L.vp3d_bn_bwd_finalize(ops._stream(), c, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr()),
+          "vp3d_bn_bwd_finalize")
+    check(L.vp3d_dy_bound(ops._stream(), c, m, sc, dgam.data_ptr(), dbet.data_ptr(), go_bound.data_ptr(), float(p),
+                          dy_bound.data_ptr()), "vp3d_dy_bound")
+    dy = torch.empty_like(y)
+    dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device)
+    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
+                                  dbet.data_ptr(), dy_bound.data_ptr(), dy.data_ptr(), dyt.data_ptr(), dyt.shape[1]),
+          "vp3d_bn_bwd_apply_s16")
+    return S16(dy, dy_bound), S16(dyt, dy_bound), dgam, dbet
+
+
+def join(x: S16) -> torch.Tensor:
+    """S16 -> fp32 (small tensors only: done with torch ops on the raw halves)."""
+    d = x.data
+    h = d.view(torch.float16).view(*d.shape[:-1], d.shape[-1] // 8, 2, 8).to(torch.float32)
+    v = (h[..., 0, :] + h[..., 1, :]).reshape(d.shape)
+    if x.bound is None:
+        return v
+    e = torch.frexp(x.bound)[1].to(torch.float32) - 15.0
+    e = torch.where((x.bound > 0) & (x.bound < 3.0e38), e, torch.zeros_like(e))
+    return v * torch.exp2(e)
