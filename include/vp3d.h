@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 101
+#define VP3D_VERSION 102
+#define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
 #define VP3D_E_INVALID (-1)   /* bad argument (null pointer, size, alignment) */
@@ -153,11 +154,13 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
  * units).  a*b is evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with fp32 accumulation.
  * ------------------------------------------------------------------------------------------------------------ */
 /* Extra arguments of the S16 GEMM.
- *   x_bound / w_bound : device floats, guaranteed bounds of max|.| of the two operand tensors; their S16 exponent is
+ *   x_bound / w_bound : device "bounds" of max|.| of the two operand tensors.  A bound is VP3D_BOUND_SLOTS (32)
+ *                       consecutive floats whose maximum is a guaranteed bound (measuring kernels spread their atomics
+ *                       over the slots; computed bounds sit in slot 0 of a zeroed array).  The S16 exponent is
  *                       e = frexp-exponent(bound) - 15 (so |v * 2^-e| < 2^15); NULL = exponent 0.  The accumulator is
  *                       scaled by 2^(e_x + e_w) before the epilogue.
- *   amax_out          : optional device float, atomically max-ed with |stored value| (the bound of the result for a
- *                       consumer that re-splits it; zero it before the launch)
+ *   amax_out          : optional bound, atomically max-ed with |stored value| (the bound of the result for a
+ *                       consumer that re-splits it; zero its 32 slots before the launch)
  *   cfg               : tile configuration (0: 128x128 tiles / 4 waves, 4: 256x256 tiles / 8 waves, -1: planned)
  *   splits            : K slices (1 = none, 0 = planned: vp3d_nt_s16_plan); > 1 needs ws of splits*M*N floats.
  *                       The slices write raw scaled partial matrices [splits][M][N]; a finishing pass sums them and
@@ -173,7 +176,7 @@ typedef struct vp3d_s16 {
   int64_t ws_floats;
   int32_t raw_partials;
 } vp3d_s16;
-int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t* cfg, int32_t* splits);
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
 /* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form
  * (c_in % 32 == 0, 16-byte aligned rows, ldx / ldw in 4-byte units).  Every GEMM of the model runs through it:
  *   forward : wt = S16 of the packed rows Wt[co][k*c_in+ci]
@@ -186,7 +189,7 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
 /* fp32 rows [M][C] (pitch ld_src floats) -> S16 rows (pitch ld_dst 4-byte units) with the exponent of *bound */
 int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, void* dst,
                     int64_t ld_dst, const float* bound);
-/* *bound = max(*bound, max|src[0..n)|)   (atomic; zero *bound first) */
+/* bound (32 slots) = max(bound, max|src[0..n)|)   (atomic; zero the slots first) */
 int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound);
 
 /* Producers of S16 operands (streaming kernels; C % 64 == 0).  "t_out" is the optional TRANSPOSED copy the weight-
@@ -194,11 +197,11 @@ int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound);
  * strided conv that consumes the tensor, 1 otherwise; M % taps == 0), S16 rows along m, ld_t >= roundup(M/taps, 64)
  * 4-byte units, columns [M/taps, roundup(M/taps, 64)) zero-filled.  Bounds are device floats (see vp3d_s16). */
 /* out = [res +] dropout(relu(y*scale + shift)) as S16 with the exponent of *out_bound; res (S16, exponent of *res_bound)
- * is addressed as in vp3d_bn_act_fwd */
+ * is addressed as in vp3d_bn_act_fwd; out_f32 (may be NULL) additionally receives the plain fp32 values */
 int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
                         int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
-                        const float* out_bound, void* out, void* t_out, int64_t ld_t, int32_t taps);
+                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps);
 /* dy of vp3d_bn_bwd_apply as S16 rows (+ transposed copy, taps = 1) */
 int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                           const float* scale, const float* shift, const float* mean, const float* invstd,

@@ -48,7 +48,7 @@ def accuracy(cfgs):
                 print("  s16 cfg %d splits %d max err/sum|ab| %.3e   max|y-y32| %.3e  stats diff %.2e %.2e  amax %.6f (true %.6f)" % (
                     cfg, splits, float(((y.double() - ref).abs() / den).max()),
                     float((y - y32).abs().max()), float((stats[0] - st32[0]).abs().max()), float((stats[1] - st32[1]).abs().max()),
-                    float(am), float(y.abs().max())))
+                    float(am.max()), float(y.abs().max())))
 
 
 def perf(cfgs):

@@ -167,10 +167,10 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
   return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/true);
 }
 
-int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t* cfg, int32_t* splits) {
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && cfg && splits, "nt_s16_plan: bad argument");
   int c, sp;
-  plan_nt_s16((int)M, N, K, 1, &c, &sp);
+  plan_nt_s16((int)M, N, K, 1, raw_partials, &c, &sp);
   *cfg = c;
   *splits = sp;
   return VP3D_OK;

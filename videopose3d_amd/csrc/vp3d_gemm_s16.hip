@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const Epi& e = p.epi;
   {
     int ex = 0;
-    if (e.bound_a != nullptr) ex += s16_exp_for_bound(*e.bound_a);
-    if (e.bound_b != nullptr) ex += s16_exp_for_bound(*e.bound_b);
+    if (e.bound_a != nullptr) ex += s16_exp_of(e.bound_a);
+    if (e.bound_b != nullptr) ex += s16_exp_of(e.bound_b);
     if (ex != 0) {
       const float scale = s16_pow2(ex);
 #pragma unroll
@@ -353,7 +353,14 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   if (!partial && e.amax_out != nullptr) {             // max|stored value| of the whole launch (S16 exponent of the result)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (lane == 0) atomicMax(reinterpret_cast<int*>(e.amax_out), __float_as_int(amax));
+    float* red = reinterpret_cast<float*>(smem);       // the staging regions are free (trailing barrier of the loop above)
+    if (lane == 0) red[w] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0];
+      for (int i = 1; i < C::NW; ++i) m = fmaxf(m, red[i]);
+      s16_atomic_bound(e.amax_out, m);
+    }
   }
 }
 
@@ -467,7 +474,10 @@ __global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ pa
   if (e.amax_out != nullptr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(e.amax_out), __float_as_int(amax));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) mean_s[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) s16_atomic_bound(e.amax_out, fmaxf(fmaxf(mean_s[0], mean_s[1]), fmaxf(mean_s[2], mean_s[3])));
   }
 }
 
@@ -475,11 +485,11 @@ __global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ pa
 __global__ void __launch_bounds__(256) k_split_rows(int64_t groups, int groups_per_row, const float* __restrict__ src,
                                                     int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
                                                     const float* __restrict__ bound) {
+  const float inv = bound != nullptr ? s16_pow2(-s16_exp_of(bound)) : 1.f;
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= groups) return;
   const int64_t row = g / groups_per_row;
   const int gc = (int)(g - row * groups_per_row);
-  const float inv = bound != nullptr ? s16_pow2(-s16_exp_for_bound(*bound)) : 1.f;
   const float* s = src + row * ld_src + gc * 8;
   const f32x4 v0 = *reinterpret_cast<const f32x4*>(s);
   const f32x4 v1 = *reinterpret_cast<const f32x4*>(s + 4);
@@ -495,10 +505,19 @@ __global__ void __launch_bounds__(256) k_split_rows(int64_t groups, int groups_p
 __global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict__ src, float* __restrict__ bound) {
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(src[i]));
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? n >> 2 : 0;      // 16-B loads when aligned
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = s4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(src[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(bound), __float_as_int(m));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) s16_atomic_bound(bound, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 template <class C>
@@ -519,26 +538,27 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
 
 }  // namespace
 
-// Tile configuration and split-K factor of an [M,N,K] S16 GEMM.  Cost model in units of one 32-element K-tile of a
-// 128x128 tile on one CU (measured on MI355X: the 256x256 / 8-wave configuration sustains ~420 TF-equivalent on large
-// problems, the 128x128 / 4-wave one ~360 but fills the chip from 4x fewer rows), the finishing pass of a split
-// launch streams the partial matrices once each way.
-void plan_nt_s16(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out) {
+// Tile configuration and split-K factor of an [M,N,K] S16 GEMM: cost model in microseconds fitted to MI355X
+// measurements (tools/s16_tune.py).  A CU works through ceil(workgroups/256) workgroups; per 32-element K-tile a
+// 128x128 tile takes ~0.74 us of a CU when two workgroups share it (0.85 us alone), a 256x256 tile ~2.55 us (2.1 us
+// when fewer than 256 are in flight); the finishing pass of a split forward/dgrad launch streams the partial
+// matrices (mostly Infinity-Cache resident) once each way, a raw (wgrad) launch leaves that to vp3d_wgrad_reduce.
+void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out) {
   const int nkt = K / BK;
   double best = 1e30;
   int best_cfg = 0, best_s = 1;
   for (int cfg = 0; cfg < 2; ++cfg) {
-    const int bm = cfg == 0 ? 128 : 256, bn = cfg == 0 ? 128 : 256;
-    const double tile_cost = cfg == 0 ? 1.0 : 4.0 * 364.0 / 422.0;      // per K-tile, relative to a 128x128 tile
-    const double fixed = cfg == 0 ? 4.0 : 10.0;                          // prologue + epilogue, in K-tiles of its own size
-    const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int bt = cfg == 0 ? 128 : 256;
+    const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
     for (int s = 1; s <= (allow_split ? 64 : 1); ++s) {
-      if (s > 1 && nkt / s < 8) break;
-      const double rounds = (double)((tiles * s + 255) / 256);
-      double cost = rounds * ((double)((nkt + s - 1) / s) + fixed) * tile_cost;
-      // finish: s*M*N floats written + read at ~4 TB/s; one K-tile of a 128x128 tile ~ 0.27 us on this path
-      if (s > 1) cost += (3.0 + (double)s * (double)M * (double)N * 8.0 / 4.0e6) / 0.27;
-      if (cost < best * 0.97) {
+      if (s > 1 && (nkt / s < 6 || cfg != 0)) break;                // the 256x256 configuration only pays unsplit
+      const int64_t per_cu = (tiles * s + 255) / 256;
+      const double nk = (double)((nkt + s - 1) / s);
+      double cost = 5.0;
+      if (cfg == 0) cost += (double)per_cu * (nk * (per_cu >= 2 ? 0.74 : 0.85) + 2.0);
+      else cost += (double)per_cu * (nk * (per_cu >= 2 ? 2.55 : 2.1) + 5.0);
+      if (s > 1) cost += (raw ? 0.0 : 4.0) + (double)s * (double)M * (double)N * (raw ? 4.0 : 8.0) / 8.0e6;
+      if (cost < best * 0.98) {
         best = cost;
         best_cfg = cfg == 0 ? 0 : 4;
         best_s = s;
@@ -559,7 +579,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
                "nt_s16: the split-fp16 GEMM needs channel counts %% 32 == 0 and 16-byte aligned S16 rows");
   if (cfg < 0) {
     int pc, ps;
-    plan_nt_s16(a.M, a.N, a.K, ws != nullptr, &pc, &ps);
+    plan_nt_s16(a.M, a.N, a.K, ws != nullptr, raw_partials ? 1 : 0, &pc, &ps);
     cfg = pc;
     if (splits <= 0) splits = ps;
   }
@@ -601,8 +621,8 @@ int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int
 }
 
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound) {
-  const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, n, src, bound);
+  const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);          // >= 2 float4 per thread
+  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, src, bound);
   return check_launch("amax");
 }
 

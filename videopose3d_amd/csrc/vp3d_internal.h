@@ -98,7 +98,7 @@ int red_gemm_splits(int Mred, int Mo, int N);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
 // split-fp16 NT GEMM (vp3d_gemm_s16.hip); cfg selects the tile configuration
-void plan_nt_s16(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out);
+void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out);
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, float* ws, int64_t ws_floats,
                   bool raw_partials);
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,

@@ -28,6 +28,21 @@ __device__ __forceinline__ int s16_exp_for_bound(float bound) {
   return ex - 15;
 }
 
+// A "bound" is VP3D_BOUND_SLOTS consecutive floats whose maximum is the bound: kernels that measure a maximum spread
+// their atomicMax over the slots (one per workgroup, slot = workgroup id % slots) instead of hammering one address;
+// computed bounds are written to slot 0 of a zeroed array.  Every lane of the calling wave gets the result.
+constexpr int kBoundSlots = 32;
+__device__ __forceinline__ float s16_load_bound(const float* __restrict__ b) {
+  float m = b[threadIdx.x & (kBoundSlots - 1)];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+__device__ __forceinline__ int s16_exp_of(const float* __restrict__ b) { return s16_exp_for_bound(s16_load_bound(b)); }
+__device__ __forceinline__ void s16_atomic_bound(float* b, float v) {
+  atomicMax(reinterpret_cast<int*>(b + (blockIdx.x & (kBoundSlots - 1))), __float_as_int(v));
+}
+
 __device__ __forceinline__ void s16_split8(const float (&v)[8], float inv_scale, f16x8& hi, f16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

@@ -56,7 +56,7 @@ struct ResS16 {
 __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const float* __restrict__ y,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         DropP d, ResS16 rm, const float* __restrict__ out_bound,
-                                                        float* __restrict__ out, TOut t) {
+                                                        float* __restrict__ out, float* __restrict__ out_f32, TOut t) {
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
     sc[e] = scale[c + e];
     sh[e] = shift[c + e];
   }
-  const float inv = s16_pow2(-s16_exp_for_bound(*out_bound));
-  const float rscale = rm.res != nullptr ? s16_pow2(s16_exp_for_bound(*rm.bound)) : 0.f;
+  const float inv = s16_pow2(-s16_exp_of(out_bound));
+  const float rscale = rm.res != nullptr ? s16_pow2(s16_exp_of(rm.bound)) : 0.f;
   for (int r = rsub; r < R; r += 32) {
     const int64_t m = m0 + r;
     float v[8];
@@ -101,8 +101,14 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
       for (int e = 0; e < 8; ++e) {
         const float yy = e < 4 ? y0[e] : y1[e - 4];
         const float z = fmaf(yy, sc[e], sh[e]);
-        v[e] = (rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f))) * inv;
+        v[e] = rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f));
       }
+      if (out_f32 != nullptr) {
+        *reinterpret_cast<f32x4*>(out_f32 + e0) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(out_f32 + e0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= inv;
       f16x8 hi, lo;
       s16_split8(v, 1.f, hi, lo);
       f16x8* o = reinterpret_cast<f16x8*>(out + e0);
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
     kb[e] = dbeta[c + e] * inv_m;
     kg[e] = dgamma[c + e] * inv_m;
   }
-  const float inv = s16_pow2(-s16_exp_for_bound(*out_bound));
+  const float inv = s16_pow2(-s16_exp_of(out_bound));
   for (int r = rsub; r < 64; r += 32) {
     const int64_t m = m0 + r;
     float v[8];
@@ -201,7 +207,7 @@ __global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __re
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
   const int64_t m0 = (int64_t)blockIdx.y * 64;
-  const float inv = bound != nullptr ? s16_pow2(-s16_exp_for_bound(*bound)) : 1.f;
+  const float inv = bound != nullptr ? s16_pow2(-s16_exp_of(bound)) : 1.f;
   for (int r = rsub; r < 64; r += 32) {
     const int64_t m = m0 + r;
     float v[8];
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(256) k_pack_weight_s16(int c_out, int c_in, in
                                                          int dilated_form) {
   extern __shared__ float tile[];                 // [taps][64 co][TPITCH] (ci fastest)
   const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
-  const float inv = s16_pow2(-s16_exp_for_bound(*bound));
+  const float inv = s16_pow2(-s16_exp_of(bound));
   const int row_f = 64 * taps;                    // contiguous floats per co row of the tile
   for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
     const int co = idx / row_f, q = idx - co * row_f;     // q = ci_local*taps + k
@@ -299,10 +305,11 @@ __global__ void __launch_bounds__(1024) k_act_bound(int C, float sqrt_m1, const 
                                                     const float* __restrict__ beta, float inv_keep,
                                                     const float* __restrict__ res_bound, float* __restrict__ out) {
   __shared__ float red[1024];
+  const float rb = res_bound != nullptr ? s16_load_bound(res_bound) : 0.f;
   float m = 0.f;
   for (int c = threadIdx.x; c < C; c += 1024) m = fmaxf(m, fabsf(gamma[c]) * sqrt_m1 + fabsf(beta[c]));
   m = block_max_1024(m, red);
-  if (threadIdx.x == 0) out[0] = m * inv_keep + (res_bound != nullptr ? res_bound[0] : 0.f);
+  if (threadIdx.x == 0) out[0] = m * inv_keep + rb;
 }
 
 // |dy_c| <= |scale_c| * (gmax + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M),  gmax = go_bound / (1-p)
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(1024) k_dy_bound(int C, float inv_m, float sqr
                                                    const float* __restrict__ go_bound, float inv_keep,
                                                    float* __restrict__ out) {
   __shared__ float red[1024];
-  const float gmax = go_bound[0] * inv_keep;
+  const float gmax = s16_load_bound(go_bound) * inv_keep;
   float m = 0.f;
   for (int c = threadIdx.x; c < C; c += 1024)
     m = fmaxf(m, fabsf(scale[c]) * (gmax + fabsf(dbeta[c]) * inv_m + sqrt_m1 * fabsf(dgamma[c]) * inv_m));
@@ -337,8 +344,9 @@ extern "C" {
 int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
                         int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
-                        const float* out_bound, void* out, void* t_out, int64_t ld_t, int32_t taps) {
-  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && y && scale && shift && out && out_bound,
+                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && y && scale && shift && out && out_bound &&
+                   (out_f32 == nullptr || aligned16(out_f32)),
                "bn_act_fwd_s16: bad argument (needs C %% 64 == 0)");
   VP3D_REQUIRE(aligned16(y) && aligned16(out) && (res == nullptr || (aligned16(res) && res_bound && r_ld % 8 == 0)),
                "bn_act_fwd_s16: 16-byte aligned buffers required");
@@ -351,7 +359,7 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   const int R = 64 * t.taps;
   const size_t lds = t_out ? (size_t)R * TPITCH * 4 : 0;
   hipLaunchKernelGGL(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
-                     (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, t);
+                     (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, out_f32, t);
   return check_launch("bn_act_fwd_s16");
 }
 

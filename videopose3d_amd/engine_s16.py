@@ -65,7 +65,7 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
     plan.lengths(x3.shape[1])
     packs = folded_weights(mod)
     dev = x3.device
-    bounds = torch.zeros((1 + 2 * plan.n_blocks, 1), dtype=torch.float32, device=dev)
+    bounds = S.new_bounds(1 + 2 * plan.n_blocks, dev)
     xin, spec0, _ = engine._expand_input(plan, x3)
     wt, bias = packs[0]
     h = S.conv_nt(S.split(xin), wt, spec0, bias=bias, relu=True, amax_out=bounds[0])
@@ -103,7 +103,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     mod._stats_epoch += 1
     dev = x3.device
     n_layers = len(plan.convs)
-    bounds = torch.zeros((2 * n_layers + 2, 1), dtype=torch.float32, device=dev)   # [0,n): activations, [n,2n): weights, 2n: input
+    bounds = S.new_bounds(2 * n_layers + 1, dev)   # [0,n): activations, [n,2n): weights, 2n: input
     saved: List[_Saved] = []
     b = x3.shape[0]
 
@@ -146,10 +146,12 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         S.act_bound(bns[idx], m_rows, p, residual[0].bound if residual is not None else None, bounds[idx])
         if save:
             saved.append(_Saved(a_t, y, coef, drop, wd, t_in if idx == 0 else t_cur, kpad if idx == 0 else 0))
-        a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0)
+        if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
+            a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True)
+        else:
+            a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0)
         if idx % 2 == 0:
             h_prev = a
-    h_last = S.join(a)                       # [B, 1, C] fp32 for the 3*J-column shrink conv (fp32-MFMA path)
     out = engine._shrink(mod, h_last)
     if not save:
         return out, None
@@ -169,7 +171,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     sink = mod.__dict__.get("_vp3d_grad_sink")
     convs, bns = engine._convs(mod), engine._bns(mod)
     n_layers = len(L)
-    bounds = torch.zeros((2 * n_layers + 1, 1), dtype=torch.float32, device=dev)   # [0,n): go of layer i, [n,2n): dy of layer i
+    bounds = S.new_bounds(2 * n_layers, dev)   # [0,n): go of layer i, [n,2n): dy of layer i
 
     def view(prm):
         return sink.view_for(prm) if sink is not None else None

@@ -30,8 +30,16 @@ class S16:
         return None if self.bound is None else self.bound.data_ptr()
 
 
+BOUND_SLOTS = 32        # VP3D_BOUND_SLOTS: a bound = 32 floats whose maximum is the bound
+
+
 def new_bound(device) -> torch.Tensor:
-    return torch.zeros(1, dtype=torch.float32, device=device)
+    return torch.zeros(BOUND_SLOTS, dtype=torch.float32, device=device)
+
+
+def new_bounds(n: int, device) -> torch.Tensor:
+    """n zeroed bounds: index with [i] to get the i-th (a contiguous 32-float row)."""
+    return torch.zeros((n, BOUND_SLOTS), dtype=torch.float32, device=device)
 
 
 def amax(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -55,9 +63,9 @@ def split(t: torch.Tensor, bound: Optional[torch.Tensor] = None, measure: bool =
     return S16(out, bound)
 
 
-def plan(m: int, n: int, k: int) -> Tuple[int, int]:
+def plan(m: int, n: int, k: int, raw: bool = False) -> Tuple[int, int]:
     cfg, splits = C.c_int32(0), C.c_int32(1)
-    check(_lib.lib().vp3d_nt_s16_plan(m, n, k, C.byref(cfg), C.byref(splits)), "vp3d_nt_s16_plan")
+    check(_lib.lib().vp3d_nt_s16_plan(m, n, k, 1 if raw else 0, C.byref(cfg), C.byref(splits)), "vp3d_nt_s16_plan")
     return cfg.value, splits.value
 
 
@@ -67,7 +75,7 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
     o.w_bound = w.bound_ptr()
     o.amax_out = None if amax_out is None else amax_out.data_ptr()
     if cfg < 0 or splits <= 0:
-        pc, ps = plan(m, n, k)
+        pc, ps = plan(m, n, k, raw)
         cfg = pc if cfg < 0 else cfg
         splits = ps if splits <= 0 else splits
     o.cfg, o.splits = cfg, splits
@@ -133,7 +141,7 @@ def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, ou
     mp = dy_t.data.shape[-1]
     assert dy_t.data.shape == (c_out, mp) and x_t.data.shape == (n_cols, mp), (dy_t.data.shape, x_t.data.shape)
     dev = dy_t.data.device
-    cfg, splits = plan(c_out, n_cols, mp)
+    cfg, splits = plan(c_out, n_cols, mp, raw=True)
     o, ws = _opts(dy_t, x_t, c_out, n_cols, mp, dev, None, cfg, splits, raw=True)
     rm = RowMap(1, c_out, c_out, 1, 0, 0, 1)
     ops._timed_call("tconv_wgrad", 2.0 * (flops_rows or mp) * c_out * taps * c_in, _lib.lib().vp3d_tconv_nt_s16,
@@ -183,7 +191,7 @@ def act_bound(bn: torch.nn.BatchNorm1d, m_rows: int, p: float, res_bound: Option
 
 
 def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tuple[S16, ResSpec]], out_bound: torch.Tensor,
-               t_taps: int = 0):
+               t_taps: int = 0, want_f32: bool = False):
     """a = [res +] dropout(relu(bn(y))) as S16 rows [B,T,C] (+ the transposed copy for the consuming conv's wgrad when
     t_taps > 0: [t_taps*C][roundup(M/t_taps, 64)])."""
     ops._chk(y, "y")
@@ -201,10 +209,13 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
         rargs = (rd.data_ptr(), r.bound.data_ptr(), t, rd.shape[1], rs.step, rs.start, c)
     else:
         rargs = (None, None, t, 0, 0, 0, c)
+    f32 = torch.empty_like(y) if want_f32 else None
     check(_lib.lib().vp3d_bn_act_fwd_s16(ops._stream(), m, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                          C.byref(drop) if drop is not None else None, *rargs, out_bound.data_ptr(),
-                                         out.data_ptr(), ops._p(tt), tt.shape[1] if tt is not None else 0, max(t_taps, 1)),
-          "vp3d_bn_act_fwd_s16")
+                                         out.data_ptr(), ops._p(f32), ops._p(tt), tt.shape[1] if tt is not None else 0,
+                                         max(t_taps, 1)), "vp3d_bn_act_fwd_s16")
+    if want_f32:
+        return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None), f32
     return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
 
 
@@ -249,6 +260,7 @@ def join(x: S16) -> torch.Tensor:
     v = (h[..., 0, :] + h[..., 1, :]).reshape(d.shape)
     if x.bound is None:
         return v
-    e = torch.frexp(x.bound)[1].to(torch.float32) - 15.0
-    e = torch.where((x.bound > 0) & (x.bound < 3.0e38), e, torch.zeros_like(e))
+    bd = x.bound.max()
+    e = torch.frexp(bd)[1].to(torch.float32) - 15.0
+    e = torch.where((bd > 0) & (bd < 3.0e38), e, torch.zeros_like(e))
     return v * torch.exp2(e)
