@@ -1,0 +1,208 @@
+"""GPU tests of the split-fp16 ("S16") kernels through the C ABI: the NT GEMM (tile configurations, split-K + finishing
+pass, ragged shapes, epilogues, BatchNorm slab statistics, amax), the S16 producers (row split, transposed copies,
+weight packs, activation forward / backward) and the device-side bounds -- against fp64 references built with torch on
+the CPU/GPU.  Tolerance of the GEMM: |err| <= 1e-6 * sum|a||b| (22+ bit operands; the fp32-MFMA kernel sits at ~1e-7)."""
+import numpy as np
+import pytest
+import torch
+
+import videopose3d_amd as V
+from videopose3d_amd import ops, ops_s16 as S
+from videopose3d_amd.plan import ConvSpec, ResSpec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GEMM_TOL = 1e-6
+
+
+def _ref_conv(x, w, spec, bias=None):
+    xd, wd = x.double().permute(0, 2, 1), w.double()
+    y = torch.nn.functional.conv1d(xd, wd, None if bias is None else bias.double(), dilation=spec.dil, stride=spec.stride)
+    den = torch.nn.functional.conv1d(xd.abs(), wd.abs(), dilation=spec.dil, stride=spec.stride)
+    return y.permute(0, 2, 1), den.permute(0, 2, 1)
+
+
+CASES = [  # (B, T, spec, cfg, splits)
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 0, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 4, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 2, 1),
+    (5, 27, ConvSpec(160, 96, 3, 1, 3), 0, 1),          # N = 96 (ragged column tile), strided
+    (5, 27, ConvSpec(160, 96, 3, 1, 3), 4, 3),          # split-K + finishing pass
+    (3, 31, ConvSpec(64, 200, 1), 0, 2),                # ragged M = 93, N = 200
+    (7, 40, ConvSpec(128, 128, 3, 9, 1), -1, 0),        # planned
+    (2, 300, ConvSpec(64, 64, 5, 1, 1), 0, 1),          # 5 adjacent taps ("dense"-style)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_T%d_%dx%d_k%d_d%d_s%d_cfg%d_sp%d" % (
+    c[0], c[1], c[2].c_in, c[2].c_out, c[2].taps, c[2].dil, c[2].stride, c[3], c[4]))
+def test_nt_gemm_vs_fp64(case):
+    b, t, spec, cfg, splits = case
+    g = torch.Generator().manual_seed(3)
+    x = (torch.relu(torch.randn(b, t, spec.c_in, generator=g)) * 1.3).to(DEV)
+    w = ((torch.rand(spec.c_out, spec.c_in, spec.taps, generator=g) * 2 - 1) * 0.03).to(DEV)
+    bias = torch.randn(spec.c_out, generator=g).to(DEV)
+    ref, den = _ref_conv(x, w, spec, bias)
+    ref = torch.relu(ref)
+    xs, ws = S.split(x), S.split(ops.pack_weight(w))
+    m = b * spec.t_out(t)
+    stats = ops.stat_buffers(m, spec.c_out, DEV)
+    am = S.new_bound(DEV)
+    y = S.conv_nt(xs, ws, spec, bias=bias, relu=True, stats=stats, amax_out=am, cfg=cfg, splits=splits)
+    assert float(((y.double() - ref).abs() / den).max()) < GEMM_TOL
+    assert float(am.max()) == float(y.abs().max())
+    # slab statistics are those of the raw conv output (before bias / ReLU)
+    raw = (_ref_conv(x, w, spec)[0]).reshape(m, spec.c_out)
+    for s0 in range(0, m, 64):
+        blk = raw[s0:s0 + 64]
+        assert torch.allclose(stats[0][s0 // 64].double(), blk.sum(0), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(stats[1][s0 // 64].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
+
+
+def test_nt_gemm_exponents_and_residual():
+    """Operands far outside fp16's range (1e-6 gradients x 1e4 'weights'): the per-tensor exponents keep full precision;
+    residual rows are added after the scaling."""
+    g = torch.Generator().manual_seed(5)
+    b, t, c = 6, 9, 128
+    spec = ConvSpec(c, c, 1)
+    x = (torch.randn(b, t, c, generator=g) * 1e-6).to(DEV)
+    w = (torch.randn(c, c, 1, generator=g) * 1e4).to(DEV)
+    r = torch.randn(b, 2 * t + 1, c, generator=g).to(DEV)
+    ref, den = _ref_conv(x, w, spec)
+    ref = ref + r[:, 1::2][:, :t].double()
+    y = S.conv_nt(S.split(x), S.split(ops.pack_weight(w)), spec, residual=(r, ResSpec(1, 2)))
+    assert float(((y.double() - ref).abs() / den).max()) < GEMM_TOL
+    # without exponents the same data underflows fp16: the bound is what makes the format safe
+    y0 = S.conv_nt(S.split(x, measure=False), S.split(ops.pack_weight(w) * 1e-4, measure=False), spec)
+    assert float(((y0.double() * 1e4 - (ref - r[:, 1::2][:, :t].double())).abs() / den).max()) > 1e-3
+
+
+def test_split_join_and_transposed_copy():
+    g = torch.Generator().manual_seed(7)
+    m, c = 200, 128                                     # ragged: 200 rows -> transposed pitch 256, zero padded
+    v = (torch.randn(m, c, generator=g) * torch.exp(torch.randn(m, c, generator=g) * 3)).to(DEV)
+    bd = S.amax(v)
+    assert float(bd.max()) == float(v.abs().max())
+    rows, tt = S.split_t(v, bd)
+    back = S.join(rows)
+    assert float(((back - v).abs() / float(v.abs().max())).max()) < 2.0 ** -22        # abs error vs the tensor bound
+    big = v.abs() > float(v.abs().max()) * 2.0 ** -10
+    assert float(((back - v).abs() / v.abs())[big].max()) < 2.0 ** -21                 # 22+ significant bits
+    assert tt.data.shape == (c, 256)
+    t_back = S.join(tt)
+    assert torch.equal(t_back[:, :m], back.t().contiguous())
+    assert float(t_back[:, m:].abs().max()) == 0.0
+
+
+def test_weight_packs_match_reference_layout():
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(128, 64, 3, generator=g) * 0.05).to(DEV)
+    bd = S.amax(w)
+    wf, wd = S.pack_weight(w, bd)
+    f = S.join(wf)                                      # [co][k*C_in + ci]
+    d = S.join(wd)                                      # [(k*C_in + ci)][co]
+    ref = w.permute(0, 2, 1).reshape(128, 3 * 64)
+    assert float((f - ref).abs().max()) < float(w.abs().max()) * 2.0 ** -21
+    assert torch.equal(d, f.t().contiguous())
+    _, wdd = S.pack_weight(w, bd, want_fwd=False, dilated_form=True)     # [ci][k*C_out + co]
+    dd = S.join(wdd)
+    assert torch.equal(dd, S.join(wf).view(128, 3, 64).permute(2, 1, 0).reshape(64, 3 * 128))
+
+
+@pytest.mark.parametrize("taps,p", [(1, 0.0), (3, 0.25)])
+def test_activation_forward_and_backward_producers(taps, p):
+    """vp3d_bn_act_fwd_s16 / vp3d_bn_bwd_apply_s16 against the fp32 streaming kernels (same Philox mask), including the
+    transposed copies in the layout the strided conv's wgrad reduces over."""
+    g = torch.Generator().manual_seed(11)
+    b, t, c = 6, 9, 128
+    y = torch.randn(b, t, c, generator=g).to(DEV)
+    coef = torch.stack([1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g),
+                        0.05 * torch.randn(c, generator=g), 1 + 0.1 * torch.rand(c, generator=g)]).to(DEV)
+    res = torch.randn(b, 3 * t, c, generator=g).to(DEV)
+    rs = ResSpec(1, 3)
+    drop = ops.make_dropout(p, 1234, 5, 2)
+    a32 = ops.bn_act_fwd(y, coef, drop, (res, rs))
+    bd = S.new_bound(DEV)
+    bd[0] = float(a32.abs().max()) * 1.5
+    a, a_t = S.bn_act_fwd(y, coef, drop, (S.split(res), rs), bd, t_taps=taps)
+    assert float((S.join(a) - a32).abs().max()) < float(bd.max()) * 2.0 ** -20
+    at = S.join(a_t)
+    m = b * t
+    assert at.shape == (taps * c, S.t_pitch(m, taps))
+    expect = S.join(a).reshape(m // taps, taps, c).permute(1, 2, 0).reshape(taps * c, m // taps)
+    assert torch.equal(at[:, :m // taps], expect)
+    assert float(at[:, m // taps:].abs().max()) == 0.0
+    # backward
+    go = (torch.randn(b, t, c, generator=g) * 1e-5).to(DEV)
+    dy32, dg32, db32 = ops.bn_act_bwd(go, y, coef, drop)
+    gb = S.amax(go)
+    dyb = S.new_bound(DEV)
+    dy, dy_t, dg, db = S.bn_act_bwd(go, gb, y, coef, drop, p, dyb)
+    assert float(dyb.max()) >= float(dy32.abs().max())              # the Samuelson bound is a bound
+    assert torch.equal(dg, dg32) and torch.equal(db, db32)
+    assert float((S.join(dy) - dy32).abs().max()) < float(dyb.max()) * 2.0 ** -20
+    assert torch.equal(S.join(dy_t)[:, :m], S.join(dy).reshape(m, c).t().contiguous())
+
+
+def test_act_bound_is_a_bound_for_adversarial_statistics():
+    """Samuelson's inequality is tight for a one-hot column: the normalised value reaches sqrt(M-1)."""
+    m, c = 257, 64
+    y = torch.zeros(1, m, c, device=DEV)
+    y[0, 0, :] = 1.0                                    # one outlier row
+    bn = torch.nn.BatchNorm1d(c).to(DEV)
+    stats = ops.stat_buffers(m, c, DEV)
+    spec = ConvSpec(64, c, 1)
+    x = torch.zeros(1, m, 64, device=DEV)
+    x[0, 0, :] = 1.0
+    w = torch.eye(c, 64, device=DEV).reshape(c, 64, 1).contiguous()
+    yy = S.conv_nt(S.split(x), S.split(ops.pack_weight(w)), spec, stats=stats)
+    assert torch.equal(yy, y)
+    coef = ops.bn_finalize(bn, m, stats)
+    bd = S.new_bound(DEV)
+    S.act_bound(bn, m, 0.0, None, bd)
+    a32 = ops.bn_act_fwd(y, coef, None, None)
+    assert float(a32.abs().max()) <= float(bd.max())
+    assert float(a32.abs().max()) > 0.99 * float(bd.max()) - 1e-3      # and it is attained
+    a, _ = S.bn_act_fwd(y, coef, None, None, bd)
+    assert torch.isfinite(S.join(a)).all()
+    assert float((S.join(a) - a32).abs().max()) < float(bd.max()) * 2.0 ** -20
+
+
+def test_model_level_f16x3_equals_f32_path():
+    """Whole training step and eval forward in both arithmetics on the same weights / dropout stream."""
+    import copy
+    torch.manual_seed(0)
+    fw = [3, 3, 3]
+    V.set_default_math("f32")
+    try:
+        m32 = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.25, channels=128).to(DEV).train()
+    finally:
+        V.set_default_math(None)
+    m16 = copy.deepcopy(m32)
+    m16.math = "f16x3"
+    for m in (m32, m16):
+        m._drop_seed, m._drop_calls = 99, 0
+    x = (torch.randn(16, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+    tgt = torch.randn(16, 1, 17, 3, device=DEV) * 0.3
+    outs = []
+    for m in (m32, m16):
+        yv = m(x)
+        torch.mean(torch.norm(yv - tgt, dim=3)).backward()
+        outs.append(yv.detach())
+    assert float(torch.mean(torch.norm(outs[0] - outs[1], dim=3))) < 1e-5
+    for (k, a), (_, q) in zip(m16.named_parameters(), m32.named_parameters()):
+        assert float((a.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)) < 5e-5, k
+    for (k, a), (_, q) in zip(m16.named_buffers(), m32.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, q, rtol=1e-5, atol=1e-6), k
+
+
+def test_unsupported_configurations_fall_back_to_fp32_kernels():
+    from videopose3d_amd import engine_s16
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=48)        # channels % 64 != 0
+    assert m.math == V.default_math() and not engine_s16.supported(m, 27, True)
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128)                   # dilated training -> fp32
+    assert not engine_s16.supported(m, 27, True) and engine_s16.supported(m, 27, False)
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=128)
+    assert engine_s16.supported(m, 27, True) and not engine_s16.supported(m, 28, True)
+    assert not engine_s16.supported(m, 27, True, need_dx=True)

@@ -12,6 +12,16 @@ from tests.util import (GEN_CASES, GOLDEN, JOINTS_LEFT, JOINTS_RIGHT, KPS_LEFT, 
                         load_npz_groups, load_step_dataset, mpjpe_np, rel_err)
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["f16x3", "f32"])
+def math_mode(request):
+    """Every test of this module runs once per GEMM arithmetic: "f16x3" (split-fp16 MFMA wherever engine_s16 supports
+    the configuration, fp32 elsewhere) and "f32" (fp32 MFMA everywhere) -- same oracle, same tolerances."""
+    import videopose3d_amd as _V
+    _V.set_default_math(request.param)
+    yield request.param
+    _V.set_default_math(None)
 DEV = "cuda:0"
 
 

@@ -5,6 +5,6 @@ Public surface = the reference's (common/model.py): ``TemporalModel``, ``Tempora
 data-parallel helpers in ``videopose3d_amd.dp``.
 """
 from ._lib import Vp3dError, LIB_PATH  # noqa: F401
-from .model import TemporalModel, TemporalModelBase, TemporalModelOptimized1f  # noqa: F401
+from .model import TemporalModel, TemporalModelBase, TemporalModelOptimized1f, default_math, set_default_math  # noqa: F401
 
-__all__ = ["TemporalModel", "TemporalModelBase", "TemporalModelOptimized1f", "Vp3dError"]
+__all__ = ["TemporalModel", "TemporalModelBase", "TemporalModelOptimized1f", "Vp3dError", "default_math", "set_default_math"]

@@ -80,7 +80,7 @@ def _shrink(mod, h: torch.Tensor) -> torch.Tensor:
                         bias=mod.shrink.bias.detach())
 
 
-def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+def _forward_eval_f32(mod, x3: torch.Tensor) -> torch.Tensor:
     plan: StackPlan = mod._plan
     plan.lengths(x3.shape[1])
     packs = folded_weights(mod)
@@ -107,7 +107,7 @@ class _Saved:
         self.x, self.y, self.coef, self.drop, self.wt, self.kpad, self.t_in = x, y, coef, drop, wt, kpad, t_in
 
 
-def forward_train(mod, x3: torch.Tensor, save: bool):
+def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
     """Returns (out3, saved) ; saved is None unless `save`."""
     plan: StackPlan = mod._plan
     plan.lengths(x3.shape[1])
@@ -163,7 +163,7 @@ def _wgrad_stream(device) -> Optional[torch.cuda.Stream]:
     return st
 
 
-def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
+def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     """Gradients in the order of ``param_list`` (+ optional input gradient).
 
     Optional second HIP stream (VP3D_OVERLAP=1, see _wgrad_stream): the dependent chain (BN/ReLU/dropout backward ->
@@ -298,14 +298,37 @@ def use_s16(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
     return engine_s16.supported(mod, t_in, training, need_dx)
 
 
+def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+    if use_s16(mod, x3.shape[1], False):
+        from . import engine_s16
+        return engine_s16.forward_eval(mod, x3)
+    return _forward_eval_f32(mod, x3)
+
+
+def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
+    """Returns (out3, saved); saved is None unless `save` (it records which arithmetic produced it)."""
+    if use_s16(mod, x3.shape[1], True, need_dx):
+        from . import engine_s16
+        out, saved = engine_s16.forward_train(mod, x3, save)
+        if saved is not None:
+            saved["s16"] = True
+        return out, saved
+    return _forward_train_f32(mod, x3, save)
+
+
+def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
+    if saved.get("s16"):
+        from . import engine_s16
+        return engine_s16.backward_train(mod, saved, gout3, need_dx)
+    return _backward_train_f32(mod, saved, gout3, need_dx)
+
+
 class TemporalStackFn(torch.autograd.Function):
     """Whole-stack training step: forward saves raw conv outputs + BN coefficients; backward is hand-written."""
 
     @staticmethod
     def forward(ctx, mod, x3, *params):
-        from . import engine_s16
-        ctx.s16 = use_s16(mod, x3.shape[1], True, x3.requires_grad)
-        out, saved = (engine_s16.forward_train if ctx.s16 else forward_train)(mod, x3, save=True)
+        out, saved = forward_train(mod, x3, save=True, need_dx=x3.requires_grad)
         ctx.mod = mod
         ctx.saved = saved
         ctx.need_dx = x3.requires_grad
@@ -315,10 +338,6 @@ class TemporalStackFn(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.saved is None:
             raise RuntimeError("vp3d: backward called twice on the same graph (activations were freed)")
-        if ctx.s16:
-            from . import engine_s16
-            grads, dx = engine_s16.backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
-        else:
-            grads, dx = backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
+        grads, dx = backward_train(ctx.mod, ctx.saved, gout, ctx.need_dx)
         ctx.saved = None
         return (None, dx) + tuple(grads)

@@ -55,7 +55,7 @@ def folded_weights(mod):
     cache = mod.__dict__.get("_fold_cache_s16")
     if cache is not None and cache[0] == key:
         return cache[1]
-    packs = [(S.split(wt), shift) for wt, shift in engine.folded_weights(mod)]
+    packs = [(S.split(wt), shift) for wt, shift in engine.folded_weights(mod)]     # fp32 fold (cached) -> S16
     mod.__dict__["_fold_cache_s16"] = (key, packs)
     return packs
 

@@ -16,9 +16,24 @@ import os
 import torch
 import torch.nn as nn
 
-from . import engine, engine_s16
+from . import engine
 from ._lib import Vp3dError
 from .plan import make_plan
+
+
+_default_math = [None]
+
+
+def default_math() -> str:
+    """Arithmetic newly constructed models use: set_default_math() if called, else VP3D_MATH, else "f16x3"."""
+    m = _default_math[0] or os.environ.get("VP3D_MATH", "f16x3")
+    if m not in ("f32", "f16x3"):
+        raise Vp3dError("VP3D_MATH / set_default_math: expected 'f32' or 'f16x3', got %r" % (m,))
+    return m
+
+
+def set_default_math(math) -> None:
+    _default_math[0] = math
 
 
 class TemporalModelBase(nn.Module):
@@ -43,10 +58,10 @@ class TemporalModelBase(nn.Module):
         self._stats_epoch = 0
         self._drop_calls = 0
         self._drop_seed = None
-        # GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products), "f16x3" = split-fp16 operands on
-        # v_mfma_f32_32x32x16_f16 (fp32-class: 22+ operand bits, fp32 accumulation; ~3x faster).  Not part of the
-        # reference API / state_dict; default from VP3D_MATH.
-        self.math = os.environ.get("VP3D_MATH", "f32")
+        # GEMM arithmetic (not part of the reference API / state_dict): "f16x3" = split-fp16 operands on
+        # v_mfma_f32_32x32x16_f16 (fp32-class results: 22+ operand bits, exact products, fp32 accumulation; ~3x the
+        # fp32 matrix rate) wherever engine_s16.supported() says so, "f32" = v_mfma_f32_32x32x2_f32 everywhere.
+        self.math = default_math()
 
     # ---- construction helper shared by the two concrete classes -------------------------------------
     def _build(self, channels, causal, dense, strided):
@@ -120,15 +135,13 @@ class TemporalModelBase(nn.Module):
                     out3 = engine.TemporalStackFn.apply(self, x3, *engine.param_list(self))
                 else:
                     with torch.no_grad():
-                        fwd = engine_s16.forward_train if engine.use_s16(self, t, True) else engine.forward_train
-                        out3, _ = fwd(self, x3, save=False)
+                        out3, _ = engine.forward_train(self, x3, save=False)
             else:
                 if torch.is_grad_enabled() and x.requires_grad:
                     raise Vp3dError("gradients through the eval-mode (folded BatchNorm) path are not implemented; "
                                     "call model.train() or wrap evaluation in torch.no_grad() as run.py does")
                 with torch.no_grad():
-                    fwd = engine_s16.forward_eval if engine.use_s16(self, t, False) else engine.forward_eval
-                    out3 = fwd(self, x3)
+                    out3 = engine.forward_eval(self, x3)
         return out3.view(b, -1, self.num_joints_out, 3)
 
 
