@@ -10,6 +10,9 @@ Workload (BASELINE.json `metric`: "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 
   N*1024) plus the flat-gradient sum all-reduce over RCCL.  frames/s = predicted frames (= batch elements) per
   second, whole job.  The optimizer is torch.optim.Adam in run.py (out of scope) and is NOT in the timed
   region; its cost is reported separately (`adam_ms`).
+Arithmetic: the headline runs the library default, "f16x3" = split-fp16 operands on v_mfma_f32_32x32x16_f16 with fp32
+accumulation (fp32-class results: 22+ operand bits, exact products; same parity tests and tolerances as the fp32 path);
+the same step on the exact-fp32 MFMA kernels (math "f32", v_mfma_f32_32x32x2_f32) is timed next to it (`f32_mfma`).
 Extra fields in the same JSON line:
   cfg2_eval_fwd : BASELINE.json configs[1] -- TemporalModel eval forward, B=1024, T=243 (5.34 TFLOP / call)
   roofline      : dominant GEMM kernel family of the step, algorithmic FLOPs / HIP-event launch durations
@@ -35,6 +38,8 @@ C = 1024
 B = 1024
 RF = 243
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD)
+MFMA_PER_MAC_F16X3 = 3                # the split scheme issues ah*bh + ah*bl + al*bh: 3 executed MFMA FLOPs per algorithmic FLOP
 FLOP_TRAIN_PER_FRAME = 1023866880     # fwd 352,569,344 + bwd 671,297,536 (conv MACs x 2)
 FLOP_EVAL_PER_FRAME = 5217830912      # TemporalModel forward on a 243-frame window
 
@@ -50,21 +55,25 @@ def mpjpe(pred, target):                                                        
     return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-FAMILY_KERNELS = {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"}
+PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
+            "f16x3": os.path.join(ROOT, "profiles", "r01_s16_pmc_traffic.json")}
+FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"},
+                  # one kernel serves all three GEMM forms of the split-fp16 path (all are "NT")
+                  "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, math):
     """HBM-side bytes per launch of a GEMM family from the committed rocprofv3 PMC passes of THIS command
     (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
     gfx950 correction of MI355X_MICROARCH.md; tools/pmc_traffic.py).  PMC counters cannot be read from inside the
     timed process, so the value is the committed measurement, averaged over the family's launches like `achieved`."""
+    path = PMC_JSON[math]
     try:
-        with open(PMC_JSON) as f:
+        with open(path) as f:
             tab = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
-        return None, "no committed PMC profile found (%s)" % os.path.relpath(PMC_JSON, ROOT)
-    key = FAMILY_KERNELS[family].replace(" ", "")
+        return None, "no committed PMC profile found (%s)" % os.path.relpath(path, ROOT)
+    key = FAMILY_KERNELS[math][family].replace(" ", "")
     tot = n = 0.0
     for name, t in tab.items():
         if key in name.replace(" ", ""):
@@ -72,9 +81,9 @@ def pmc_traffic(family):
             tot += t["hbm_bytes_per_launch"] * launches
             n += launches
     if not n:
-        return None, "kernel family not present in %s" % os.path.relpath(PMC_JSON, ROOT)
+        return None, "kernel family not present in %s" % os.path.relpath(path, ROOT)
     return tot / n, ("bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included), mean "
-                     "over the %d launches of the family in profiles/r01_pmc_traffic.json" % int(n))
+                     "over the %d launches of %s in %s" % (int(n), key, os.path.relpath(path, ROOT)))
 
 
 def usable_cores():
@@ -165,6 +174,52 @@ def cpu_baseline(dev, budget_s=4.0):
                       sample_b=bsz, tolerance=1e-3)
 
 
+def instrumented(step, ops, n_prof, math):
+    """Per-kernel-family roofline, measured live with HIP events on the launch stream around every C-ABI GEMM call."""
+    recs = []
+    ops.set_profiler(recs)
+    for _ in range(n_prof):
+        step()
+    torch.cuda.synchronize()
+    ops.set_profiler(None)
+    fam = {}
+    for name, flops, e0, e1, nbytes in recs:
+        f = fam.setdefault(name, dict(flops=0.0, ms=0.0, calls=0, bytes=0.0))
+        f["flops"] += flops
+        f["bytes"] += nbytes
+        f["ms"] += e0.elapsed_time(e1)
+        f["calls"] += 1
+    kernels = {k: dict(calls_per_step=v["calls"] // n_prof, ms_per_step=v["ms"] / n_prof,
+                       avg_launch_ms=v["ms"] / v["calls"], tflops=v["flops"] / v["ms"] / 1e9,
+                       algorithmic_bytes_per_launch=v["bytes"] / v["calls"])
+               for k, v in fam.items()}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    alg = kernels[dom]["tflops"]
+    traffic, traffic_note = pmc_traffic(dom, math)
+    if math == "f16x3":
+        kname = "k_nt_s16<*> (vp3d_tconv_nt_s16: %s form)" % dom
+        peak = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3
+        extra = {"executed_mfma_tflops": alg * MFMA_PER_MAC_F16X3, "mfma_peak_f16_dense": PEAK_F16_MFMA_TFLOPS,
+                 "frac_of_fp32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS,
+                 "note": "split-fp16 GEMM: every algorithmic MAC is 3 f16 MFMA MACs (ah*bh + ah*bl + al*bh), so peak = "
+                         "2500 / 3 TFLOP/s of algorithmic work; achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the "
+                         "family's launches / sum of their HIP-event durations on the launch stream; frac = executed MFMA "
+                         "FLOP/s / dense f16 MFMA peak.  frac_of_fp32_mfma_peak > 1 means faster than the exact-fp32 MFMA "
+                         "path could run at 100 % of its roofline"}
+    else:
+        kname = {"tconv_fwd": "k_rows_gemm<true,*> (vp3d_tconv_fwd)", "tconv_dgrad": "k_rows_gemm<false,*> (vp3d_tconv_dgrad)",
+                 "tconv_wgrad": "k_red_gemm<*> (vp3d_tconv_wgrad)"}[dom]
+        peak = PEAK_F32_MFMA_TFLOPS
+        extra = {"note": "achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the family's launches / sum of their "
+                         "HIP-event durations on the launch stream"}
+    roof = {"bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+            "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_bytes": kernels[dom]["algorithmic_bytes_per_launch"], "kernel": kname,
+            "launches_per_step": kernels[dom]["calls_per_step"], "avg_launch_ms": kernels[dom]["avg_launch_ms"]}
+    roof.update(extra)
+    return roof, kernels
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,8 +227,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the cfg2 eval-forward section")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 MFMA comparison sections")
+    ap.add_argument("--math", default=None, help="arithmetic of the headline: f16x3 (default) or f32")
     args = ap.parse_args()
 
+    import videopose3d_amd as V
     from videopose3d_amd import TemporalModel, TemporalModelOptimized1f, dp, ops
     from videopose3d_amd import loss as vloss
     # VP3D_DIST_BACKEND / VP3D_BENCH_DEVICE are test hooks: "gloo" + device 0 let the N > 1 control flow (matched
@@ -184,160 +242,161 @@ def main():
     local = int(os.environ.get("VP3D_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    math = args.math or V.default_math()
 
-    torch.manual_seed(0)
-    model = TemporalModelOptimized1f(17, 2, 17, FW, causal=False, dropout=0.25, channels=C).to(dev).train()
-    sync = dp.FlatGradSync(model.parameters(), world=world, direct_module=model)
-    sync.broadcast_parameters(model.buffers())
     gen = torch.Generator().manual_seed(1234 + rank)
     x, tgt = synthetic_batch(B, gen)
     x, tgt = x.to(dev), tgt.to(dev)                      # inputs resident in HBM before the timed region
-
-    def step():
-        sync.zero_grad()
-        loss = vloss.mpjpe(model(x), tgt)               # loss.py:11-17 on the HIP path (one kernel: value + gradient)
-        loss.backward()
-        sync.sync()
-        return loss
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def build(mth):
+        torch.manual_seed(0)
+        model = TemporalModelOptimized1f(17, 2, 17, FW, causal=False, dropout=0.25, channels=C).to(dev).train()
+        model.math = mth
+        sync = dp.FlatGradSync(model.parameters(), world=world, direct_module=model)
+        sync.broadcast_parameters(model.buffers())
+
+        def step():
+            sync.zero_grad()
+            loss = vloss.mpjpe(model(x), tgt)           # loss.py:11-17 on the HIP path (one kernel: value + gradient)
+            loss.backward()
+            sync.sync()
+            return loss
+        return model, sync, step
+
+    def time_steps(step, warmup, steps):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    model, sync, step = build(math)
+    dt = time_steps(step, args.warmup, args.steps)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    dtype = ("f32 (products on split-fp16 MFMA: 22+ bit operands, exact fp16 products, fp32 accumulate)" if math == "f16x3"
+             else "f32")
 
     out = {
         "metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "math": math, "data": "synthetic",
         "config": {"workload": "cfg3: TemporalModelOptimized1f train step fwd+bwd (BN stats, dropout 0.25), "
                                "arc 3,3,3,3,3 C=1024, per-GPU B=1024 x 243 frames x 17 joints",
                    "global_batch": world * B, "parallelism": "dp%d" % world,
                    "grad_allreduce_bytes": sync.numel * 4 if world > 1 else 0},
         "step_tflops": FLOP_TRAIN_PER_FRAME * value / 1e12,
-        "step_frac_of_mfma_peak": FLOP_TRAIN_PER_FRAME * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+        "step_frac_of_fp32_mfma_peak": FLOP_TRAIN_PER_FRAME * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
     }
 
     # Everything below that runs training steps is executed by EVERY rank: a step contains collectives (the bucketed
     # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.
-    if True:
-        # ---- per-kernel-family roofline, measured live with HIP events on the launch stream -------------
-        recs = []
-        ops.set_profiler(recs)
-        n_prof = 3
-        for _ in range(n_prof):
-            step()
+    out["roofline"], out["kernels"] = instrumented(step, ops, 3, math)
+    gemm_ms = sum(v["ms_per_step"] for v in out["kernels"].values())
+    out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
+
+    # ---- the callers either side of the stack, outside the metric -------------------------
+    def timed(fn, n=5):
+        fn()
         torch.cuda.synchronize()
-        ops.set_profiler(None)
-        fam = {}
-        for name, flops, e0, e1, nbytes in recs:
-            f = fam.setdefault(name, dict(flops=0.0, ms=0.0, calls=0, bytes=0.0))
-            f["flops"] += flops
-            f["bytes"] += nbytes
-            f["ms"] += e0.elapsed_time(e1)
-            f["calls"] += 1
-        kernels = {k: dict(calls_per_step=v["calls"] // n_prof, ms_per_step=v["ms"] / n_prof,
-                           avg_launch_ms=v["ms"] / v["calls"], tflops=v["flops"] / v["ms"] / 1e9,
-                           algorithmic_bytes_per_launch=v["bytes"] / v["calls"])
-                   for k, v in fam.items()}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        kname = {"tconv_fwd": "k_rows_gemm<true,*> (vp3d_tconv_fwd)", "tconv_dgrad": "k_rows_gemm<false,*> (vp3d_tconv_dgrad)",
-                 "tconv_wgrad": "k_red_gemm<*> (vp3d_tconv_wgrad)"}[dom]
-        traffic, traffic_note = pmc_traffic(dom)
-        out["roofline"] = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": traffic, "traffic_note": traffic_note,
-                           "algorithmic_bytes": kernels[dom]["algorithmic_bytes_per_launch"],
-                           "kernel": kname, "launches_per_step": kernels[dom]["calls_per_step"],
-                           "avg_launch_ms": kernels[dom]["avg_launch_ms"],
-                           "note": "achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the family's launches / "
-                                   "sum of their HIP-event durations on the launch stream"}
-        out["kernels"] = kernels
-        gemm_ms = sum(v["ms_per_step"] for v in kernels.values())
-        out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
-
-        # ---- the callers either side of the stack, outside the metric -------------------------
-        def timed(fn, n=5):
+        t0 = time.perf_counter()
+        for _ in range(n):
             fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
 
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)      # run.py:252,264
-        out["adam_torch_ms"] = timed(opt.step)
-        del opt
-        from videopose3d_amd.optim import FlatAdam
-        from videopose3d_amd.generators import ChunkedGenerator
-        fopt = FlatAdam(model.parameters(), lr=1e-3, amsgrad=True, grad_sync=sync)
-        out["adam_ms"] = timed(fopt.step)                                       # vp3d_adam_step, one pass
-        rng = np.random.RandomState(0)
-        lens = [3000 + 517 * i for i in range(24)]                              # ~216k frames of synthetic "videos"
-        p2 = [rng.standard_normal((n, 17, 2)).astype(np.float32) for n in lens]
-        p3 = [rng.standard_normal((n, 17, 3)).astype(np.float32) for n in lens]
-        gen_dev = ChunkedGenerator(B, None, p3, p2, 1, pad=(RF - 1) // 2, shuffle=True, augment=True,
-                                   kps_left=[1, 3, 5, 7, 9, 11, 13, 15], kps_right=[2, 4, 6, 8, 10, 12, 14, 16],
-                                   joints_left=[4, 5, 6, 11, 12, 13], joints_right=[1, 2, 3, 14, 15, 16], device=dev)
-        it = gen_dev.next_epoch()
-        out["batch_gather_ms"] = timed(lambda: next(it), n=10)                  # vp3d_gather_chunks, B=1024 x 243 frames
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)      # run.py:252,264
+    out["adam_torch_ms"] = timed(opt.step)
+    del opt
+    from videopose3d_amd.optim import FlatAdam
+    from videopose3d_amd.generators import ChunkedGenerator
+    fopt = FlatAdam(model.parameters(), lr=1e-3, amsgrad=True, grad_sync=sync)
+    out["adam_ms"] = timed(fopt.step)                                       # vp3d_adam_step, one pass
+    rng = np.random.RandomState(0)
+    lens = [3000 + 517 * i for i in range(24)]                              # ~216k frames of synthetic "videos"
+    p2 = [rng.standard_normal((n, 17, 2)).astype(np.float32) for n in lens]
+    p3 = [rng.standard_normal((n, 17, 3)).astype(np.float32) for n in lens]
+    gen_dev = ChunkedGenerator(B, None, p3, p2, 1, pad=(RF - 1) // 2, shuffle=True, augment=True,
+                               kps_left=[1, 3, 5, 7, 9, 11, 13, 15], kps_right=[2, 4, 6, 8, 10, 12, 14, 16],
+                               joints_left=[4, 5, 6, 11, 12, 13], joints_right=[1, 2, 3, 14, 15, 16], device=dev)
+    it = gen_dev.next_epoch()
+    out["batch_gather_ms"] = timed(lambda: next(it), n=10)                  # vp3d_gather_chunks, B=1024 x 243 frames
 
-        def full_step():
-            _, b3, b2 = next(it)
-            b3[:, :, 0] = 0                                                     # run.py:407
-            fopt.zero_grad()
-            vloss.mpjpe(model(b2), b3).backward()
-            sync.sync()                                                         # no-op for one GPU
-            fopt.step()
-        ms_full = timed(full_step, n=10)
-        out["full_step"] = {"what": "device batch assembly + fwd + bwd + fused Adam (run.py:401-420 end to end), B=1024",
-                            "ms": ms_full, "frames_per_s": B / ms_full * 1e3}
-        del fopt, gen_dev, it
-
-    del model, sync
+    def full_step():
+        _, b3, b2 = next(it)
+        b3[:, :, 0] = 0                                                     # run.py:407
+        fopt.zero_grad()
+        vloss.mpjpe(model(b2), b3).backward()
+        sync.sync()                                                         # no-op for one GPU
+        fopt.step()
+    ms_full = timed(full_step, n=10)
+    out["full_step"] = {"what": "device batch assembly + fwd + bwd + fused Adam (run.py:401-420 end to end), B=1024",
+                        "ms": ms_full, "frames_per_s": B / ms_full * 1e3}
+    del fopt, gen_dev, it, model, sync, step
     torch.cuda.empty_cache()
+
+    # ---- the same step on the exact-fp32 MFMA kernels (every rank: the step holds collectives) -------------
+    if math != "f32" and not args.no_f32:
+        model, sync, step = build("f32")
+        k32 = max(5, args.steps // 2)
+        dt32 = time_steps(step, 3, k32)
+        v32 = world * B * k32 / dt32
+        roof32, kern32 = instrumented(step, ops, 3, "f32")
+        out["f32_mfma"] = {"what": "the same training step with math='f32' (v_mfma_f32_32x32x2_f32, exact fp32 products)",
+                           "value": v32, "unit": "frames/s", "ms_per_step": dt32 / k32 * 1e3, "steps": k32,
+                           "step_tflops": FLOP_TRAIN_PER_FRAME * v32 / 1e12,
+                           "step_frac_of_fp32_mfma_peak": FLOP_TRAIN_PER_FRAME * v32 / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                           "roofline": roof32, "kernels": kern32}
+        out["speedup_vs_f32_mfma"] = value / v32
+        del model, sync, step
+        torch.cuda.empty_cache()
 
     if rank == 0 and not args.no_eval:
         # ---- BASELINE.json configs[1]: dense eval forward, B=1024, T=243 ------------------------------
-        torch.manual_seed(0)
-        ev = TemporalModel(17, 2, 17, FW, channels=C).to(dev).eval()
-        k_eval = max(3, args.steps // 4)
-        with torch.no_grad():
-            for _ in range(2):
+        def eval_section(mth):
+            torch.manual_seed(0)
+            ev = TemporalModel(17, 2, 17, FW, channels=C).to(dev).eval()
+            ev.math = mth
+            k_eval = max(3, args.steps // 4)
+            with torch.no_grad():
+                for _ in range(2):
+                    ev(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k_eval):
+                    y = ev(x)
+                torch.cuda.synchronize()
+                dte = (time.perf_counter() - t0) / k_eval
+                recs = []
+                ops.set_profiler(recs)
                 ev(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k_eval):
-                ev(x)
-            torch.cuda.synchronize()
-            dte = (time.perf_counter() - t0) / k_eval
-            recs = []
-            ops.set_profiler(recs)
-            ev(x)
-            torch.cuda.synchronize()
-            ops.set_profiler(None)
-        big = [(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b in recs if f > 1e11]
-        tf = FLOP_EVAL_PER_FRAME * B / dte / 1e12
-        out["cfg2_eval_fwd"] = {"workload": "TemporalModel eval forward (BN folded), arc 3,3,3,3,3 C=1024 B=1024 T=243",
-                                "ms": dte * 1e3, "frames_per_s": B / dte, "tflops": tf,
-                                "frac_of_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS, "iters": k_eval,
-                                "big_gemm_tflops": [round(f / ms / 1e9, 1) for f, ms in big]}
-        del ev
+                torch.cuda.synchronize()
+                ops.set_profiler(None)
+            big = [(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b in recs if f > 1e11]
+            tf = FLOP_EVAL_PER_FRAME * B / dte / 1e12
+            return y, {"workload": "TemporalModel eval forward (BN folded), arc 3,3,3,3,3 C=1024 B=1024 T=243", "math": mth,
+                       "ms": dte * 1e3, "frames_per_s": B / dte, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
+                       "iters": k_eval, "big_gemm_tflops": [round(f / ms / 1e9, 1) for f, ms in big]}
+        y_a, out["cfg2_eval_fwd"] = eval_section(math)
+        if math != "f32" and not args.no_f32:
+            y_b, out["cfg2_eval_fwd_f32_mfma"] = eval_section("f32")
+            out["cfg2_eval_fwd"]["mpjpe_vs_f32_mfma"] = float(mpjpe(y_a, y_b))
+            out["cfg2_eval_fwd"]["speedup_vs_f32_mfma"] = out["cfg2_eval_fwd_f32_mfma"]["ms"] / out["cfg2_eval_fwd"]["ms"]
+            del y_b
+        del y_a
         torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
