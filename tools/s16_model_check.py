@@ -20,6 +20,7 @@ def rel(a, b):
 def parity(fw, c, b, p):
     torch.manual_seed(0)
     m32 = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=p, channels=c).to(dev).train()
+    m32.math = "f32"
     m16 = copy.deepcopy(m32)
     m16.math = "f16x3"
     for m in (m32, m16):
@@ -48,6 +49,7 @@ def parity(fw, c, b, p):
     # eval (dilated) parity with the trained-state buffers
     e32 = V.TemporalModel(17, 2, 17, fw, channels=c).to(dev).eval()
     e32.load_state_dict(m32.state_dict())
+    e32.math = "f32"
     e16 = copy.deepcopy(e32)
     e16.math = "f16x3"
     xe = (torch.randn(4, rf + 20, 17, 2, device=dev) * 0.5).clamp(-1, 1)

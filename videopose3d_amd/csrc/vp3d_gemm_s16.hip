@@ -22,21 +22,30 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;   // elements per K-tile (= 128 B per row)
+constexpr int KQ = 32;   // K and channels-per-tap are multiples of this many elements (launcher check)
 
-template <int WM_, int WN_, int RB_, int CB_, int NSTAGE_>
+// BKE: elements per K-tile (16 or 32 -> 64- or 128-byte rows in the LDS image, 1 or 2 MFMA k-steps per tile).
+// With 16-element tiles a 4-deep ring fits twice in a CU's LDS (2 workgroups x 4 x 16 KiB for 128x128), keeping three
+// tiles in flight per workgroup: the MFMA time of a K-tile (768 pipe cycles for a 64x64 sub-tile) is far below the
+// LDS-DMA latency under load (~1.5 us), so the depth of the ring, not its width, is what feeds the matrix pipe.
+template <int WM_, int WN_, int RB_, int CB_, int NSTAGE_, int BKE_ = 32, int PIPE_ = 0, int BUF_ = 0>
 struct Cfg {
-  static constexpr int WM = WM_, WN = WN_, RB = RB_, CB = CB_, NSTAGE = NSTAGE_;
+  static constexpr int WM = WM_, WN = WN_, RB = RB_, CB = CB_, NSTAGE = NSTAGE_, BKE = BKE_, PIPE = PIPE_, BUF = BUF_;
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int BM = WM * RB * 32, BN = WN * CB * 32;
-  static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;   // 1-KiB LDS-DMA pieces per wave per K-tile
-  static constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;
+  static constexpr int ROWB = BKE * 4;                       // bytes per row per K-tile
+  static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB LDS-DMA piece (8 or 16)
+  static constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;   // pieces per wave per K-tile
+  static constexpr int A_B = BM * ROWB, B_B = BN * ROWB, STAGE_B = A_B + B_B;
   static constexpr int TAB_OFF = NSTAGE * STAGE_B;
   static constexpr int SMEM_B = TAB_OFF + 2 * BM * 4;
   static constexpr int OCC = (SMEM_B * 2 <= 160 * 1024 && NT * 2 <= 1024) ? 2 : 1;   // workgroups per CU aimed at
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "DMA pieces must divide evenly over the waves");
+  static_assert(BKE == 16 || BKE == 32, "K-tile of 16 or 32 elements");
+  static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "DMA pieces must divide evenly over the waves");
   static_assert(NW * 32 * CB * 32 * 4 <= NSTAGE * STAGE_B, "epilogue staging must fit in the operand ring");
   static_assert(RB % 2 == 0, "64-row statistic slabs need an even number of 32-row blocks per wave");
+  // 16-B chunk c of tile row r sits at chunk position c ^ swz(r): conflict-free ds_read_b128 for both row widths
+  __device__ static __forceinline__ int swz(int r) { return BKE == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 };
 
 __device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
@@ -44,32 +53,87 @@ __device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: 32-bit per-lane byte offset, out-of-range offsets deliver zeros (no zero page,
+// no 64-bit pointer arithmetic or validity select per piece per K-tile)
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+constexpr int kOob = (int)0x80000000u;     // >= num_records of any tensor the launcher lets onto this path (< 2 GiB)
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One 32-element K-tile of this wave's sub-tile: 2 MFMA k-steps x 3 products.
-template <int RB, int CB>
-__device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
-                                             f32x16 (&acc)[RB][CB], int off0, int off1) {
-  f16x8 ah[2][RB], al[2][RB], bh[2][CB], bl[2][CB];
+// Register-resident fragments of one K-tile of a wave's sub-tile, and the two halves of compute_tile as separate
+// functions: the pipelined main loop (Cfg::PIPE) reads the fragments of tile it+1 while the MFMAs of tile it run.
+template <int RB, int CB, int STEPS>
+struct Frags {
+  f16x8 ah[STEPS][RB], al[STEPS][RB], bh[STEPS][CB], bl[STEPS][CB];
+};
+
+template <int RB, int CB, int STEPS, int ROWB>
+__device__ __forceinline__ void load_frags(const char* __restrict__ sA, const char* __restrict__ sB, int off0, int off1,
+                                           Frags<RB, CB, STEPS>& f) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < STEPS; ++s) {
     const int off = s == 0 ? off0 : off1;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * 4096 + off);
-      al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * 4096 + (off ^ 16));
+      f.ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + off);
+      f.al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + (off ^ 16));
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-      bh[s][j] = *reinterpret_cast<const f16x8*>(sB + j * 4096 + off);
-      bl[s][j] = *reinterpret_cast<const f16x8*>(sB + j * 4096 + (off ^ 16));
+      f.bh[s][j] = *reinterpret_cast<const f16x8*>(sB + j * (32 * ROWB) + off);
+      f.bl[s][j] = *reinterpret_cast<const f16x8*>(sB + j * (32 * ROWB) + (off ^ 16));
+    }
+  }
+}
+
+template <int RB, int CB, int STEPS>
+__device__ __forceinline__ void mma_frags(const Frags<RB, CB, STEPS>& f, f32x16 (&acc)[RB][CB]) {
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[s][i], f.bh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[s][i], f.bl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[s][i], f.bh[s][j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// One K-tile of this wave's sub-tile: STEPS MFMA k-steps (16 elements each) x 3 products.
+template <int RB, int CB, int STEPS, int ROWB>
+__device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
+                                             f32x16 (&acc)[RB][CB], int off0, int off1) {
+  f16x8 ah[STEPS][RB], al[STEPS][RB], bh[STEPS][CB], bl[STEPS][CB];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int off = s == 0 ? off0 : off1;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + off);
+      al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + (off ^ 16));
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      bh[s][j] = *reinterpret_cast<const f16x8*>(sB + j * (32 * ROWB) + off);
+      bl[s][j] = *reinterpret_cast<const f16x8*>(sB + j * (32 * ROWB) + (off ^ 16));
     }
   }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -103,6 +167,7 @@ __device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int& 
 template <class C>
 __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const RowsGemmArgs p) {
   constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE, PA = C::PA, PB = C::PB;
+  constexpr int BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP, CPR = ROWB / 16;   // chunks per row
   __shared__ __attribute__((aligned(16))) char smem[C::SMEM_B];
   int* tab_b = reinterpret_cast<int*>(smem + C::TAB_OFF);
   int* tab_t = tab_b + BM;
@@ -148,28 +213,72 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const float* a_ptr[PA];
   const float* b_ptr[PB];
   int b_inc[PB];
-  const int zoff = (lane & 7) * 4;
+  const int zoff = (lane & (CPR - 1)) * 4;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int r = (w * PA + i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const int r = (w * PA + i) * RPP + lane / CPR;
+    const int chunk = (lane & (CPR - 1)) ^ C::swz(r);
     const int b = tab_b[r], t = tab_t[r];
     a_t[i] = t * p.t_stride + p.t_off + tap0 * p.tap_step;
     a_ptr[i] = p.A + ((int64_t)b * p.t_src + a_t[i]) * p.lda + c0 + chunk * 4;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int r = (w * PB + i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const int r = (w * PB + i) * RPP + lane / CPR;
+    const int chunk = (lane & (CPR - 1)) ^ C::swz(r);
     const bool ok = (n0 + r) < p.N;
     b_ptr[i] = ok ? p.B + (int64_t)(n0 + r) * p.ldb + (int64_t)kt_begin * BK + chunk * 4 : p.zeros + chunk * 4;
     b_inc[i] = ok ? BK : 0;
   }
   const int64_t a_jump = (int64_t)p.tap_step * p.lda - p.c_src + BK;   // at a tap boundary
 
-  auto issue = [&](int stage, bool live) {          // `live` = false: harmless zero-page DMA (keeps vmcnt uniform)
+  // buffer-descriptor path (C::BUF): per piece one 32-bit byte offset that advances by a constant per K-tile
+  int a_vo[PA], a_cur[PA], b_cur[PB];
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  if (C::BUF) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      a_vo[i] = (int)((a_ptr[i] - p.A) * 4);
+      a_cur[i] = (unsigned)a_t[i] < (unsigned)p.t_src ? a_vo[i] : kOob;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_cur[i] = b_inc[i] != 0 ? (int)((b_ptr[i] - p.B) * 4) : kOob;
+  }
+  auto issue = [&](int stage, bool live) {          // `live` = false: harmless all-zero DMA (keeps vmcnt uniform)
     char* sA = smem + stage * C::STAGE_B;
     char* sB = sA + C::A_B;
+    if (C::BUF) {
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) blds16(rsA, a_cur[i], sA + (w * PA + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) blds16(rsB, b_cur[i], sB + (w * PB + i) * 1024);
+      } else {
+#pragma unroll
+        for (int i = 0; i < PA + PB; ++i) blds16(rsA, kOob, sA + (w * (PA + PB) + i) * 1024 % C::STAGE_B);
+      }
+      c0 += BK;
+      if (c0 >= p.c_src) {                            // wave-uniform, once per tap
+        c0 = 0;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          a_vo[i] += (int)(a_jump * 4);
+          a_t[i] += p.tap_step;
+          a_cur[i] = (unsigned)a_t[i] < (unsigned)p.t_src ? a_vo[i] : kOob;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          a_vo[i] += BK * 4;
+          a_cur[i] += BK * 4;                         // kOob + a few K-tiles stays out of range
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) b_cur[i] += BK * 4;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const bool ok = live && (unsigned)a_t[i] < (unsigned)p.t_src;
@@ -195,29 +304,59 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     for (int i = 0; i < PB; ++i) b_ptr[i] += b_inc[i];
   };
 
-  // fragment addressing: row = block base + cl, swizzle term ((row>>1)&7) depends on cl only
-  const int sw = (cl >> 1) & 7;
+  // fragment addressing: row = block base + cl, the swizzle term depends on cl only (block bases are multiples of 32);
+  // lane half h supplies elements 16 s + 8 h .. +7 of k-step s: chunk 2 (2 s + h) holds their hi parts, the next their lo
+  const int sw = C::swz(cl);
   const int off0 = ((2 * (0 + h)) ^ sw) * 16;
-  const int off1 = ((2 * (2 + h)) ^ sw) * 16;
-  const int a_row = (wm * RB * 32 + cl) * 128;
-  const int b_row = (wn * CB * 32 + cl) * 128;
+  const int off1 = BK == 32 ? ((2 * (2 + h)) ^ sw) * 16 : 0;
+  const int a_row = (wm * RB * 32 + cl) * ROWB;
+  const int b_row = (wn * CB * 32 + cl) * ROWB;
 
-  if (nkt > 0) {
-    issue(0, true);
-    if (NSTAGE == 3) issue(1, nkt > 1);
+  if (nkt > 0 && !C::PIPE) {
+    // NSTAGE-deep ring, NSTAGE-1 tiles in flight: iteration `it` waits for ITS tile only (counted vmcnt: the newer
+    // tiles stay in flight across the barrier), then refills the stage everyone left at the end of iteration it-1
+#pragma unroll
+    for (int ps = 0; ps < NSTAGE - 1; ++ps) issue(ps, ps < nkt);
+    int st_c = 0, st_i = NSTAGE - 1;                 // stage computed / issued this iteration
     for (int it = 0; it < nkt; ++it) {
-      if (NSTAGE == 3) {
-        wait_vmcnt<PA + PB>();                       // tile `it` landed (this wave's pieces); tile it+1 stays in flight
-        __builtin_amdgcn_s_barrier();                // ... everyone's did, and everyone left stage (it+2)%3
-        issue((it + 2) % 3, it + 2 < nkt);
-      } else {
-        wait_vmcnt<0>();
-        __syncthreads();
-        issue((it + 1) & 1, it + 1 < nkt);
-      }
-      const char* sA = smem + (it % NSTAGE) * C::STAGE_B;
-      compute_tile<RB, CB>(sA + a_row, sA + C::A_B + b_row, acc, off0, off1);
+      wait_vmcnt<(PA + PB) * (NSTAGE - 2)>();
+      if (NSTAGE == 2) __syncthreads();
+      else __builtin_amdgcn_s_barrier();
+      issue(st_i, it + NSTAGE - 1 < nkt);
+      const char* sA = smem + st_c * C::STAGE_B;
+      compute_tile<RB, CB, BK / 16, ROWB>(sA + a_row, sA + C::A_B + b_row, acc, off0, off1);
+      st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+      st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
     }
+  }
+  if (nkt > 0 && C::PIPE) {
+    // Register double-buffered variant: the fragments of tile it+1 are read from LDS while the MFMAs of tile `it`
+    // (already in registers) run, so a wave's matrix work starts right behind the barrier instead of behind its DMA
+    // issue + LDS read latency.  All NSTAGE stages are kept loaded: the stage of tile `it` is free once everybody has
+    // its fragments in registers (lgkmcnt(0) + barrier) and is refilled with tile it+NSTAGE.
+    Frags<RB, CB, BK / 16> fr[2];
+#pragma unroll
+    for (int ps = 0; ps < NSTAGE; ++ps) issue(ps, ps < nkt);
+    wait_vmcnt<(PA + PB) * (NSTAGE - 1)>();          // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    load_frags<RB, CB, BK / 16, ROWB>(smem + a_row, smem + C::A_B + b_row, off0, off1, fr[0]);
+    int st = 0;                                      // stage of tile `it`
+    auto body = [&](int it, Frags<RB, CB, BK / 16>& cur, Frags<RB, CB, BK / 16>& nxt) {
+      wait_vmcnt<(PA + PB) * (NSTAGE - 2)>();        // tile it+1 landed (own pieces)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads of tile `it` are in registers
+      __builtin_amdgcn_s_barrier();
+      issue(st, it + NSTAGE < nkt);                  // refill the stage of tile `it`
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+      const char* sN = smem + st * C::STAGE_B;       // tile it+1 (a harmless zero-page tile past the end)
+      load_frags<RB, CB, BK / 16, ROWB>(sN + a_row, sN + C::A_B + b_row, off0, off1, nxt);
+      mma_frags<RB, CB, BK / 16>(cur, acc);
+    };
+    int it = 0;
+    for (; it + 1 < nkt; it += 2) {
+      body(it, fr[0], fr[1]);
+      body(it + 1, fr[1], fr[0]);
+    }
+    if (it < nkt) body(it, fr[0], fr[1]);
   }
   wait_vmcnt<0>();                                   // the trailing zero-page DMAs must not land in the staging below
 
@@ -281,7 +420,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   __syncthreads();                                   // every wave is done reading the operand ring
   // Each wave stages one 32-row block of its sub-tile at a time through its own [32][CB*32] fp32 LDS region and
   // writes it out with 16-B stores (a row of the region = CB*128 B contiguous in C).
-  constexpr int WCOLS = CB * 32, LPR = WCOLS / 4, RPP = 64 / LPR;   // lanes per row, rows per pass
+  constexpr int WCOLS = CB * 32, LPR = WCOLS / 4, ERPP = 64 / LPR;   // lanes per row, rows per pass
   float* wreg = reinterpret_cast<float*>(smem) + w * (32 * WCOLS);
   const int rr = lane / LPR, c4 = (lane % LPR) * 4;
   float* Cbase = partial ? p.part + (int64_t)split * p.part_floats : e.C;
@@ -304,8 +443,8 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       }
     __syncthreads();
 #pragma unroll 4
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
-      const int r = ps * RPP + rr;
+    for (int ps = 0; ps < 32 / ERPP; ++ps) {
+      const int r = ps * ERPP + rr;
       const int lr = (wm * RB + i) * 32 + r;         // row inside the tile
       if (m0 + lr >= p.M || n >= Nlim) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
@@ -527,7 +666,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
   const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
   const int m_groups = (a.m_tiles + 7) / 8, n_groups = (a.n_tiles + gn - 1) / gn;
   const int positions = 8 * gn * m_groups * n_groups;
-  const int nkt = a.K / BK;
+  const int nkt = a.K / C::BKE;
   a.pos_full = positions;
   a.tail_pos = 0;
   a.splits = splits;
@@ -544,7 +683,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
 // when fewer than 256 are in flight); the finishing pass of a split forward/dgrad launch streams the partial
 // matrices (mostly Infinity-Cache resident) once each way, a raw (wgrad) launch leaves that to vp3d_wgrad_reduce.
 void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out) {
-  const int nkt = K / BK;
+  const int nkt = K / 32;
   double best = 1e30;
   int best_cfg = 0, best_s = 1;
   for (int cfg = 0; cfg < 2; ++cfg) {
@@ -560,7 +699,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
       if (s > 1) cost += (raw ? 0.0 : 4.0) + (double)s * (double)M * (double)N * (raw ? 4.0 : 8.0) / 8.0e6;
       if (cost < best * 0.98) {
         best = cost;
-        best_cfg = cfg == 0 ? 0 : 4;
+        best_cfg = cfg == 0 ? 20 : 22;              // buffer-descriptor DMA variants (the launcher falls back for >= 2 GiB operands)
         best_s = s;
       }
     }
@@ -574,7 +713,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, float* ws, int64_t ws_floats,
                   bool raw_partials) {
   RowsGemmArgs a = a_in;
-  VP3D_REQUIRE(a.K % BK == 0 && a.c_src % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && aligned16(a.A) && aligned16(a.B) &&
+  VP3D_REQUIRE(a.K % KQ == 0 && a.c_src % KQ == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && aligned16(a.A) && aligned16(a.B) &&
                    aligned16(a.zeros),
                "nt_s16: the split-fp16 GEMM needs channel counts %% 32 == 0 and 16-byte aligned S16 rows");
   if (cfg < 0) {
@@ -584,7 +723,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     if (splits <= 0) splits = ps;
   }
   if (splits <= 0) splits = 1;
-  VP3D_REQUIRE(splits <= a.K / BK, "nt_s16: splits=%d exceeds the %d K-tiles", splits, a.K / BK);
+  VP3D_REQUIRE(splits <= a.K / KQ, "nt_s16: splits=%d exceeds the %d K-tiles", splits, a.K / KQ);
   if (splits > 1) {
     VP3D_REQUIRE(ws != nullptr && aligned16(ws) && ws_floats >= (int64_t)splits * a.M * a.N,
                  "nt_s16: split-K needs a workspace of splits*M*N floats");
@@ -595,6 +734,15 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
               (a.epi.bias == nullptr || aligned16(a.epi.bias)) &&
               (a.epi.R == nullptr || (aligned16(a.epi.R) && a.epi.r_ld % 4 == 0 && a.epi.r_bpitch % 4 == 0 &&
                                       a.epi.r_col0 % 4 == 0 && a.epi.r_cols % 4 == 0));
+  // byte extents for the buffer-descriptor DMA path (configurations >= 20): both operands must stay below 2 GiB
+  const int64_t a_rows = (int64_t)(a.M / a.t_dst) * a.t_src;
+  const int64_t a_bytes = ((a_rows - 1) * a.lda + a.c_src) * 4, b_bytes = ((int64_t)(a.N - 1) * a.ldb + a.K) * 4;
+  a.a_bytes = (uint32_t)a_bytes;
+  a.b_bytes = (uint32_t)b_bytes;
+  if (cfg >= 20 && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31))) {
+    static const int flat_of[5] = {0, 10, 4, 13, 11};
+    cfg = flat_of[cfg - 20];
+  }
   int rc;
   switch (cfg) {
     case 0: rc = launch_cfg<Cfg<2, 2, 2, 2, 2>>(s, a, splits); break;     // 128x128, 4 waves, 2 stages, 2 WG/CU
@@ -602,6 +750,21 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     case 2: rc = launch_cfg<Cfg<4, 2, 2, 2, 2>>(s, a, splits); break;     // 256x128, 8 waves, 2 stages
     case 3: rc = launch_cfg<Cfg<4, 2, 2, 2, 3>>(s, a, splits); break;     // 256x128, 8 waves, 3 stages
     case 4: rc = launch_cfg<Cfg<2, 4, 4, 2, 2>>(s, a, splits); break;     // 256x256, 8 waves (128x64 each), 2 stages
+    case 5: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16>>(s, a, splits); break; // 128x128, 4 waves, 4 x 16-element stages, 2 WG/CU
+    case 6: rc = launch_cfg<Cfg<2, 2, 2, 2, 3, 16>>(s, a, splits); break; // 128x128, 3 x 16-element stages
+    case 7: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16>>(s, a, splits); break; // 256x256, 8 waves, 4 x 16-element stages (128 KiB)
+    case 8: rc = launch_cfg<Cfg<2, 4, 4, 2, 3, 16>>(s, a, splits); break; // 256x256, 8 waves, 3 x 16-element stages
+    case 9: rc = launch_cfg<Cfg<4, 2, 2, 2, 4, 16>>(s, a, splits); break; // 256x128, 8 waves, 4 x 16-element stages (96 KiB)
+    case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break; // cfg 0 with buffer-descriptor DMA
+    case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break; // cfg 10 with buffer-descriptor DMA
+    case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break; // cfg 4 with buffer-descriptor DMA
+    case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break; // cfg 13 with buffer-descriptor DMA
+    case 24: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16, 1, 1>>(s, a, splits); break; // cfg 11 with buffer-descriptor DMA
+    case 10: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1>>(s, a, splits); break; // 128x128 register-pipelined, 2 x 32
+    case 11: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16, 1>>(s, a, splits); break; // 128x128 register-pipelined, 4 x 16
+    case 12: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 1>>(s, a, splits); break; // 256x256 register-pipelined, 2 x 32
+    case 13: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1>>(s, a, splits); break; // 256x256 register-pipelined, 4 x 16
+    case 14: rc = launch_cfg<Cfg<2, 2, 2, 2, 3, 16, 1>>(s, a, splits); break; // 128x128 register-pipelined, 3 x 16
     default:
       set_error("nt_s16: unknown tile configuration %d", cfg);
       return VP3D_E_INVALID;

@@ -70,6 +70,7 @@ struct RowsGemmArgs {
   int32_t pos_full, tail_pos, splits, kt_per_split;
   float* part;
   int64_t part_floats;
+  uint32_t a_bytes, b_bytes;   // S16 kernel, buffer-descriptor DMA: byte extents of the two operands (set by the launcher)
   Epi epi;
 };
 
