@@ -202,7 +202,7 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
                         const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
                         int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
                         const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps);
-/* dy of vp3d_bn_bwd_apply as S16 rows (+ transposed copy, taps = 1) */
+/* dy of vp3d_bn_bwd_apply as S16 rows (dy, may be NULL when only the transposed copy is wanted) + transposed copy (taps = 1) */
 int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
                           const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
@@ -223,6 +223,21 @@ int vp3d_act_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* gamm
 /* *out = max_c |scale_c|*(g + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M), g = *go_bound/(1-p): bound of vp3d_bn_bwd_apply's dy */
 int vp3d_dy_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* scale, const float* dgamma,
                   const float* dbeta, const float* go_bound, float p, float* out);
+
+/* One-launch forms of the per-layer prologue of a training step (at most 16 tensors / layers; the pointer tables are
+ * HOST arrays, copied into the kernel arguments).  bounds: n consecutive bounds (32 floats each), zeroed by the caller. */
+int vp3d_amax_multi(vp3d_stream_t stream, int32_t n_tensors, const float* const* src, const int64_t* n, float* bounds);
+/* vp3d_pack_weight_s16 (strided dgrad form) for n_layers [c_out][c_in][taps_i] weights; layer i uses bounds + 32*i */
+int vp3d_pack_weight_s16_multi(vp3d_stream_t stream, int32_t n_layers, const float* const* w, const int32_t* taps,
+                               int32_t c_out, int32_t c_in, const float* bounds, void* const* wf, void* const* wd);
+/* vp3d_act_bound for every layer of the stack: bounds[i] = max_c(|gamma_i|*sqrt(M_i-1) + |beta_i|)/(1-p) +
+ * (res_from[i] >= 0 ? bounds[res_from[i]] : 0)   (res_from[i] < i) */
+int vp3d_act_bounds_multi(vp3d_stream_t stream, int32_t n_layers, int32_t C, const float* const* gamma,
+                          const float* const* beta, const int64_t* M, const int32_t* res_from, float p, float* bounds);
+/* vp3d_bn_bwd_finalize + vp3d_dy_bound in one launch (dy_bound: zeroed bound, atomically max-ed) */
+int vp3d_bn_bwd_finalize_s16(vp3d_stream_t stream, int32_t C, int64_t M, const float* partials, int32_t nparts,
+                             float* dgamma, float* dbeta, const float* scale, const float* go_bound, float p,
+                             float* dy_bound);
 
 /* dx[b,s,:] = sum_k dy[b, map(s,k), :] @ W_k^T (+ epilogue: the residual-gradient scatter).
  *   M = B*t_dst rows of dx, N = n_out columns, K = taps*c_out.

@@ -81,6 +81,10 @@ SIGNATURES = {
                                         _i64]),
     "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
+    "vp3d_amax_multi": (C.c_int, [_vp, _i32, _P(_vp), _P(_i64), _vp]),
+    "vp3d_pack_weight_s16_multi": (C.c_int, [_vp, _i32, _P(_vp), _P(_i32), _i32, _i32, _vp, _P(_vp), _P(_vp)]),
+    "vp3d_act_bounds_multi": (C.c_int, [_vp, _i32, _i32, _P(_vp), _P(_vp), _P(_i64), _P(_i32), _f32, _vp]),
+    "vp3d_bn_bwd_finalize_s16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp]),
     "vp3d_act_bound": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _f32, _vp, _vp]),
     "vp3d_dy_bound": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _vp]),
     "vp3d_tconv_dgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32,

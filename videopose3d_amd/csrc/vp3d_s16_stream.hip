@@ -180,11 +180,13 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
         const float xh = (yy - mu[e]) * is[e];
         v[e] = sc[e] * (g - kb[e] - xh * kg[e]) * inv;
       }
-      f16x8 hi, lo;
-      s16_split8(v, 1.f, hi, lo);
-      f16x8* o = reinterpret_cast<f16x8*>(dy + e0);
-      o[0] = hi;
-      o[1] = lo;
+      if (dy != nullptr) {                          // (the expand conv needs no dgrad: only the transposed copy is written)
+        f16x8 hi, lo;
+        s16_split8(v, 1.f, hi, lo);
+        f16x8* o = reinterpret_cast<f16x8*>(dy + e0);
+        o[0] = hi;
+        o[1] = lo;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -326,6 +328,167 @@ __global__ void __launch_bounds__(1024) k_dy_bound(int C, float inv_m, float sqr
   if (threadIdx.x == 0) out[0] = m;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// per-step prologue of the training forward, one launch each for ALL layers (the per-layer launches of a few
+// microseconds each added up to ~0.3 ms of a 5.8 ms step)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxLayers = 16;
+
+struct AmaxMulti {
+  const float* src[kMaxLayers];
+  int64_t n[kMaxLayers];
+  float* bounds;               // bound of tensor i at bounds + i * kBoundSlots
+};
+
+__global__ void __launch_bounds__(256) k_amax_multi(AmaxMulti a) {
+  const int ti = blockIdx.y;
+  const float* src = a.src[ti];
+  const int64_t n = a.n[ti];
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? n >> 2 : 0;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = s4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) s16_atomic_bound(a.bounds + ti * kBoundSlots, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+struct PackMulti {
+  const float* w[kMaxLayers];
+  float* wf[kMaxLayers];
+  float* wd[kMaxLayers];
+  int taps[kMaxLayers];
+  const float* bounds;         // bound of layer i at bounds + i * kBoundSlots
+  int c_out, c_in;
+};
+
+__global__ void __launch_bounds__(256) k_pack_weight_s16_multi(PackMulti a) {
+  extern __shared__ float tile[];                 // [taps][64 co][TPITCH]
+  const int li = blockIdx.z;
+  const int taps = a.taps[li], c_in = a.c_in, c_out = a.c_out;
+  const float* __restrict__ w = a.w[li];
+  float* __restrict__ wf = a.wf[li];
+  float* __restrict__ wd = a.wd[li];
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const float inv = s16_pow2(-s16_exp_of(a.bounds + li * kBoundSlots));
+  const int row_f = 64 * taps;
+  for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
+    const int co = idx / row_f, q = idx - co * row_f;
+    const int ci = q / taps, k = q - ci * taps;
+    tile[(k * 64 + co) * TPITCH + ci] = w[((int64_t)(co0 + co) * c_in + ci0) * taps + q] * inv;
+  }
+  __syncthreads();
+  const int64_t ld_f = (int64_t)taps * c_in, ld_d = c_out;
+  if (wf != nullptr) {
+    for (int idx = threadIdx.x; idx < taps * 512; idx += 256) {
+      const int g = idx & 7, co = (idx >> 3) & 63, k = idx >> 9;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[(k * 64 + co) * TPITCH + g * 8 + j];
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      f16x8* d = reinterpret_cast<f16x8*>(wf + (int64_t)(co0 + co) * ld_f + (int64_t)k * c_in + ci0 + g * 8);
+      d[0] = hi;
+      d[1] = lo;
+    }
+  }
+  if (wd != nullptr) {
+    for (int idx = threadIdx.x; idx < taps * 512; idx += 256) {
+      const int g = idx & 7, ci = (idx >> 3) & 63, k = idx >> 9;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[(k * 64 + g * 8 + j) * TPITCH + ci];
+      f16x8 hi, lo;
+      s16_split8(v, 1.f, hi, lo);
+      f16x8* d = reinterpret_cast<f16x8*>(wd + ((int64_t)k * c_in + ci0 + ci) * ld_d + co0 + g * 8);
+      d[0] = hi;
+      d[1] = lo;
+    }
+  }
+}
+
+struct ActBoundsMulti {
+  const float* gamma[kMaxLayers];
+  const float* beta[kMaxLayers];
+  float sqrt_m1[kMaxLayers];
+  int res_from[kMaxLayers];    // index of the layer whose activation is the residual source, -1: none
+  float* bounds;               // bound of layer i at bounds + i * kBoundSlots (slot 0 written, the rest zero)
+  int n_layers, C;
+  float inv_keep;
+};
+
+__global__ void __launch_bounds__(1024) k_act_bounds_multi(ActBoundsMulti a) {
+  __shared__ float red[1024];
+  __shared__ float done[kMaxLayers];
+  for (int li = 0; li < a.n_layers; ++li) {
+    float m = 0.f;
+    for (int c = threadIdx.x; c < a.C; c += 1024)
+      m = fmaxf(m, fabsf(a.gamma[li][c]) * a.sqrt_m1[li] + fabsf(a.beta[li][c]));
+    m = block_max_1024(m, red);
+    if (threadIdx.x == 0) {
+      const float b = m * a.inv_keep + (a.res_from[li] >= 0 ? done[a.res_from[li]] : 0.f);
+      done[li] = b;
+      a.bounds[li * kBoundSlots] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// BN backward finalize (dgamma, dbeta from the partial sums, fp64) + the bound of dy in the same launch:
+// |dy_c| <= |scale_c| * (g + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M),  g = go_bound / (1-p)
+constexpr int FIN_CH = 16, FIN_GROUPS = 64;
+__global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize_bound(
+    int C, const float* __restrict__ partials, int nparts, float* dgamma, float* dbeta, const float* __restrict__ scale,
+    const float* __restrict__ go_bound, float inv_keep, float inv_m, float sqrt_m1, float* __restrict__ dy_bound) {
+  __shared__ double s1[FIN_GROUPS][FIN_CH], s2[FIN_GROUPS][FIN_CH];
+  __shared__ float bmax[FIN_CH];
+  const float gmax = s16_load_bound(go_bound) * inv_keep;
+  const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int p = g; p < nparts; p += FIN_GROUPS) {
+      a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
+      a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
+    }
+  }
+  s1[g][cl] = a1;
+  s2[g][cl] = a2;
+  __syncthreads();
+  for (int o = FIN_GROUPS / 2; o >= 1; o >>= 1) {
+    if (g < o) {
+      s1[g][cl] += s1[g + o][cl];
+      s2[g][cl] += s2[g + o][cl];
+    }
+    __syncthreads();
+  }
+  if (g == 0) {
+    float b = 0.f;
+    if (c < C) {
+      const float db = (float)s1[0][cl], dg = (float)s2[0][cl];
+      dbeta[c] = db;
+      dgamma[c] = dg;
+      b = fabsf(scale[c]) * (gmax + fabsf(db) * inv_m + sqrt_m1 * fabsf(dg) * inv_m);
+    }
+    bmax[cl] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = bmax[0];
+    for (int i = 1; i < FIN_CH; ++i) m = fmaxf(m, bmax[i]);
+    s16_atomic_bound(dy_bound, m);
+  }
+}
+
 }  // namespace
 }  // namespace vp3d
 
@@ -368,7 +531,7 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
                           const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
                           void* dy, void* t_out, int64_t ld_t) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && y && scale && shift && mean && invstd &&
-                   dgamma && dbeta && out_bound && dy,
+                   dgamma && dbeta && out_bound && (dy || t_out),
                "bn_bwd_apply_s16: bad argument (needs C %% 64 == 0)");
   VP3D_REQUIRE(aligned16(go) && aligned16(y) && aligned16(dy), "bn_bwd_apply_s16: 16-byte aligned buffers required");
   int rc = check_t("bn_bwd_apply_s16", t_out, ld_t, 1, M);
@@ -422,6 +585,83 @@ int vp3d_dy_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* scale
   hipLaunchKernelGGL(k_dy_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, 1.0f / (float)M,
                      sqrtf((float)(M > 1 ? M - 1 : 1)), scale, dgamma, dbeta, go_bound, 1.0f / (1.0f - p), out);
   return check_launch("dy_bound");
+}
+
+int vp3d_amax_multi(vp3d_stream_t stream, int32_t n_tensors, const float* const* src, const int64_t* n, float* bounds) {
+  VP3D_REQUIRE(n_tensors > 0 && n_tensors <= kMaxLayers && src && n && bounds, "amax_multi: bad argument (at most %d tensors)",
+               kMaxLayers);
+  AmaxMulti a;
+  int64_t nmax = 0;
+  for (int i = 0; i < kMaxLayers; ++i) {
+    a.src[i] = i < n_tensors ? src[i] : nullptr;
+    a.n[i] = i < n_tensors ? n[i] : 0;
+    if (i < n_tensors) {
+      VP3D_REQUIRE(src[i] != nullptr && n[i] > 0, "amax_multi: tensor %d is empty", i);
+      nmax = n[i] > nmax ? n[i] : nmax;
+    }
+  }
+  a.bounds = bounds;
+  int64_t blocks = (nmax + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1024 ? blocks : 1024;
+  hipLaunchKernelGGL(k_amax_multi, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("amax_multi");
+}
+
+int vp3d_pack_weight_s16_multi(vp3d_stream_t stream, int32_t n_layers, const float* const* w, const int32_t* taps,
+                               int32_t c_out, int32_t c_in, const float* bounds, void* const* wf, void* const* wd) {
+  VP3D_REQUIRE(n_layers > 0 && n_layers <= kMaxLayers && w && taps && bounds && wf && wd && c_out > 0 && c_in > 0 &&
+                   c_out % 64 == 0 && c_in % 64 == 0,
+               "pack_weight_s16_multi: bad argument (at most %d layers, channels %% 64 == 0)", kMaxLayers);
+  PackMulti a;
+  int tmax = 1;
+  for (int i = 0; i < kMaxLayers; ++i) {
+    a.w[i] = i < n_layers ? w[i] : nullptr;
+    a.wf[i] = i < n_layers ? (float*)wf[i] : nullptr;
+    a.wd[i] = i < n_layers ? (float*)wd[i] : nullptr;
+    a.taps[i] = i < n_layers ? taps[i] : 1;
+    if (i < n_layers) {
+      VP3D_REQUIRE(w[i] && taps[i] >= 1 && taps[i] <= 3 && (wf[i] || wd[i]) && aligned16(wf[i]) && aligned16(wd[i]),
+                   "pack_weight_s16_multi: layer %d (taps 1..3, 16-byte aligned outputs)", i);
+      tmax = taps[i] > tmax ? taps[i] : tmax;
+    }
+  }
+  a.bounds = bounds;
+  a.c_out = c_out;
+  a.c_in = c_in;
+  hipLaunchKernelGGL(k_pack_weight_s16_multi, dim3(c_in / 64, c_out / 64, n_layers), dim3(256), (size_t)tmax * 64 * TPITCH * 4,
+                     (hipStream_t)stream, a);
+  return check_launch("pack_weight_s16_multi");
+}
+
+int vp3d_act_bounds_multi(vp3d_stream_t stream, int32_t n_layers, int32_t C, const float* const* gamma,
+                          const float* const* beta, const int64_t* M, const int32_t* res_from, float p, float* bounds) {
+  VP3D_REQUIRE(n_layers > 0 && n_layers <= kMaxLayers && C > 0 && gamma && beta && M && res_from && bounds && p >= 0.f && p < 1.f,
+               "act_bounds_multi: bad argument (at most %d layers)", kMaxLayers);
+  ActBoundsMulti a;
+  for (int i = 0; i < kMaxLayers; ++i) {
+    a.gamma[i] = i < n_layers ? gamma[i] : nullptr;
+    a.beta[i] = i < n_layers ? beta[i] : nullptr;
+    a.sqrt_m1[i] = i < n_layers ? sqrtf((float)(M[i] > 1 ? M[i] - 1 : 1)) : 0.f;
+    a.res_from[i] = i < n_layers ? res_from[i] : -1;
+    if (i < n_layers) VP3D_REQUIRE(gamma[i] && beta[i] && res_from[i] < i, "act_bounds_multi: layer %d", i);
+  }
+  a.bounds = bounds;
+  a.n_layers = n_layers;
+  a.C = C;
+  a.inv_keep = 1.0f / (1.0f - p);
+  hipLaunchKernelGGL(k_act_bounds_multi, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return check_launch("act_bounds_multi");
+}
+
+int vp3d_bn_bwd_finalize_s16(vp3d_stream_t stream, int32_t C, int64_t M, const float* partials, int32_t nparts,
+                             float* dgamma, float* dbeta, const float* scale, const float* go_bound, float p,
+                             float* dy_bound) {
+  VP3D_REQUIRE(C > 0 && M > 0 && nparts > 0 && partials && dgamma && dbeta && scale && go_bound && dy_bound && p >= 0.f && p < 1.f,
+               "bn_bwd_finalize_s16: bad argument");
+  hipLaunchKernelGGL(k_bn_bwd_finalize_bound, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C,
+                     partials, nparts, dgamma, dbeta, scale, go_bound, 1.0f / (1.0f - p), 1.0f / (float)M,
+                     sqrtf((float)(M > 1 ? M - 1 : 1)), dy_bound);
+  return check_launch("bn_bwd_finalize_s16");
 }
 
 }  // extern "C"

@@ -121,21 +121,25 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         """taps of the conv that consumes the activation of layer idx (its wgrad reduces over the transposed copy)."""
         return plan.convs[idx + 1].taps if idx + 1 < n_layers else 0
 
+    # per-step prologue for ALL layers, one launch each: weight maxima -> S16 weight packs; activation bounds
+    ws = [c.weight.detach() for c in convs]
+    S.amax_multi(ws, bounds[n_layers:])
+    packs = [(S.split(ops.pack_weight(ws[0], ld_out=kpad), bounds[n_layers]), None)]
+    packs += S.pack_weights_multi(ws[1:], bounds[n_layers + 1:], want_dgrad=save)
+    t_len = plan.lengths(t_in0)
+    m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
+    res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
+    S.act_bounds_multi(bns, m_all, res_from, p, bounds)
+
     h_prev = None          # S16 block input (residual source)
     a = x_rows
     a_t = x_t
-    t_in = t_in0
     for idx in range(n_layers):
         spec = spec0 if idx == 0 else plan.convs[idx]
-        w = convs[idx].weight.detach()
-        wb = S.amax(w, out=bounds[n_layers + idx])
-        if idx == 0:
-            wf = S.split(ops.pack_weight(w, ld_out=kpad), wb)
-            wd = None
-        else:
-            wf, wd = S.pack_weight(w, wb, want_fwd=True, want_dgrad=save)
+        wf, wd = packs[idx]
         t_cur = a.data.shape[1]
         m_rows = b * spec.t_out(t_cur)
+        assert m_rows == m_all[idx]
         stats = ops.stat_buffers(m_rows, spec.c_out, dev)
         y = S.conv_nt(a, wf, spec, stats=stats)
         coef = ops.bn_finalize(bns[idx], m_rows, stats)
@@ -143,9 +147,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         residual = None
         if idx >= 2 and idx % 2 == 0:
             residual = (h_prev, plan.res[idx // 2 - 1])
-        S.act_bound(bns[idx], m_rows, p, residual[0].bound if residual is not None else None, bounds[idx])
         if save:
-            saved.append(_Saved(a_t, y, coef, drop, wd, t_in if idx == 0 else t_cur, kpad if idx == 0 else 0))
+            saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0))
         if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True)
         else:
@@ -201,7 +204,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         if o_g is None or o_bt is None:
             o_g = o_bt = None
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
-                                            out_dgamma=o_g, out_dbeta=o_bt)
+                                            out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0)   # expand: no dgrad
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
         return dy, dy_t

@@ -220,8 +220,9 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
 
 
 def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
-               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None):
-    """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows, dy S16 transposed, dgamma, dbeta)."""
+               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True):
+    """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows [None unless want_rows: only dgrad reads them],
+    dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy."""
     ops._chk(go, "go")
     ops._chk(y, "y")
     b, t, c = y.shape
@@ -241,16 +242,14 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     else:
         dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
         dgam, dbet = dgb[0], dgb[1]
-    check(L.vp3d_bn_bwd_finalize(ops._stream(), c, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr()),
-          "vp3d_bn_bwd_finalize")
-    check(L.vp3d_dy_bound(ops._stream(), c, m, sc, dgam.data_ptr(), dbet.data_ptr(), go_bound.data_ptr(), float(p),
-                          dy_bound.data_ptr()), "vp3d_dy_bound")
-    dy = torch.empty_like(y)
+    check(L.vp3d_bn_bwd_finalize_s16(ops._stream(), c, m, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr(), sc,
+                                     go_bound.data_ptr(), float(p), dy_bound.data_ptr()), "vp3d_bn_bwd_finalize_s16")
+    dy = torch.empty_like(y) if want_rows else None
     dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device)
     check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
-                                  dbet.data_ptr(), dy_bound.data_ptr(), dy.data_ptr(), dyt.data_ptr(), dyt.shape[1]),
+                                  dbet.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(), dyt.shape[1]),
           "vp3d_bn_bwd_apply_s16")
-    return S16(dy, dy_bound), S16(dyt, dy_bound), dgam, dbet
+    return (S16(dy, dy_bound) if dy is not None else None), S16(dyt, dy_bound), dgam, dbet
 
 
 def join(x: S16) -> torch.Tensor:
@@ -264,3 +263,50 @@ def join(x: S16) -> torch.Tensor:
     e = torch.frexp(bd)[1].to(torch.float32) - 15.0
     e = torch.where((bd > 0) & (bd < 3.0e38), e, torch.zeros_like(e))
     return v * torch.exp2(e)
+
+
+# --------------------------------------------------------------------------------------------------------
+# one-launch prologue of a training step (all layers at once)
+# --------------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def amax_multi(tensors, bounds: torch.Tensor):
+    """bounds[i] (rows of a new_bounds() array) = max|tensors[i]|, one launch."""
+    n = (C.c_int64 * len(tensors))(*[t.numel() for t in tensors])
+    for t in tensors:
+        ops._chk(t, "t")
+    check(_lib.lib().vp3d_amax_multi(ops._stream(), len(tensors), _ptr_array(tensors), n, bounds.data_ptr()),
+          "vp3d_amax_multi")
+
+
+def pack_weights_multi(weights, bounds: torch.Tensor, want_dgrad=True):
+    """[(S16 fwd pack, S16 dgrad pack or None)] for same-shaped-channel conv weights, one launch; layer i uses bounds[i]."""
+    c_out, c_in = weights[0].shape[0], weights[0].shape[1]
+    dev = weights[0].device
+    wfs, wds, taps = [], [], []
+    for w in weights:
+        ops._chk(w, "weight")
+        assert w.shape[0] == c_out and w.shape[1] == c_in
+        k = w.shape[2]
+        taps.append(k)
+        wfs.append(torch.empty((c_out, k * c_in), dtype=torch.float32, device=dev))
+        wds.append(torch.empty((k * c_in, c_out), dtype=torch.float32, device=dev) if want_dgrad else None)
+    check(_lib.lib().vp3d_pack_weight_s16_multi(ops._stream(), len(weights), _ptr_array(weights),
+                                                (C.c_int32 * len(taps))(*taps), c_out, c_in, bounds.data_ptr(),
+                                                _ptr_array(wfs), _ptr_array(wds)), "vp3d_pack_weight_s16_multi")
+    return [(S16(wf, bounds[i]), S16(wd, bounds[i]) if wd is not None else None)
+            for i, (wf, wd) in enumerate(zip(wfs, wds))]
+
+
+def act_bounds_multi(bns, m_rows, res_from, p: float, bounds: torch.Tensor):
+    """bounds[i] = guaranteed bound of layer i's activation (vp3d_act_bound for every layer, one launch)."""
+    n = len(bns)
+    check(_lib.lib().vp3d_act_bounds_multi(ops._stream(), n, bns[0].num_features, _ptr_array([b.weight for b in bns]),
+                                           _ptr_array([b.bias for b in bns]), (C.c_int64 * n)(*m_rows),
+                                           (C.c_int32 * n)(*res_from), float(p), bounds.data_ptr()),
+          "vp3d_act_bounds_multi")
