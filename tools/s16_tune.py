@@ -33,7 +33,7 @@ def sweep(tag, m, n, k, raw):
     rm = RowMap(1, m, m, 1, 0, 0, 1)
     flops = 2.0 * m * n * k
     res = []
-    for cfg in (0, 2, 4):
+    for cfg in (20, 22):
         for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
             if s > 1 and (k // 32) // s < 4:
                 continue
@@ -51,7 +51,7 @@ def sweep(tag, m, n, k, raw):
                 continue
             res.append((ms, cfg, s))
     res.sort()
-    pc, ps = S.plan(m, n, k)
+    pc, ps = S.plan(m, n, k, raw)
     planned = [r for r in res if r[1] == pc and r[2] == ps]
     print("%-16s M=%6d N=%5d K=%6d  best c%d s%-2d %7.3f ms %6.1f TF | 2nd c%d s%-2d %7.3f | plan c%d s%-2d %s" % (
         tag, m, n, k, res[0][1], res[0][2], res[0][0], flops / res[0][0] / 1e9, res[1][1], res[1][2], res[1][0], pc, ps,

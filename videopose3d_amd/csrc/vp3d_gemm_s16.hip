@@ -689,7 +689,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
   for (int cfg = 0; cfg < 2; ++cfg) {
     const int bt = cfg == 0 ? 128 : 256;
     const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
-    for (int s = 1; s <= (allow_split ? 64 : 1); ++s) {
+    for (int s = 1; s <= (allow_split ? 32 : 1); ++s) {
       if (s > 1 && (nkt / s < 6 || cfg != 0)) break;                // the 256x256 configuration only pays unsplit
       const int64_t per_cu = (tiles * s + 255) / 256;
       const double nk = (double)((nkt + s - 1) / s);

@@ -147,13 +147,13 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
 _side_streams = {}
 
 
-def _wgrad_stream(device) -> Optional[torch.cuda.Stream]:
+def _wgrad_stream(device, default_on: bool = False) -> Optional[torch.cuda.Stream]:
     """Second HIP stream for the weight-gradient GEMMs of backward: opt-in (VP3D_OVERLAP=1), never under bench.py's
     per-kernel event instrumentation.  Measured on MI355X (gpurun_out b9/b10, B=1024): forking wgrad next to its own
     dgrad is neutral (10.39 vs 10.34 ms/step: two fp32-MFMA GEMMs just split the matrix pipes), forking it under the
     next layer's HBM-bound BN-backward kernels costs 1.3 % (10.47 ms) -- the streaming kernels and the GEMM's
     L2-miss traffic contend for the fabric -- so the serial order stays the default."""
-    if os.environ.get("VP3D_OVERLAP", "0") != "1" or ops._prof is not None:
+    if os.environ.get("VP3D_OVERLAP", "1" if default_on else "0") != "1" or ops._prof is not None:
         return None
     key = torch.device(device).index
     st = _side_streams.get(key)
