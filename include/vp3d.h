@@ -175,6 +175,22 @@ typedef struct vp3d_s16 {
   float* ws;
   int64_t ws_floats;
   int32_t raw_partials;
+  /* eval-mode chaining without an fp32 round trip (all optional, 0 / NULL = off):
+   *   res_s16 / res_bound : the epilogue's residual tensor holds S16 rows with the exponent of *res_bound
+   *   out_s16             : y receives S16 rows instead of fp32 (same addressing, same bytes).  Their exponent comes
+   *                         from the bound  l1[0]*max(in_amax) + l1[1] + (res_amax ? max(res_amax) : 0)  with
+   *                         l1 = { max_n sum_k |wt[n][k]|, max_n |bias[n]| } (device floats, weight-only) and in_amax /
+   *                         res_amax the MEASURED maxima of the input / residual tensors (bounds written by the
+   *                         amax_out of the launches that produced them): a guaranteed bound that is loose by one
+   *                         layer only.  It is published in out_wbound[0] (32 zeroed floats) = the bound consumers
+   *                         decode y with; amax_out still measures the true values.  No statistics, no split-K. */
+  int32_t res_s16;
+  const float* res_bound;
+  int32_t out_s16;
+  const float* in_amax;
+  const float* l1;
+  const float* res_amax;
+  float* out_wbound;
 } vp3d_s16;
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
 /* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form

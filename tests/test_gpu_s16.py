@@ -206,3 +206,37 @@ def test_unsupported_configurations_fall_back_to_fp32_kernels():
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=128)
     assert engine_s16.supported(m, 27, True) and not engine_s16.supported(m, 28, True)
     assert not engine_s16.supported(m, 27, True, need_dx=True)
+
+
+@pytest.mark.parametrize("cfg", [20, 22])
+def test_s16_output_and_s16_residual_chain(cfg):
+    """Eval chaining: the epilogue writes S16 rows under the device-evaluated one-layer bound l1[0]*amax(in)+l1[1]+amax(res),
+    reads an S16 residual, and still measures the true maximum."""
+    g = torch.Generator().manual_seed(13)
+    b, t, c = 5, 40, 128
+    spec = ConvSpec(c, c, 3, 3, 1)
+    x = (torch.relu(torch.randn(b, t, c, generator=g)) * 2.0).to(DEV)
+    w = ((torch.rand(c, c, 3, generator=g) * 2 - 1) * 0.05).to(DEV)
+    bias = torch.randn(c, generator=g).to(DEV)
+    r = (torch.randn(b, t, c, generator=g) * 3).to(DEV)
+    rs = ResSpec(3, 1)
+    wt = ops.pack_weight(w)
+    ref, den = _ref_conv(x, w, spec, bias)
+    ref = torch.relu(ref) + r[:, 3:3 + spec.t_out(t)].double()
+    xs, ws_, r16 = S.split(x), S.split(wt), S.split(r)
+    l1 = torch.stack([wt.abs().sum(dim=1).max(), bias.abs().max()]).contiguous()
+    am = S.new_bound(DEV)
+    y = S.conv_nt(xs, ws_, spec, bias=bias, relu=True, residual=(r16, rs), amax_out=am, cfg=cfg,
+                  s16_out=(xs.bound, l1, r16.bound))
+    yv = S.join(y)
+    tol = GEMM_TOL * den + float(y.bound.max()) * 2.0 ** -21
+    assert bool(((yv.double() - ref).abs() <= tol).all())
+    assert abs(float(am.max()) - float(ref.abs().max())) < 1e-4
+    assert float(y.bound.max()) >= float(ref.abs().max())                     # the published bound is a bound
+    expect = float(l1[0]) * float(x.abs().max()) + float(l1[1]) + float(r.abs().max())
+    assert abs(float(y.bound.max()) - expect) < 1e-3 * expect
+    # fp32 output with an S16 residual (the last block of the eval stack) agrees with the fp32-residual form
+    y32 = S.conv_nt(xs, ws_, spec, bias=bias, relu=True, residual=(r16, rs), cfg=cfg)
+    y32b = S.conv_nt(xs, ws_, spec, bias=bias, relu=True, residual=(S.join(r16), rs), cfg=cfg)
+    assert float((y32 - y32b).abs().max()) < 1e-5
+    assert float((y32.double() - ref).abs().max()) < 1e-4

@@ -42,6 +42,9 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->ab_drop = make_drop(nullptr);
   e->bound_a = e->bound_b = nullptr;
   e->amax_out = nullptr;
+  e->r_s16 = e->c_s16 = 0;
+  e->r_bound = e->in_amax = e->l1 = e->res_amax = nullptr;
+  e->out_wbound = nullptr;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -217,8 +220,26 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
   a.epi.bound_a = o->x_bound;
   a.epi.bound_b = o->w_bound;
   a.epi.amax_out = o->amax_out;
+  if (o->res_s16) {
+    VP3D_REQUIRE(a.epi.R != nullptr && o->res_bound != nullptr && a.epi.r_ld % 8 == 0 && a.epi.r_col0 % 8 == 0 && c_out % 8 == 0,
+                 "tconv_nt_s16: an S16 residual needs its bound and 8-element aligned rows");
+    a.epi.r_s16 = 1;
+    a.epi.r_bound = o->res_bound;
+  }
+  if (o->out_s16) {
+    VP3D_REQUIRE(!o->raw_partials && o->in_amax && o->l1 && o->out_wbound && c_out % 8 == 0 && ldy % 8 == 0 && y_bpitch % 8 == 0 &&
+                     aligned16(y) && (epi == nullptr || epi->stat_sum == nullptr) && (o->splits == 1 || o->splits == 0),
+                 "tconv_nt_s16: S16 output needs in_amax / l1 / out_wbound, 8-element aligned rows, no statistics, no split-K");
+    VP3D_REQUIRE(a.epi.R == nullptr || o->res_s16, "tconv_nt_s16: S16 output takes an S16 residual");
+    a.epi.c_s16 = 1;
+    a.epi.in_amax = o->in_amax;
+    a.epi.l1 = o->l1;
+    a.epi.res_amax = o->res_amax;
+    a.epi.out_wbound = o->out_wbound;
+  }
   set_splits(&a, nullptr, 0);
-  return launch_nt_s16((hipStream_t)stream, a, o->cfg, o->splits, o->ws, o->ws_floats, o->raw_partials != 0);
+  return launch_nt_s16((hipStream_t)stream, a, o->cfg, (o->out_s16 || o->res_s16) ? 1 : o->splits, o->ws, o->ws_floats,
+                       o->raw_partials != 0);   // the finishing pass of a split launch knows neither S16 residuals nor S16 output
 }
 
 int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, void* dst,

@@ -424,10 +424,68 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   float* wreg = reinterpret_cast<float*>(smem) + w * (32 * WCOLS);
   const int rr = lane / LPR, c4 = (lane % LPR) * 4;
   float* Cbase = partial ? p.part + (int64_t)split * p.part_floats : e.C;
-  const int n = n0 + wn * WCOLS + c4;
   const int Nlim = p.N;
   const bool vec = partial ? (p.N % 4 == 0) : (e.vec != 0);
   float amax = 0.f;
+  const float rscale = (!partial && e.r_s16) ? s16_pow2(s16_exp_of(e.r_bound)) : 1.f;
+  if (!partial && e.c_s16) {
+    // ---- S16 output (eval chaining): lane = 8 consecutive columns = one S16 group --------------------------
+    const float wb = e.l1[0] * s16_load_bound(e.in_amax) + e.l1[1] + (e.res_amax != nullptr ? s16_load_bound(e.res_amax) : 0.f);
+    if (blockIdx.x == 0 && tid == 0) e.out_wbound[0] = wb;
+    const float inv = s16_pow2(-s16_exp_for_bound(wb));
+    constexpr int LPR8 = WCOLS / 8, ERPP8 = 64 / LPR8;
+    const int rr8 = lane / LPR8, c8 = (lane % LPR8) * 8;
+    const int n8 = n0 + wn * WCOLS + c8;
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e.bias != nullptr && n8 < Nlim) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) b8[c] = e.bias[n8 + c];
+    }
+    const int rc8 = n8 - e.r_col0;
+    const bool rcol_ok8 = e.R != nullptr && rc8 >= 0 && rc8 < e.r_cols;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
+        }
+      __syncthreads();
+#pragma unroll 2
+      for (int ps = 0; ps < 32 / ERPP8; ++ps) {
+        const int r = ps * ERPP8 + rr8;
+        const int lr = (wm * RB + i) * 32 + r;
+        if (m0 + lr >= p.M || n8 >= Nlim) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int b = tab_b[lr], t = tab_t[lr];
+        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int tr = t * e.r_stride + e.r_off;
+        if (rcol_ok8 && (unsigned)tr < (unsigned)e.r_t) {
+          const f16x8* rp = reinterpret_cast<const f16x8*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc8);
+          s16_join8(rp[0], rp[1], rscale, rv);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float x = v[c] + b8[c];
+          if (e.relu) x = x < 0.f ? 0.f : x;
+          x += rv[c];
+          amax = fmaxf(amax, fabsf(x));
+          v[c] = x * inv;
+        }
+        f16x8 hi, lo;
+        s16_split8(v, 1.f, hi, lo);
+        f16x8* o = reinterpret_cast<f16x8*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n8);
+        o[0] = hi;
+        o[1] = lo;
+      }
+      __syncthreads();
+    }
+  } else {
+  const int n = n0 + wn * WCOLS + c4;
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (!partial && e.bias != nullptr && vec && n < Nlim) bias = *reinterpret_cast<const f32x4*>(e.bias + n);
   const int rc = n - e.r_col0;
@@ -470,7 +528,16 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
         }
-        if (rcol_ok && r_row_ok) v += *reinterpret_cast<const f32x4*>(rrow + n);
+        if (rcol_ok && r_row_ok) {
+          if (e.r_s16) {                               // S16 residual: this lane's 4 columns are half of a group
+            const int g0 = (n - e.r_col0) & ~7, hf = ((n - e.r_col0) >> 2) & 1;
+            const _Float16* rp = reinterpret_cast<const _Float16*>(rrow + e.r_col0 + g0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += ((float)rp[hf * 4 + c] + (float)rp[8 + hf * 4 + c]) * rscale;
+          } else {
+            v += *reinterpret_cast<const f32x4*>(rrow + n);
+          }
+        }
         *reinterpret_cast<f32x4*>(crow + n) = v;
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
       } else {
@@ -488,6 +555,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       }
     }
     __syncthreads();
+  }
   }
   if (!partial && e.amax_out != nullptr) {             // max|stored value| of the whole launch (S16 exponent of the result)
 #pragma unroll

@@ -52,6 +52,17 @@ struct Epi {
   const float* bound_a;
   const float* bound_b;
   float* amax_out;
+  // S16 residual: R holds S16 rows with the exponent of *r_bound (r_s16 != 0)
+  int32_t r_s16;
+  const float* r_bound;
+  // S16 output (eval forward, c_s16 != 0): C receives S16 rows whose exponent comes from the bound
+  //   l1[0] * amax(in_amax) + l1[1] + (res_amax ? amax(res_amax) : 0)      (l1 = {max_n sum_k |W[n][k]|, max_n |bias[n]|})
+  // which every workgroup evaluates identically and workgroup 0 publishes in out_wbound[0] for the consumers
+  int32_t c_s16;
+  const float* in_amax;
+  const float* l1;
+  const float* res_amax;
+  float* out_wbound;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";

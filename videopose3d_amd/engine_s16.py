@@ -51,36 +51,54 @@ def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
 # eval
 # --------------------------------------------------------------------------------------------------------
 def folded_weights(mod):
+    """[(S16 folded weight pack, shift, l1)] per layer, cached until a parameter / buffer changes;
+    l1 = device [max_n sum_k |W[n][k]|, max_n |shift[n]|]: with the measured maximum of a layer's input it bounds the
+    layer's output (|y| <= l1[0] * max|x| + l1[1]), which is what lets the GEMM epilogue write S16 directly."""
     key = engine._eval_key(mod)
     cache = mod.__dict__.get("_fold_cache_s16")
     if cache is not None and cache[0] == key:
         return cache[1]
-    packs = [(S.split(wt), shift) for wt, shift in engine.folded_weights(mod)]     # fp32 fold (cached) -> S16
+    packs = []
+    for wt, shift in engine.folded_weights(mod):     # fp32 fold (cached) -> S16; weight-only work, once per weight version
+        l1 = torch.stack([wt.abs().sum(dim=1).max(), shift.abs().max()]).to(torch.float32).contiguous()
+        packs.append((S.split(wt), shift, l1))
     mod.__dict__["_fold_cache_s16"] = (key, packs)
     return packs
 
 
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+    """Eval forward with the activations kept in S16 between the GEMMs: every epilogue applies bias / ReLU / residual,
+    measures the true maximum (for the next layer's bound) and writes S16 rows with a guaranteed one-layer bound; only the
+    input of the 3*J-column shrink conv is written as fp32."""
     plan: StackPlan = mod._plan
     plan.lengths(x3.shape[1])
     packs = folded_weights(mod)
     dev = x3.device
-    bounds = S.new_bounds(1 + 2 * plan.n_blocks, dev)
+    amax = S.new_bounds(1 + 2 * plan.n_blocks, dev)
     xin, spec0, _ = engine._expand_input(plan, x3)
-    wt, bias = packs[0]
-    h = S.conv_nt(S.split(xin), wt, spec0, bias=bias, relu=True, amax_out=bounds[0])
+    xs = S.split(xin)                                 # measured bound: doubles as the input's amax
     del xin
-    hs = S.split(h, bounds[0])
+    wt, bias, l1 = packs[0]
+    hs = S.conv_nt(xs, wt, spec0, bias=bias, relu=True, amax_out=amax[0], s16_out=(xs.bound, l1, None))
+    h_amax = amax[0]
+    del xs
+    h = None
     for i in range(plan.n_blocks):
-        wt, bias = packs[1 + 2 * i]
-        u = S.conv_nt(hs, wt, plan.convs[1 + 2 * i], bias=bias, relu=True, amax_out=bounds[1 + 2 * i])
-        us = S.split(u, bounds[1 + 2 * i])
-        del u, hs
-        wt, bias = packs[2 + 2 * i]
-        h = S.conv_nt(us, wt, plan.convs[2 + 2 * i], bias=bias, relu=True, residual=(h, plan.res[i]),
-                      amax_out=bounds[2 + 2 * i])
+        last = i + 1 == plan.n_blocks
+        wt, bias, l1 = packs[1 + 2 * i]
+        us = S.conv_nt(hs, wt, plan.convs[1 + 2 * i], bias=bias, relu=True, amax_out=amax[1 + 2 * i],
+                       s16_out=(h_amax, l1, None))
+        wt, bias, l1 = packs[2 + 2 * i]
+        nxt = S.conv_nt(us, wt, plan.convs[2 + 2 * i], bias=bias, relu=True, residual=(hs, plan.res[i]),
+                        amax_out=None if last else amax[2 + 2 * i],
+                        s16_out=None if last else (amax[1 + 2 * i], l1, h_amax))
         del us
-        hs = S.split(h, bounds[2 + 2 * i]) if i + 1 < plan.n_blocks else None
+        if last:
+            h = nxt
+        else:
+            hs, h_amax = nxt, amax[2 + 2 * i]
+    if h is None:                                     # no blocks (single filter width): shrink reads the expand output
+        h = S.join(hs)
     return engine._shrink(mod, h)
 
 

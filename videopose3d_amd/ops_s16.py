@@ -87,10 +87,13 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
     return o, ws
 
 
-def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False,
-            residual: Optional[Tuple[torch.Tensor, ResSpec]] = None, stats=None, amax_out=None,
-            cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y (fp32) = conv(x) with the fused epilogue of ops.conv_fwd; x [B,T_in,C_in] and wt [C_out, taps*C_in] in S16."""
+def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=None, stats=None, amax_out=None,
+            cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None, s16_out=None):
+    """y = conv(x) with the fused epilogue of ops.conv_fwd; x [B,T_in,C_in] and wt [C_out, taps*C_in] in S16.
+
+    residual = (tensor, ResSpec): fp32 tensor or S16 (decoded with its own bound).
+    s16_out = None: y is fp32 (returned).  s16_out = (in_amax, l1, res_amax or None): y is written as S16 whose bound
+    l1[0]*max(in_amax) + l1[1] + max(res_amax) is evaluated on the device; returns S16(y, that bound)."""
     xd, wd = x.data, wt.data
     b, t_in, c_in = xd.shape
     assert c_in == spec.c_in and wd.shape == (spec.c_out, spec.taps * spec.c_in), (xd.shape, wd.shape, spec)
@@ -104,19 +107,33 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False,
         rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, spec.taps)
         c_src = c_in
     res = None
+    res_s16 = None
     if residual is not None:
         r, rs = residual
+        if isinstance(r, S16):
+            res_s16, r = r, r.data
         assert r.shape[0] == b and r.shape[2] == spec.c_out
         res = (r, rs.step, rs.start, 0)
     e = ops._epi(bias, relu, res, stats, spec.c_out)
     m, k = b * t_out, spec.taps * c_in
+    if s16_out is not None or res_s16 is not None:
+        splits = 1
     o, ws = _opts(x, wt, m, spec.c_out, k, xd.device, amax_out, cfg, splits)
+    if res_s16 is not None:
+        o.res_s16, o.res_bound = 1, res_s16.bound.data_ptr()
+    wbound = None
+    if s16_out is not None:
+        in_amax, l1, res_amax = s16_out
+        wbound = new_bound(xd.device)
+        o.out_s16, o.in_amax, o.l1 = 1, in_amax.data_ptr(), l1.data_ptr()
+        o.res_amax = None if res_amax is None else res_amax.data_ptr()
+        o.out_wbound = wbound.data_ptr()
     ops._timed_call("tconv_fwd", 2.0 * m * spec.c_out * k, _lib.lib().vp3d_tconv_nt_s16,
                     ops._stream(), C.byref(rm), xd.data_ptr(), c_in, c_src, wd.data_ptr(), wd.shape[1], spec.c_out,
                     out.data_ptr(), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
                     nbytes=4.0 * (xd.numel() + wd.numel() + out.numel() + (out.numel() if residual is not None else 0)))
-    return out
+    return out if s16_out is None else S16(out, wbound)
 
 
 def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: torch.Tensor, y_bpitch: int, ldy: int,
