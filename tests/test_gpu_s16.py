@@ -15,6 +15,15 @@ DEV = "cuda:0"
 GEMM_TOL = 1e-6
 
 
+@pytest.fixture(autouse=True)
+def _no_size_threshold():
+    from videopose3d_amd import engine
+    keep = dict(engine.S16_MIN_FORWARD_FLOPS)
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})
+    yield
+    engine.S16_MIN_FORWARD_FLOPS.update(keep)
+
+
 def _ref_conv(x, w, spec, bias=None):
     xd, wd = x.double().permute(0, 2, 1), w.double()
     y = torch.nn.functional.conv1d(xd, wd, None if bias is None else bias.double(), dilation=spec.dil, stride=spec.stride)
@@ -206,6 +215,14 @@ def test_unsupported_configurations_fall_back_to_fp32_kernels():
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=128)
     assert engine_s16.supported(m, 27, True) and not engine_s16.supported(m, 28, True)
     assert not engine_s16.supported(m, 27, True, need_dx=True)
+    # and calls too small to be compute-bound stay on the fp32 kernels (launch-latency regime)
+    from videopose3d_amd import engine
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 60e9, False: 35e9})
+    m.math = "f16x3"
+    assert not engine.use_s16(m, 27, True, batch=1024)                       # arc 3,3,3, B = 1024: 36 GFLOP forward
+    big = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
+    big.math = "f16x3"
+    assert engine.use_s16(big, 243, True, batch=1024) and not engine.use_s16(big, 243, True, batch=64)
 
 
 @pytest.mark.parametrize("cfg", [20, 22])

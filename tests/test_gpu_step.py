@@ -19,9 +19,13 @@ def math_mode(request):
     """Every test of this module runs once per GEMM arithmetic: "f16x3" (split-fp16 MFMA wherever engine_s16 supports
     the configuration, fp32 elsewhere) and "f32" (fp32 MFMA everywhere) -- same oracle, same tolerances."""
     import videopose3d_amd as _V
-    _V.set_default_math(request.param)
+    from videopose3d_amd import engine as _E
+    keep = dict(_E.S16_MIN_FORWARD_FLOPS)
+    _E.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})     # the small test models must not fall below the
+    _V.set_default_math(request.param)                            # engine's "big enough to be compute-bound" threshold
     yield request.param
     _V.set_default_math(None)
+    _E.S16_MIN_FORWARD_FLOPS.update(keep)
 DEV = "cuda:0"
 
 

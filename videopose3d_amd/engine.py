@@ -289,17 +289,28 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     return grads + [d_sw, d_sb], dx
 
 
-def use_s16(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
-    """True when this call runs on the split-fp16 GEMM path (module attribute ``math`` == "f16x3", see model.py) and the
-    configuration is one engine_s16 implements; everything else runs on the fp32-MFMA kernels."""
+# Below this much forward conv work per call the step is bound by launch latency, not by the matrix pipes, and the
+# split-fp16 engine's extra producers / bound kernels cost more than its GEMMs save (measured on MI355X,
+# tools/small_modes.py: arc 3,3,3,3,3 training crosses over between B = 128 and 256, B = 2 evaluation between 485 and
+# 742 input frames; arc 3,3,3 stays on the fp32 kernels up to B = 1024).  VP3D_S16_MIN_GFLOP overrides both (0 = always).
+_min_gf = os.environ.get("VP3D_S16_MIN_GFLOP")
+S16_MIN_FORWARD_FLOPS = {True: float(_min_gf or 60.0) * 1e9, False: float(_min_gf or 35.0) * 1e9}   # [training]
+
+
+def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Optional[int] = None) -> bool:
+    """True when this call runs on the split-fp16 GEMM path (module attribute ``math`` == "f16x3", see model.py), the
+    configuration is one engine_s16 implements and the call is big enough to be compute-bound; everything else runs on
+    the fp32-MFMA kernels."""
     if getattr(mod, "math", "f32") != "f16x3":
         return False
     from . import engine_s16
-    return engine_s16.supported(mod, t_in, training, need_dx)
+    if not engine_s16.supported(mod, t_in, training, need_dx):
+        return False
+    return batch is None or mod._plan.forward_flops(batch, t_in) >= S16_MIN_FORWARD_FLOPS[bool(training)]
 
 
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
-    if use_s16(mod, x3.shape[1], False):
+    if use_s16(mod, x3.shape[1], False, batch=x3.shape[0]):
         from . import engine_s16
         return engine_s16.forward_eval(mod, x3)
     return _forward_eval_f32(mod, x3)
@@ -307,7 +318,7 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 
 def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     """Returns (out3, saved); saved is None unless `save` (it records which arithmetic produced it)."""
-    if use_s16(mod, x3.shape[1], True, need_dx):
+    if use_s16(mod, x3.shape[1], True, need_dx, batch=x3.shape[0]):
         from . import engine_s16
         out, saved = engine_s16.forward_train(mod, x3, save)
         if saved is not None:

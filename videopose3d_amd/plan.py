@@ -57,6 +57,14 @@ class StackPlan:
             next_dil *= self.filter_widths[i]
         return frames
 
+    def forward_flops(self, batch: int, t_in: int) -> float:
+        """Conv FLOPs (2 per MAC) of one forward pass over [batch, t_in] frames (shrink included)."""
+        t, total = t_in, 0.0
+        for spec in self.convs:
+            t = spec.t_out(t) if spec is self.convs[0] or spec.taps > 1 else t
+            total += 2.0 * batch * max(t, 0) * spec.c_out * spec.c_in * spec.taps
+        return total + 2.0 * batch * max(t, 0) * self.shrink.c_out * self.shrink.c_in
+
     def lengths(self, t_in: int) -> List[int]:
         """Time length after expand and after every block; raises if the input is shorter than needed."""
         t = self.convs[0].t_out(t_in)
