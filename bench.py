@@ -40,6 +40,9 @@ RF = 243
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD)
 MFMA_PER_MAC_F16X3 = 3                # the split scheme issues ah*bh + ah*bl + al*bh: 3 executed MFMA FLOPs per algorithmic FLOP
+SUSTAINED_F16_MFMA_TFLOPS = 1700.0    # what a bare v_mfma_f32_32x32x16_f16 loop sustains on RANDOM operands on this chip (DVFS /
+                                      # power: tools/ubench/mfma_peak.hip measured 1,697-1,703 TFLOP/s with 1 and 2 workgroups per
+                                      # CU, with and without a barrier every 24 MFMAs) -- the practical ceiling of the matrix pipes
 FLOP_TRAIN_PER_FRAME = 1023866880     # fwd 352,569,344 + bwd 671,297,536 (conv MACs x 2)
 FLOP_EVAL_PER_FRAME = 5217830912      # TemporalModel forward on a 243-frame window
 
@@ -200,12 +203,15 @@ def instrumented(step, ops, n_prof, math):
         kname = "k_nt_s16<*> (vp3d_tconv_nt_s16: %s form)" % dom
         peak = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3
         extra = {"executed_mfma_tflops": alg * MFMA_PER_MAC_F16X3, "mfma_peak_f16_dense": PEAK_F16_MFMA_TFLOPS,
+                 "sustained_mfma_f16_random_operands": SUSTAINED_F16_MFMA_TFLOPS,
+                 "frac_of_sustained_mfma": alg * MFMA_PER_MAC_F16X3 / SUSTAINED_F16_MFMA_TFLOPS,
                  "frac_of_fp32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS,
                  "note": "split-fp16 GEMM: every algorithmic MAC is 3 f16 MFMA MACs (ah*bh + ah*bl + al*bh), so peak = "
                          "2500 / 3 TFLOP/s of algorithmic work; achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the "
                          "family's launches / sum of their HIP-event durations on the launch stream; frac = executed MFMA "
-                         "FLOP/s / dense f16 MFMA peak.  frac_of_fp32_mfma_peak > 1 means faster than the exact-fp32 MFMA "
-                         "path could run at 100 % of its roofline"}
+                         "FLOP/s / dense f16 MFMA peak (nominal, 2.4 GHz); frac_of_sustained_mfma = the same against what a bare "
+                         "MFMA loop sustains on random operands under this chip's power management (tools/ubench/mfma_peak.hip).  "
+                         "frac_of_fp32_mfma_peak > 1 means faster than the exact-fp32 MFMA path could run at 100 % of its roofline"}
     else:
         kname = {"tconv_fwd": "k_rows_gemm<true,*> (vp3d_tconv_fwd)", "tconv_dgrad": "k_rows_gemm<false,*> (vp3d_tconv_dgrad)",
                  "tconv_wgrad": "k_red_gemm<*> (vp3d_tconv_wgrad)"}[dom]
