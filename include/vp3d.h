@@ -75,6 +75,8 @@ typedef struct vp3d_dropout {
   uint64_t seed;
   uint64_t offset;
   uint32_t layer;
+  const uint64_t* offset_ptr; /* optional device uint64 added to `offset` when the kernel runs (NULL: none): lets a
+                                 captured hipGraph draw a fresh mask on every replay (bump the counter inside the graph) */
 } vp3d_dropout;
 
 /* Backward of the UPSTREAM layer's activation a = dropout(relu(bn(y_up))) fused into the dgrad epilogue (vp3d_tconv_dgrad

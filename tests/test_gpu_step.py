@@ -366,3 +366,54 @@ def test_overlapped_bucket_exchange_through_rccl_single_rank():
             assert torch.equal(pa.grad, pb.grad), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_graphed_train_step_equals_eager_steps(p_drop):
+    """graph.GraphedTrainStep (hipGraph replay of forward + mpjpe + backward) against the same steps run eagerly: losses,
+    gradients, BatchNorm running statistics, and a dropout mask that advances on every replay."""
+    import copy
+    import videopose3d_amd as V
+    from videopose3d_amd import dp
+    from videopose3d_amd import loss as vloss
+    from videopose3d_amd.graph import GraphedTrainStep
+    torch.manual_seed(3)
+    fw = [3, 3, 3]
+    m_e = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=p_drop, channels=128).to(DEV).train()
+    m_g = copy.deepcopy(m_e)
+    for m in (m_e, m_g):
+        m._drop_seed = 4242
+    m_e._drop_calls, m_g._drop_calls = 1, 0          # replay k draws offset 0 + k; the eager model starts at 1
+    sync_e = dp.FlatGradSync(m_e.parameters(), direct_module=m_e)
+    step = GraphedTrainStep(m_g)
+    gen = torch.Generator().manual_seed(5)
+    losses_e, losses_g, masks = [], [], []
+    for k in range(3):
+        x = (torch.randn(16, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(DEV)
+        tgt = (torch.randn(16, 1, 17, 3, generator=gen) * 0.3).to(DEV)
+        sync_e.zero_grad()
+        le = vloss.mpjpe(m_e(x), tgt)                  # the same fused loss kernel the captured step uses
+        le.backward()
+        lg = step(x, tgt)
+        losses_e.append(float(le))
+        losses_g.append(float(lg))
+        assert abs(losses_e[-1] - losses_g[-1]) < 1e-6 * max(1.0, abs(losses_e[-1])), (k, losses_e, losses_g)
+        for (name, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
+            assert torch.allclose(pe.grad, pg.grad, rtol=1e-5, atol=1e-8), (k, name)
+        masks.append(m_g.expand_bn.running_mean.clone())
+    for (name, be), (_, bg) in zip(m_e.named_buffers(), m_g.named_buffers()):
+        assert torch.allclose(be.float(), bg.float(), rtol=1e-6, atol=1e-7), name
+    assert int(m_g.expand_bn.num_batches_tracked) == 3
+    assert len(step._cache) == 1                       # one capture, three replays
+    if p_drop > 0:
+        assert len({round(v, 9) for v in losses_g}) == 3
+    # a new BatchNorm momentum (run.py:590-593) re-captures instead of replaying the stale launch arguments
+    m_g.set_bn_momentum(0.05)
+    m_e.set_bn_momentum(0.05)
+    x = (torch.randn(16, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(DEV)
+    tgt = (torch.randn(16, 1, 17, 3, generator=gen) * 0.3).to(DEV)
+    sync_e.zero_grad()
+    vloss.mpjpe(m_e(x), tgt).backward()
+    step(x, tgt)
+    assert len(step._cache) == 2
+    assert torch.allclose(m_e.expand_bn.running_var, m_g.expand_bn.running_var, rtol=1e-6, atol=1e-7)

@@ -23,7 +23,8 @@ class RowMap(C.Structure):
 
 
 class Dropout(C.Structure):
-    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32)]
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("layer", C.c_uint32),
+                ("offset_ptr", C.c_void_p)]
 
 
 class ActBwd(C.Structure):

@@ -15,7 +15,14 @@ struct DropP {
   float p, inv_keep;
   uint32_t k0, k1, off_lo, layer;
   int on;
+  const uint64_t* off_ptr;   // optional device-side step counter added to the offset (hipGraph replays: the launch
+                             // arguments are frozen, the counter is bumped inside the graph)
 };
+
+// call once at the top of a kernel (the by-value kernel argument is a private copy)
+__device__ __forceinline__ void drop_resolve(DropP& d) {
+  if (d.on && d.off_ptr != nullptr) d.off_lo += (uint32_t)*d.off_ptr;
+}
 
 __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                         uint32_t (&out)[4]) {
@@ -52,6 +59,7 @@ inline DropP make_drop(const vp3d_dropout* d) {
   r.k1 = r.on ? (uint32_t)(d->seed >> 32) : 0u;
   r.off_lo = r.on ? (uint32_t)d->offset : 0u;
   r.layer = r.on ? d->layer : 0u;
+  r.off_ptr = r.on ? d->offset_ptr : nullptr;
   return r;
 }
 

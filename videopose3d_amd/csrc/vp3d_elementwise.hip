@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd(int M, int C, const float* _
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     DropP d, ResMap rm, float* __restrict__ out, int lanes_per_row,
                                                     int rows_per_block) {
+  drop_resolve(d);
   const int lr = threadIdx.x % lanes_per_row;
   const int rsub = threadIdx.x / lanes_per_row;
   const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(int M, int C, const float
                                                        const float* __restrict__ invstd, DropP d,
                                                        float* __restrict__ partials, int lanes_per_row,
                                                        int rows_per_block) {
+  drop_resolve(d);
   const int lr = threadIdx.x % lanes_per_row;
   const int rsub = threadIdx.x / lanes_per_row;
   const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int M, int C, const float*
                                                       const float* __restrict__ invstd, DropP d,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                       float* __restrict__ dy, int lanes_per_row, int rows_per_block) {
+  drop_resolve(d);
   const int lr = threadIdx.x % lanes_per_row;
   const int rsub = threadIdx.x / lanes_per_row;
   const int c = (blockIdx.x * lanes_per_row + lr) * VEC;
@@ -380,6 +383,7 @@ __global__ void __launch_bounds__(256) k_im2row(int M, int t_dst, int t_src, int
 }
 
 __global__ void __launch_bounds__(256) k_dropout_mask(int64_t n, DropP d, float* out) {
+  drop_resolve(d);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (d.on) drop4(d, (uint64_t)(e >> 2), mk);

@@ -187,6 +187,8 @@ __device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], char
     // fused activation backward of the upstream layer: per-column BN coefficients, per-half-tile partial sums
     f32x4 a_sc, a_sh, a_mu, a_is;
     f32x4 sg[2], sgx[2];
+    DropP ab_drop = e.ab_drop;
+    if (fused) drop_resolve(ab_drop);       // (partial-tile launches carry an uninitialised ab_drop)
     if (fused) {
       const int ch = n % e.ab_c;
       a_sc = *reinterpret_cast<const f32x4*>(e.ab_scale + ch);
@@ -236,7 +238,7 @@ __device__ __forceinline__ void epilogue(const Epi& e, f32x16 (&acc)[2][2], char
           }
           v += rv[i8];
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (e.ab_drop.on) drop4(e.ab_drop, (uint64_t)(offs[i8] >> 2), mk);
+          if (ab_drop.on) drop4(ab_drop, (uint64_t)(offs[i8] >> 2), mk);
           f32x4 g;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -534,6 +536,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_rows_gemm(const RowsGemmArgs p)
     e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
     e.stat_sum = e.stat_m2 = nullptr;
     e.ab_y = nullptr;
+    e.ab_drop.on = 0;
+    e.ab_drop.off_ptr = nullptr;
     e.vec = 1;                                   // workspace tiles are 16-B aligned
     epilogue<false>(e, acc, smem, 0, 0, wm, wn, tid, lane, BM, BN, nullptr, nullptr, 0);
     return;
@@ -622,6 +626,8 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
   if (!nok) return;
   f32x4 a_sc, a_sh, a_mu, a_is;
   f32x4 sgv = {0.f, 0.f, 0.f, 0.f}, sgxv = {0.f, 0.f, 0.f, 0.f};
+  DropP ab_drop2 = e.ab_drop;
+  if (fused) drop_resolve(ab_drop2);
   if (fused) {
     const int chn = n % e.ab_c;
     a_sc = *reinterpret_cast<const f32x4*>(e.ab_scale + chn);
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
         const int64_t off = (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n;
         const f32x4 yv = *reinterpret_cast<const f32x4*>(e.ab_y + off);
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (e.ab_drop.on) drop4(e.ab_drop, (uint64_t)(off >> 2), mk);
+        if (ab_drop2.on) drop4(ab_drop2, (uint64_t)(off >> 2), mk);
         f32x4 g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -840,6 +846,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_red_gemm(const RedGemmArgs p) {
   e.r_ld = e.r_t = e.r_stride = e.r_off = e.r_col0 = e.r_cols = 0;
   e.stat_sum = e.stat_m2 = nullptr;
   e.ab_y = nullptr;
+  e.ab_drop.on = 0;
+  e.ab_drop.off_ptr = nullptr;
   e.vec = (p.N % 4 == 0) ? 1 : 0;               // partial matrices are 16-B aligned allocations
   epilogue<false>(e, acc, smem, m0, n0, wm, wn, tid, lane, p.Mo, p.N, nullptr, nullptr, 0);
 }

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         DropP d, ResS16 rm, const float* __restrict__ out_bound,
                                                         float* __restrict__ out, float* __restrict__ out_f32, TOut t) {
+  drop_resolve(d);
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
@@ -138,6 +139,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                           const float* __restrict__ out_bound, float* __restrict__ dy,
                                                           TOut t) {
+  drop_resolve(d);
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;

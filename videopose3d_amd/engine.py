@@ -128,7 +128,7 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
         stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
         y = ops.conv_fwd(h, wt, spec, stats=stats)
         coef = ops.bn_finalize(bns[idx], m_rows, stats)
-        drop = ops.make_dropout(p, seed, offset, idx)
+        drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         a = ops.bn_act_fwd(y, coef, drop, residual)
         if save:
             saved.append(_Saved(h, y, coef, drop, wt, kpad, t_in))

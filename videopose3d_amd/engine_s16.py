@@ -161,7 +161,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         stats = ops.stat_buffers(m_rows, spec.c_out, dev)
         y = S.conv_nt(a, wf, spec, stats=stats)
         coef = ops.bn_finalize(bns[idx], m_rows, stats)
-        drop = ops.make_dropout(p, seed, offset, idx)
+        drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:
             residual = (h_prev, plan.res[idx // 2 - 1])

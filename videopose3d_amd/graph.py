@@ -1,0 +1,128 @@
+"""hipGraph capture of the training step (forward + mpjpe loss + backward) of a videopose3d_amd model.
+
+The step of run.py:401-420 is ~130 kernel launches; for the large benchmark configuration the GPU is the bottleneck,
+but for the small ones (the semi-supervised setup of BASELINE configs[4]: arc 3,3,3, 64 + 64 samples; short last
+batches; small ``--batch-size``) the step is bound by launch latency.  ``GraphedTrainStep`` records the launches once per
+input shape into a ``torch.cuda.CUDAGraph`` (every libvp3d.so entry point only enqueues on the stream it is given and
+never allocates or synchronises: include/vp3d.h) and replays them with ONE host call per step.
+
+What makes a replay a new step although the launch arguments are frozen:
+  * the batch is copied into the graph's static input buffers;
+  * dropout masks: the kernels add a device-side step counter to the (frozen) Philox offset (``vp3d_dropout.offset_ptr``)
+    and the graph itself bumps the counter;
+  * BatchNorm running statistics / ``num_batches_tracked`` live in device memory and are updated in place;
+  * the BatchNorm momentum (run.py:590-593 changes it every epoch) IS a launch argument: it is part of the cache key, a
+    new value re-captures.
+Gradients land in the flat buffer of a ``dp.FlatGradSync`` (the parameters' ``.grad`` are views of it), so
+``optimizer.step()`` -- torch Adam or ``optim.FlatAdam`` -- follows unchanged; with more than one rank the gradient
+exchange runs after the replay (``sync.sync()``: one all-reduce of the flat buffer).
+
+    step = GraphedTrainStep(model_pos_train)            # once
+    for _, batch_3d, batch_2d in train_generator.next_epoch():
+        ...
+        loss_3d_pos = step(inputs_2d, inputs_3d)        # replaces zero_grad / forward / mpjpe / backward (run.py:410-418)
+        optimizer.step()
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import dp, engine, loss as vloss
+from ._lib import Vp3dError
+
+
+class _Entry:
+    __slots__ = ("graph", "x", "t", "loss", "keep")
+
+
+class GraphedTrainStep:
+    def __init__(self, model, sync: Optional[dp.FlatGradSync] = None):
+        self.model = model
+        self.sync = sync if sync is not None else dp.FlatGradSync(model.parameters(), direct_module=model)
+        if model.__dict__.get("_vp3d_grad_sink") is not self.sync:
+            raise Vp3dError("GraphedTrainStep needs a FlatGradSync created with direct_module=model (the captured backward "
+                            "writes the gradients straight into its flat buffer)")
+        self._cache: Dict[Tuple, _Entry] = {}
+
+    # one training step, eagerly (this is also what gets captured)
+    def _step(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        b, tt = x.shape[0], x.shape[1]
+        if m._drop_counter is not None:
+            m._drop_counter.add_(1)
+        out3, saved = engine.forward_train(m, x.view(b, tt, -1), save=True)
+        pred = out3.view(b, -1, m.num_joints_out, 3)
+        lval, gout = vloss._mpjpe_call(pred, t, None, True)
+        reduce = self.sync._reduce
+        self.sync._reduce = False                     # no collectives inside the step: sync.sync() exchanges afterwards
+        try:
+            grads, _ = engine.backward_train(m, saved, gout.view_as(out3), False)
+        finally:
+            self.sync._reduce = reduce
+        assert all(g is None for g in grads), "the gradient sink did not take every gradient"
+        return lval
+
+    def _key(self, x, t):
+        m = self.model
+        return (tuple(x.shape), tuple(t.shape), x.device.index, m.math, float(m.drop.p), m.expand_bn.momentum,
+                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]))
+
+    def _capture(self, x, t) -> _Entry:
+        m = self.model
+        if not m.training:
+            raise Vp3dError("GraphedTrainStep: call model.train() first")
+        if m._drop_counter is None:
+            m._drop_counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+        e = _Entry()
+        e.x = x.detach().to(torch.float32).contiguous().clone()
+        e.t = t.detach().to(torch.float32).contiguous().clone()
+        # one eager warm-up step (creates the lazily built helpers, loads the code objects, sizes the allocator) with the
+        # model's state put back afterwards: capture itself executes nothing
+        state = [b_.clone() for b_ in m.buffers()]
+        counters = (m._drop_calls, m._stats_epoch, m._drop_counter.clone())
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._step(e.x, e.t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for b_, s_ in zip(m.buffers(), state):
+                b_.copy_(s_)
+            m._drop_counter.copy_(counters[2])
+        m._drop_calls, m._stats_epoch = counters[0], counters[1]
+        # The captured backward forks its weight-gradient GEMMs onto the engine's second stream.  Capture with a FRESH one:
+        # a stream that RCCL collectives have run on (the overlapped bucket exchange of eager steps) made hipGraphLaunch
+        # crash on ROCm 7.0 when it was pulled into a capture.
+        key = x.device.index
+        cached = engine._side_streams.get(key)
+        engine._side_streams[key] = torch.cuda.Stream(device=x.device)
+        e.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):   # (an RCCL watchdog thread may be alive)
+                e.loss = self._step(e.x, e.t)
+        finally:
+            e.keep = engine._side_streams.pop(key)
+            if cached is not None:
+                engine._side_streams[key] = cached
+        m._stats_epoch = counters[1]
+        return e
+
+    def __call__(self, inputs_2d: torch.Tensor, inputs_3d: torch.Tensor) -> torch.Tensor:
+        """One training step on the batch; returns the mpjpe loss (a 0-dim device tensor that the next call overwrites)."""
+        if not inputs_2d.is_cuda:
+            raise Vp3dError("GraphedTrainStep runs on the GPU only")
+        key = self._key(inputs_2d, inputs_3d)
+        e = self._cache.get(key)
+        if e is None:
+            e = self._capture(inputs_2d, inputs_3d)
+            self._cache[key] = e
+        e.x.copy_(inputs_2d.reshape(e.x.shape))
+        e.t.copy_(inputs_3d.reshape(e.t.shape))
+        self.model._stats_epoch += 1                  # the running statistics are about to change (eval-fold cache key)
+        e.graph.replay()
+        if self.sync._reduce:
+            self.sync.sync()
+        return e.loss

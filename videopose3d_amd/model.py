@@ -58,6 +58,7 @@ class TemporalModelBase(nn.Module):
         self._stats_epoch = 0
         self._drop_calls = 0
         self._drop_seed = None
+        self._drop_counter = None       # optional device uint64 step counter added to the dropout offset (graph.py)
         # GEMM arithmetic (not part of the reference API / state_dict): "f16x3" = split-fp16 operands on
         # v_mfma_f32_32x32x16_f16 (fp32-class results: 22+ operand bits, exact products, fp32 accumulation; ~3x the
         # fp32 matrix rate) wherever engine_s16.supported() says so, "f32" = v_mfma_f32_32x32x2_f32 everywhere.
@@ -107,6 +108,9 @@ class TemporalModelBase(nn.Module):
         return groups
 
     # ---- dropout stream ---------------------------------------------------------------------------------
+    def _dropout_counter_ptr(self):
+        return None if self._drop_counter is None else self._drop_counter.data_ptr()
+
     def _next_dropout_state(self):
         if self._drop_seed is None:
             rank = int(os.environ.get("RANK", "0"))

@@ -72,10 +72,12 @@ def zeros_page(device) -> torch.Tensor:
     return z
 
 
-def make_dropout(p: float, seed: int, offset: int, layer: int) -> Optional[Dropout]:
+def make_dropout(p: float, seed: int, offset: int, layer: int, offset_ptr: Optional[int] = None) -> Optional[Dropout]:
+    """offset_ptr: device address of a uint64 step counter that the kernels add to `offset` (graph replays)."""
     if p <= 0.0:
         return None
-    return Dropout(float(p), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), int(layer))
+    return Dropout(float(p), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), int(layer),
+                   offset_ptr)
 
 
 def _epi(bias=None, relu=False, residual=None, stats=None, n_cols=0) -> Optional[Epilogue]:
