@@ -163,7 +163,9 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
  *                       scaled by 2^(e_x + e_w) before the epilogue.
  *   amax_out          : optional bound, atomically max-ed with |stored value| (the bound of the result for a
  *                       consumer that re-splits it; zero its 32 slots before the launch)
- *   cfg               : tile configuration (0: 128x128 tiles / 4 waves, 4: 256x256 tiles / 8 waves, -1: planned)
+ *   cfg               : tile configuration, -1: planned (vp3d_nt_s16_plan).  20 / 22: 128x128 tiles of 4 waves / 256x256
+ *                       tiles of 8 waves with buffer-descriptor LDS-DMA (operands < 2 GiB, else their flat-address forms
+ *                       0 / 4 are used); 10, 13, 21, 23: register-pipelined variants kept for measurements
  *   splits            : K slices (1 = none, 0 = planned: vp3d_nt_s16_plan); > 1 needs ws of splits*M*N floats.
  *                       The slices write raw scaled partial matrices [splits][M][N]; a finishing pass sums them and
  *                       applies the epilogue -- unless raw_partials, where the partials ARE the result (wgrad:

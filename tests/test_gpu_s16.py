@@ -34,9 +34,12 @@ def _ref_conv(x, w, spec, bias=None):
 CASES = [  # (B, T, spec, cfg, splits)
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 0, 1),
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 4, 1),
-    (8, 27, ConvSpec(256, 256, 3, 3, 1), 2, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 20, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 22, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 13, 1),
     (5, 27, ConvSpec(160, 96, 3, 1, 3), 0, 1),          # N = 96 (ragged column tile), strided
-    (5, 27, ConvSpec(160, 96, 3, 1, 3), 4, 3),          # split-K + finishing pass
+    (5, 27, ConvSpec(160, 96, 3, 1, 3), 22, 3),         # split-K + finishing pass
+    (5, 27, ConvSpec(160, 96, 3, 1, 3), 21, 1),         # register-pipelined fragments, ragged N
     (3, 31, ConvSpec(64, 200, 1), 0, 2),                # ragged M = 93, N = 200
     (7, 40, ConvSpec(128, 128, 3, 9, 1), -1, 0),        # planned
     (2, 300, ConvSpec(64, 64, 5, 1, 1), 0, 1),          # 5 adjacent taps ("dense"-style)

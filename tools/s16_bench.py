@@ -82,6 +82,6 @@ def perf(cfgs):
 
 
 if __name__ == "__main__":
-    cfgs = [int(a) for a in sys.argv[1:]] or [0, 2, 4]
+    cfgs = [int(a) for a in sys.argv[1:]] or [0, 4, 20, 22]
     accuracy(cfgs)
     perf(cfgs)

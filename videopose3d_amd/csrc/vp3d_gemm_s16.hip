@@ -807,32 +807,22 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   const int64_t a_bytes = ((a_rows - 1) * a.lda + a.c_src) * 4, b_bytes = ((int64_t)(a.N - 1) * a.ldb + a.K) * 4;
   a.a_bytes = (uint32_t)a_bytes;
   a.b_bytes = (uint32_t)b_bytes;
-  if (cfg >= 20 && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31))) {
-    static const int flat_of[5] = {0, 10, 4, 13, 11};
+  if (cfg >= 20 && cfg <= 23 && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31))) {
+    static const int flat_of[4] = {0, 10, 4, 13};
     cfg = flat_of[cfg - 20];
   }
   int rc;
   switch (cfg) {
-    case 0: rc = launch_cfg<Cfg<2, 2, 2, 2, 2>>(s, a, splits); break;     // 128x128, 4 waves, 2 stages, 2 WG/CU
-    case 1: rc = launch_cfg<Cfg<2, 2, 2, 2, 3>>(s, a, splits); break;     // 128x128, 4 waves, 3 stages
-    case 2: rc = launch_cfg<Cfg<4, 2, 2, 2, 2>>(s, a, splits); break;     // 256x128, 8 waves, 2 stages
-    case 3: rc = launch_cfg<Cfg<4, 2, 2, 2, 3>>(s, a, splits); break;     // 256x128, 8 waves, 3 stages
-    case 4: rc = launch_cfg<Cfg<2, 4, 4, 2, 2>>(s, a, splits); break;     // 256x256, 8 waves (128x64 each), 2 stages
-    case 5: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16>>(s, a, splits); break; // 128x128, 4 waves, 4 x 16-element stages, 2 WG/CU
-    case 6: rc = launch_cfg<Cfg<2, 2, 2, 2, 3, 16>>(s, a, splits); break; // 128x128, 3 x 16-element stages
-    case 7: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16>>(s, a, splits); break; // 256x256, 8 waves, 4 x 16-element stages (128 KiB)
-    case 8: rc = launch_cfg<Cfg<2, 4, 4, 2, 3, 16>>(s, a, splits); break; // 256x256, 8 waves, 3 x 16-element stages
-    case 9: rc = launch_cfg<Cfg<4, 2, 2, 2, 4, 16>>(s, a, splits); break; // 256x128, 8 waves, 4 x 16-element stages (96 KiB)
-    case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break; // cfg 0 with buffer-descriptor DMA
-    case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break; // cfg 10 with buffer-descriptor DMA
-    case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break; // cfg 4 with buffer-descriptor DMA
-    case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break; // cfg 13 with buffer-descriptor DMA
-    case 24: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16, 1, 1>>(s, a, splits); break; // cfg 11 with buffer-descriptor DMA
-    case 10: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1>>(s, a, splits); break; // 128x128 register-pipelined, 2 x 32
-    case 11: rc = launch_cfg<Cfg<2, 2, 2, 2, 4, 16, 1>>(s, a, splits); break; // 128x128 register-pipelined, 4 x 16
-    case 12: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 1>>(s, a, splits); break; // 256x256 register-pipelined, 2 x 32
-    case 13: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1>>(s, a, splits); break; // 256x256 register-pipelined, 4 x 16
-    case 14: rc = launch_cfg<Cfg<2, 2, 2, 2, 3, 16, 1>>(s, a, splits); break; // 128x128 register-pipelined, 3 x 16
+    // flat-address LDS-DMA (operands of any size)
+    case 0: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 0>>(s, a, splits); break;    // 128x128, 4 waves, 2 x 32-element stages, 2 WG/CU
+    case 4: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 0>>(s, a, splits); break;    // 256x256, 8 waves of 128x64, 2 x 32
+    case 10: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 0>>(s, a, splits); break;   // 128x128, register-pipelined fragments
+    case 13: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 0>>(s, a, splits); break;   // 256x256, register-pipelined, 4 x 16-element ring
+    // buffer-descriptor LDS-DMA (operands < 2 GiB): what plan_nt_s16 picks
+    case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break;
+    case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break;
+    case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break;   // measured alternatives
+    case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break;
     default:
       set_error("nt_s16: unknown tile configuration %d", cfg);
       return VP3D_E_INVALID;
