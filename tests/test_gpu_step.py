@@ -417,3 +417,33 @@ def test_graphed_train_step_equals_eager_steps(p_drop):
     step(x, tgt)
     assert len(step._cache) == 2
     assert torch.allclose(m_e.expand_bn.running_var, m_g.expand_bn.running_var, rtol=1e-6, atol=1e-7)
+
+
+def test_batched_sequence_evaluation_equals_one_by_one():
+    """generators.predict_sequences (several ragged-length videos per forward call, TTA pair folded) against the reference
+    evaluation loop: one sequence + its mirrored copy per call (run.py:652-680)."""
+    import videopose3d_amd as V
+    from videopose3d_amd import generators as G
+    rng = np.random.RandomState(3)
+    lens = [40, 133, 61, 300, 29, 135, 300, 77]
+    p2 = [rng.standard_normal((n, 17, 2)).astype(np.float32) * 0.5 for n in lens]
+    kl, kr = [1, 3, 5, 7, 9, 11, 13, 15], [2, 4, 6, 8, 10, 12, 14, 16]
+    jl, jr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    torch.manual_seed(1)
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128).to(DEV).eval()
+    pad = (m.receptive_field() - 1) // 2
+    gen = G.UnchunkedGenerator(None, None, p2, pad=pad, augment=True, kps_left=kl, kps_right=kr, joints_left=jl,
+                               joints_right=jr, device=DEV)
+    groups = gen.length_groups(max_frames=700)
+    assert sorted(i for g_ in groups for i in g_) == list(range(len(lens))) and len(groups) > 2
+    got = G.predict_sequences(m, gen, max_frames=700)
+    with torch.no_grad():
+        for s_id, (_, _, b2) in enumerate(gen.next_epoch()):
+            ref = G.tta_average(m(b2), jl, jr)[0]
+            assert got[s_id].shape == ref.shape == (lens[s_id], 17, 3)
+            assert float((got[s_id] - ref).abs().max()) < 2e-5, s_id
+    gen.set_augment(False)
+    got = G.predict_sequences(m, gen, max_frames=10 ** 6)              # everything in one call
+    with torch.no_grad():
+        for s_id, (_, _, b2) in enumerate(gen.next_epoch()):
+            assert float((got[s_id] - m(b2)[0]).abs().max()) < 2e-5, s_id

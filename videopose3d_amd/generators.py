@@ -269,6 +269,62 @@ class UnchunkedGenerator:
                                    self._perm2 if self.augment else None, self._perm3 if self.augment else None)
 
 
+    # ---- many sequences per call (not in the reference) ------------------------------------
+    def length_groups(self, max_frames: int = 32768):
+        """Sequence indices grouped by similar length so that (sequences x longest length) stays <= max_frames per group
+        (a sequence longer than that forms its own group)."""
+        order = sorted(range(len(self.poses_2d)), key=lambda i: self._res.lens[i])
+        groups, cur = [], []
+        for i in order:
+            if cur and (len(cur) + 1) * self._res.lens[i] > max_frames:
+                groups.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
+            groups.append(cur)
+        return groups
+
+    def next_epoch_batched(self, max_frames: int = 32768):
+        """Like next_epoch(), but several sequences per batch: yields (seq_ids, lengths, cam, batch_3d, batch_2d) where
+        batch_2d is [n, T_max + 2*pad, J, F] with rows ordered [all sequences of the group..., then their mirrored copies
+        when augmentation is on].  Shorter sequences are extended by edge replication (exactly the padding rule of
+        generators.py:216-239 continued to T_max): the model is convolutional along time, so the first len(s) output
+        frames of row s are what a call on that sequence alone produces."""
+        aug = self.augment
+        for grp in self.length_groups(max_frames):
+            k = len(grp)
+            n = 2 * k if aug else k
+            tab = np.zeros((n, 3), dtype=np.int32)
+            tab[:k, 0] = grp
+            if aug:
+                tab[k:, 0] = grp
+                tab[k:, 2] = 1
+            lens = [self._res.lens[i] for i in grp]
+            cam, b3, b2 = self._res.gather(torch.from_numpy(tab).to(self._res.device), n, max(lens), self.pad,
+                                           self.causal_shift, self._perm2 if aug else None, self._perm3 if aug else None)
+            yield grp, lens, cam, b3, b2
+
+
+def predict_sequences(model, generator: "UnchunkedGenerator", max_frames: int = 32768):
+    """Predictions of ``model`` (eval mode) for every sequence of an UnchunkedGenerator, many sequences per forward call:
+    the evaluation loop of run.py:652-680 (forward, un-flip + average of the test-time-augmentation pair) with one
+    launch set per length group instead of one per video.  Returns a list of [T_i, J_out, 3] tensors in sequence order."""
+    out = [None] * len(generator.poses_2d)
+    traj = model.num_joints_out == 1                       # run.py:676: the trajectory model has no joints to swap
+    with torch.no_grad():
+        for grp, lens, _, _, b2 in generator.next_epoch_batched(max_frames):
+            pred = model(b2)                                # [n, T_max (- causal trim), J_out, 3]
+            k = len(grp)
+            if generator.augment_enabled():
+                t = pred.shape[1]
+                pair = pred.reshape(2, k * t, pred.shape[2], pred.shape[3])     # rows [originals | mirrored]
+                pred = tta_average(pair, None if traj else generator.joints_left,
+                                   None if traj else generator.joints_right).reshape(k, t, pred.shape[2], pred.shape[3])
+            for j, s_id in enumerate(grp):
+                out[s_id] = pred[j, :lens[j]].clone()
+    return out
+
+
 def tta_average(predicted: torch.Tensor, joints_left=None, joints_right=None) -> torch.Tensor:
     """run.py:677-680: ``predicted`` [2,T,J,3] holds the prediction for a sequence and for its mirrored copy; undo
     the mirroring of copy 1 (negate x, swap left/right joints unless both lists are None, as for the trajectory
