@@ -124,3 +124,41 @@ def test_split_heuristics_bounds():
     assert h.vp3d_rows_gemm_splits(65536, 1024, 3072) == 1
     assert h.vp3d_rows_gemm_ws_floats(1024, 1024, 3072) == h.vp3d_rows_gemm_splits(1024, 1024, 3072) * 64 * 128 * 128
     assert h.vp3d_rows_gemm_splits(1024, 1024, 3072) > 1                # the T_out = 1 tail is
+
+
+def test_forward_flops_match_the_survey_figures():
+    """plan.forward_flops (the size measure that decides between the two GEMM engines) against SURVEY.md 8(d):
+    5,217,830,912 FLOP per sample for the cfg2 eval forward, 352,569,344 for the cfg3 training forward."""
+    from videopose3d_amd.plan import make_plan
+    dil = make_plan("dilated", 34, 1024, 51, [3, 3, 3, 3, 3])
+    stri = make_plan("strided", 34, 1024, 51, [3, 3, 3, 3, 3])
+    assert dil.forward_flops(1, 243) == 5217830912
+    assert stri.forward_flops(1, 243) == 352569344
+    assert stri.forward_flops(1024, 243) == 1024 * 352569344
+
+
+def test_engine_selection_by_arithmetic_and_size():
+    """engine.use_s16: the split-fp16 engine needs math == "f16x3", a supported configuration and a call big enough to be
+    compute-bound; everything else runs on the fp32-MFMA kernels."""
+    import videopose3d_amd as V
+    from videopose3d_amd import engine
+    big = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
+    assert big.math == V.default_math()
+    big.math = "f16x3"
+    assert engine.use_s16(big, 243, True, batch=1024)
+    assert not engine.use_s16(big, 243, True, batch=64)                   # launch-latency regime
+    assert not engine.use_s16(big, 243, True, need_dx=True, batch=1024)   # input gradients: fp32 engine
+    assert not engine.use_s16(big, 244, True, batch=1024)                 # windows that do not tile
+    big.math = "f32"
+    assert not engine.use_s16(big, 243, True, batch=1024)
+    ev = V.TemporalModel(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
+    ev.math = "f16x3"
+    assert engine.use_s16(ev, 243, False, batch=1024) and not engine.use_s16(ev, 300, False, batch=2)
+    assert not engine.use_s16(ev, 243, True, batch=1024)                  # training of the dilated class
+    odd = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=48)
+    odd.math = "f16x3"
+    assert not engine.use_s16(odd, 100, False, batch=4096)                # channels % 64 != 0
+    with pytest.raises(V.Vp3dError):
+        V.set_default_math("bf16")
+        V.default_math()
+    V.set_default_math(None)
