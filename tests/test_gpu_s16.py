@@ -260,3 +260,40 @@ def test_s16_output_and_s16_residual_chain(cfg):
     y32b = S.conv_nt(xs, ws_, spec, bias=bias, relu=True, residual=(S.join(r16), rs), cfg=cfg)
     assert float((y32 - y32b).abs().max()) < 1e-5
     assert float((y32.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
+def test_model_level_parity_is_scale_invariant(scale):
+    """Inputs far outside fp16's comfortable range: the device-side bounds keep the split-fp16 engine on the fp32 engine's
+    results (BatchNorm renormalises, so the outputs are comparable across scales)."""
+    import copy
+    torch.manual_seed(2)
+    fw = [3, 3, 3]
+    m32 = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=128).to(DEV).train()
+    m32.math = "f32"
+    with torch.no_grad():
+        m32.expand_conv.weight.mul_(37.0)              # and weights whose magnitudes differ by orders between layers
+        m32.layers_conv[1].weight.mul_(1e-3)
+    m16 = copy.deepcopy(m32)
+    m16.math = "f16x3"
+    x = (torch.randn(16, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1) * scale
+    tgt = torch.randn(16, 1, 17, 3, device=DEV) * 0.3
+    outs = []
+    for m in (m32, m16):
+        yv = m(x)
+        torch.mean(torch.norm(yv - tgt, dim=3)).backward()
+        outs.append(yv.detach())
+    assert torch.isfinite(outs[1]).all()
+    assert float(torch.mean(torch.norm(outs[0] - outs[1], dim=3))) < 2e-5
+    for (k, a), (_, q) in zip(m16.named_parameters(), m32.named_parameters()):
+        assert torch.isfinite(a.grad).all(), k
+        assert float((a.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)) < 2e-4, k
+    ev32 = V.TemporalModel(17, 2, 17, fw, channels=128).to(DEV).eval()
+    ev32.load_state_dict(m32.state_dict())
+    ev32.math = "f32"
+    ev16 = copy.deepcopy(ev32)
+    ev16.math = "f16x3"
+    with torch.no_grad():
+        xe = (torch.randn(3, 60, 17, 2, device=DEV) * 0.5).clamp(-1, 1) * scale
+        a, q = ev16(xe), ev32(xe)
+    assert float((a - q).abs().max() / (q.abs().max() + 1e-30)) < 1e-5
