@@ -18,6 +18,7 @@ Extra fields in the same JSON line:
   roofline      : dominant GEMM kernel family of the step, algorithmic FLOPs / HIP-event launch durations
   cpu_baseline  : the reference's CPU path (ATen/oneDNN through oracle/torch_cpu_path.py, kind "port") on this
                   host's cores, bounded sample of the same workload; mpjpe_vs_ref = HIP vs that path on the sample
+  rocm_reference_baseline : the same reference path executed by PyTorch-ROCm (MIOpen) on this GPU, B=1024 (N=1 only)
 Rank 0 prints ONE JSON line on stdout.
 """
 import argparse
@@ -177,6 +178,43 @@ def cpu_baseline(dev, budget_s=4.0):
                       sample_b=bsz, tolerance=1e-3)
 
 
+def rocm_reference_baseline(dev, x, tgt):
+    """Second baseline ("optional second comparator"): the reference's own execution path -- the
+    torch.nn.functional conv1d / batch_norm / relu / dropout + autograd wiring of oracle/torch_cpu_path.py, i.e. what
+    run.py executes with the reference classes -- run by PyTorch-ROCm (MIOpen / rocBLAS) on THIS GPU, same shapes, same
+    batch.  This is "the reference on MI355X"; like cpu_baseline it is a baseline leg, never the product path."""
+    from oracle import torch_cpu_path as T
+    from videopose3d_amd import TemporalModelOptimized1f
+    torch.manual_seed(0)
+    m = TemporalModelOptimized1f(17, 2, 17, FW, dropout=0.25, channels=C)
+    sd = {k: v.detach().to(dev) for k, v in m.state_dict().items()}
+    t0 = time.perf_counter()
+    for _ in range(2):                                                   # MIOpen's kernel search happens here
+        T.train_step(sd, x, tgt, FW, kind="strided", dropout=0.25)
+    torch.cuda.synchronize()
+    t_find = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        T.train_step(sd, x, tgt, FW, kind="strided", dropout=0.25)
+    torch.cuda.synchronize()
+    ms_train = (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        for _ in range(2):
+            T.forward(sd, x, FW, kind="dilated", training=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            T.forward(sd, x, FW, kind="dilated", training=False)
+        torch.cuda.synchronize()
+        ms_eval = (time.perf_counter() - t0) / 3 * 1e3
+    return {"what": "the reference's module stack (F.conv1d / F.batch_norm / relu / dropout + autograd, oracle/torch_cpu_path.py) "
+                    "executed by PyTorch-ROCm (MIOpen / rocBLAS, fp32) on this GPU: cfg3 train step and cfg2 eval forward, B=1024",
+            "value": B / ms_train * 1e3, "unit": "frames/s", "train_ms_per_step": ms_train, "cfg2_eval_ms": ms_eval,
+            "cfg2_eval_frames_per_s": B / ms_eval * 1e3, "torch": torch.__version__,
+            "first_two_steps_s": t_find}
+
+
 def instrumented(step, ops, n_prof, math):
     """Per-kernel-family roofline, measured live with HIP events on the launch stream around every C-ABI GEMM call."""
     recs = []
@@ -235,6 +273,7 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the cfg2 eval-forward section")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 MFMA comparison sections")
     ap.add_argument("--math", default=None, help="arithmetic of the headline: f16x3 (default) or f32")
+    ap.add_argument("--no-rocm-ref", action="store_true", help="skip the PyTorch-ROCm (MIOpen) reference-path baseline (~75 s)")
     args = ap.parse_args()
 
     import videopose3d_amd as V
@@ -407,6 +446,15 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["mpjpe_vs_ref"] = cpu_baseline(dev)
+    if rank == 0 and world == 1 and not args.no_rocm_ref:
+        try:
+            ref = rocm_reference_baseline(dev, x, tgt)
+            out["rocm_reference_baseline"] = ref
+            out["speedup_vs_rocm_reference"] = value / ref["value"]
+            if "cfg2_eval_fwd" in out:
+                out["cfg2_eval_fwd"]["speedup_vs_rocm_reference"] = ref["cfg2_eval_ms"] / out["cfg2_eval_fwd"]["ms"]
+        except Exception as ex:  # noqa: BLE001  (a missing MIOpen kernel database must not cost the run its result)
+            out["rocm_reference_baseline"] = {"error": repr(ex)}
 
     if world > 1:
         dist.barrier()

@@ -14,16 +14,16 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # (a) the training step alone: every launch of a GEMM kernel in this command has one of the step's 10 shapes, so the
 #     per-kernel average duration is directly comparable with bench.py's `kernels.*.avg_launch_ms`
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval --no-f32 ${MATH:+--math $MATH}"
+BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-eval --no-f32 ${MATH:+--math $MATH}"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o kt -- $BENCH > "$OUT/kt.log" 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH"; python "$R/tools/prof_summary.py" "$OUT/kt_results.db" 40; } \
     > "$OUT/${TAG}_bench_train_kernel_trace_stats.txt" 2>&1
 # (b) the full default command (adds the cfg2 eval-forward section: the 11 ms k_rows_gemm<true,true> launches)
-FULL="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 ${MATH:+--math $MATH}"
+FULL="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-f32 ${MATH:+--math $MATH}"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o ktfull -- $FULL > "$OUT/ktfull.log" 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- $FULL"; python "$R/tools/prof_summary.py" "$OUT/ktfull_results.db" 40; } \
     > "$OUT/${TAG}_bench_full_kernel_trace_stats.txt" 2>&1
-SHORT="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eval --no-f32 ${MATH:+--math $MATH}"
+SHORT="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rocm-ref --no-eval --no-f32 ${MATH:+--math $MATH}"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o fetch -- $SHORT > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o write -- $SHORT > "$OUT/write.log" 2>&1
 python "$R/tools/pmc_traffic.py" "$OUT/fetch_results.db" "$OUT/write_results.db" "$OUT/${TAG}_pmc_traffic.json" \
