@@ -165,7 +165,8 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
  *                       consumer that re-splits it; zero its 32 slots before the launch)
  *   cfg               : tile configuration, -1: planned (vp3d_nt_s16_plan).  20 / 22: 128x128 tiles of 4 waves / 256x256
  *                       tiles of 8 waves with buffer-descriptor LDS-DMA (operands < 2 GiB, else their flat-address forms
- *                       0 / 4 are used); 10, 13, 21, 23: register-pipelined variants kept for measurements
+ *                       0 / 4 are used); 30: 22 on the rows that fill whole rounds of 256 tiles + 20 on the rest (two
+ *                       launches, no split-K); 10, 13, 21, 23: register-pipelined variants kept for measurements
  *   splits            : K slices (1 = none, 0 = planned: vp3d_nt_s16_plan); > 1 needs ws of splits*M*N floats.
  *                       The slices write raw scaled partial matrices [splits][M][N]; a finishing pass sums them and
  *                       applies the epilogue -- unless raw_partials, where the partials ARE the result (wgrad:

@@ -42,6 +42,8 @@ CASES = [  # (B, T, spec, cfg, splits)
     (5, 27, ConvSpec(160, 96, 3, 1, 3), 21, 1),         # register-pipelined fragments, ragged N
     (3, 31, ConvSpec(64, 200, 1), 0, 2),                # ragged M = 93, N = 200
     (7, 40, ConvSpec(128, 128, 3, 9, 1), -1, 0),        # planned
+    (300, 27, ConvSpec(64, 300, 3, 1, 3), 30, 1),       # hybrid: 256x256 tiles on whole rounds + 128x128 on the rest (M = 2700)
+    (1200, 81, ConvSpec(64, 512, 3, 1, 3), 30, 1),      # hybrid with a real split (M = 32400: 254 tiles + tail rows)
     (2, 300, ConvSpec(64, 64, 5, 1, 1), 0, 1),          # 5 adjacent taps ("dense"-style)
 ]
 

@@ -183,10 +183,10 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const int bid = blockIdx.x - split * p.pos_full;
   int tile_m, tile_n;
   if (!tile_of(bid, p.m_tiles, p.n_tiles, tile_m, tile_n)) return;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;      // this launch covers rows [m_begin, m_end)
 
   for (int r = tid; r < BM; r += C::NT) {
-    const int m = min(m0 + r, p.M - 1);
+    const int m = min(m0 + r, p.m_end - 1);
     const int b = m / p.t_dst;
     tab_b[r] = b;
     tab_t[r] = m - b * p.t_dst;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
 #pragma unroll
       for (int sb = 0; sb < RB / 2; ++sb) {
         const int row0 = m0 + (wm * RB + sb * 2) * 32;
-        const int cnt = min(64, p.M - row0);         // wave-uniform
+        const int cnt = min(64, p.m_end - row0);     // wave-uniform
         if (cnt > 0) {
 #pragma unroll
           for (int j = 0; j < CB; ++j) {
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       for (int ps = 0; ps < 32 / ERPP8; ++ps) {
         const int r = ps * ERPP8 + rr8;
         const int lr = (wm * RB + i) * 32 + r;
-        if (m0 + lr >= p.M || n8 >= Nlim) continue;
+        if (m0 + lr >= p.m_end || n8 >= Nlim) continue;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     for (int ps = 0; ps < 32 / ERPP; ++ps) {
       const int r = ps * ERPP + rr;
       const int lr = (wm * RB + i) * 32 + r;         // row inside the tile
-      if (m0 + lr >= p.M || n >= Nlim) continue;
+      if (m0 + lr >= p.m_end || n >= Nlim) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
       if (partial) {
         float* prow = Cbase + (int64_t)(m0 + lr) * p.N + n;
@@ -728,8 +728,10 @@ __global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict
 }
 
 template <class C>
-int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
-  a.m_tiles = (a.M + C::BM - 1) / C::BM;
+int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m_end = -1) {
+  a.m_begin = m_begin;
+  a.m_end = m_end < 0 ? a.M : m_end;
+  a.m_tiles = (a.m_end - a.m_begin + C::BM - 1) / C::BM;
   a.n_tiles = (a.N + C::BN - 1) / C::BN;
   const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
   const int m_groups = (a.m_tiles + 7) / 8, n_groups = (a.n_tiles + gn - 1) / gn;
@@ -750,6 +752,15 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits) {
 // 128x128 tile takes ~0.74 us of a CU when two workgroups share it (0.85 us alone), a 256x256 tile ~2.55 us (2.1 us
 // when fewer than 256 are in flight); the finishing pass of a split forward/dgrad launch streams the partial
 // matrices (mostly Infinity-Cache resident) once each way, a raw (wgrad) launch leaves that to vp3d_wgrad_reduce.
+// rows [0, m_split) = the largest whole number of m-tiles whose 256x256 tiles fit in whole rounds of 256 (0: no such split)
+static int hybrid_split_rows(int M, int N) {
+  const int n256 = (N + 255) / 256;
+  const int64_t tiles = (int64_t)((M + 255) / 256) * n256;
+  const int64_t full_rounds = tiles / 256;
+  if (full_rounds < 1 || tiles % 256 == 0) return 0;
+  return (int)((full_rounds * 256 / n256) * 256);
+}
+
 void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out) {
   const int nkt = K / 32;
   double best = 1e30;
@@ -770,6 +781,21 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
         best_cfg = cfg == 0 ? 20 : 22;              // buffer-descriptor DMA variants (the launcher falls back for >= 2 GiB operands)
         best_s = s;
       }
+    }
+  }
+  // Hybrid 30: the 256x256 configuration on whole rounds of 256 tiles and the 128x128 one on the rows of the fractional
+  // last round (4x finer tiles on 2x the slots instead of 256 - f idle CUs for a whole tile time).
+  if (best_cfg == 22 && best_s == 1) {
+    const int m_split = hybrid_split_rows(M, N);
+    if (m_split > 0 && m_split < M) {
+      const int n256 = (N + 255) / 256, n128 = (N + 127) / 128;
+      const double nk = (double)nkt;
+      const int64_t tiles = (int64_t)((M + 255) / 256) * n256;
+      const double single = (double)((tiles + 255) / 256) * (nk * 2.55 + 5.0);
+      const int64_t ta = (int64_t)(m_split / 256) * n256, tb = (int64_t)((M - m_split + 127) / 128) * n128;
+      const int64_t pcb = (tb + 255) / 256;
+      const double hybrid = (double)((ta + 255) / 256) * (nk * 2.55 + 5.0) + 5.0 + (double)pcb * (nk * (pcb >= 2 ? 0.74 : 0.85) + 2.0);
+      if (hybrid < single * 0.97) best_cfg = 30;
     }
   }
   *cfg_out = best_cfg;
@@ -810,6 +836,19 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   if (cfg >= 20 && cfg <= 23 && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31))) {
     static const int flat_of[4] = {0, 10, 4, 13};
     cfg = flat_of[cfg - 20];
+  }
+  if (cfg == 30) {                               // hybrid (see plan_nt_s16): two launches over disjoint row ranges
+    const int m_split = hybrid_split_rows(a.M, a.N);
+    const bool flat = a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31);
+    if (m_split <= 0 || m_split >= a.M || splits != 1) {
+      cfg = flat ? 4 : 22;
+    } else {
+      int r1 = flat ? launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 0>>(s, a, 1, 0, m_split)
+                    : launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, 1, 0, m_split);
+      if (r1 != VP3D_OK) return r1;
+      return flat ? launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 0>>(s, a, 1, m_split, a.M)
+                  : launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, 1, m_split, a.M);
+    }
   }
   int rc;
   switch (cfg) {

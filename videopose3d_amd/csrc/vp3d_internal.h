@@ -82,6 +82,7 @@ struct RowsGemmArgs {
   float* part;
   int64_t part_floats;
   uint32_t a_bytes, b_bytes;   // S16 kernel, buffer-descriptor DMA: byte extents of the two operands (set by the launcher)
+  int32_t m_begin, m_end;      // S16 kernel: the rows this launch covers (set by the launcher; [0, M) normally)
   Epi epi;
 };
 
