@@ -4,12 +4,15 @@
 // (22+ significant operand bits, exact fp16 products) at 3/16 of the fp32-MFMA matrix-pipe time.
 //
 // Because an S16 row has the byte geometry of the fp32 row it replaces, the staging is the fp32 kernel's: K in
-// 32-element (128-B) tiles, DMA'd HBM/L2 -> LDS with global_load_lds (16 B per lane) into an NSTAGE ring of
+// 32-element (128-B) tiles (or 16-element / 64-B ones), DMA'd HBM/L2 -> LDS 16 B per lane into an NSTAGE ring of
 // [rows][128 B] images whose 16-B chunks are XOR-swizzled by ((row>>1)&7) on the SOURCE address; chunk 2g / 2g+1
 // of a row = hi / lo halves of elements 8g..8g+7 = one MFMA A/B fragment each (ds_read_b128, conflict-free).
 // Per 32-element K-tile a wave with an (RB x CB)-block sub-tile issues 4(RB+CB) fragment reads and 6*RB*CB
-// MFMAs of 32 matrix-pipe cycles: the kernel needs ~5x the operand bandwidth of the fp32 one per unit time, hence
-// the larger workgroup tiles (template) and the 3-stage ring with counted vmcnt.
+// MFMAs of 32 matrix-pipe cycles: the MFMA time of a K-tile is ~5x shorter than the fp32 kernel's while the bytes per
+// tile are the same, so the kernel lives or dies by operand traffic per FLOP (hence the 256x256 configuration) and by
+// the cost of issuing the LDS-DMA (hence the buffer-descriptor form: one 32-bit offset per 1-KiB piece).  What was
+// measured on the way (ring depth, K-tile width, register-pipelined fragments, other tile shapes) is in DESIGN.md 4.6;
+// the template keeps those knobs.
 //
 // All GEMM forms of the model are expressed as NT: forward (B = packed weight rows), dgrad (B = the transposed
 // pack [(tap,ci)][co]), wgrad (both operands pre-transposed by their producers).
