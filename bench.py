@@ -215,6 +215,56 @@ def rocm_reference_baseline(dev, x, tgt):
             "first_two_steps_s": t_find}
 
 
+def semi_supervised_step_latency(dev):
+    """BASELINE.json configs[4]: run.py's semi-supervised step (run.py:322-394) -- pose + trajectory models (arc 3,3,3,
+    C=1024), 64 labelled + 64 unlabelled 27-frame windows, mpjpe + weighted trajectory loss + back-projection through
+    project_to_2d (HIP) + bone-length term -- forward + backward of both models, step latency.  Launch-latency-bound at this
+    size, so the models stay on the fp32 kernels (engine.use_s16's size threshold)."""
+    from videopose3d_amd import TemporalModelOptimized1f
+    from videopose3d_amd import loss as vloss
+    from videopose3d_amd.camera import project_to_2d
+    fw, bsz = [3, 3, 3], 64
+    torch.manual_seed(0)
+    pos = TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.25, channels=C).to(dev).train()
+    traj = TemporalModelOptimized1f(17, 2, 1, fw, dropout=0.25, channels=C).to(dev).train()
+    gen = torch.Generator().manual_seed(5)
+    x_l = (torch.randn(bsz, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(dev)
+    x_u = (torch.randn(bsz, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(dev)
+    y3 = (torch.randn(bsz, 1, 17, 3, generator=gen) * 0.3).to(dev)
+    y3[:, :, 0, 2] = y3[:, :, 0, 2].abs() + 3.0                                  # a trajectory in front of the camera
+    cam = torch.tensor([1.15, 1.15, 0.0, 0.0, -0.2, 0.25, 0.0, 0.0, 0.0]).repeat(bsz, 1).to(dev)
+    parents = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]
+    y_traj = y3[:, :, :1].clone()
+    y_pos = y3.clone()
+    y_pos[:, :, 0] = 0
+    cat = torch.cat((x_l, x_u), dim=0)
+    target = x_u[:, 13:-13, :, :2].contiguous()
+
+    def step():
+        pos.zero_grad(set_to_none=True)
+        traj.zero_grad(set_to_none=True)
+        p_cat, t_cat = pos(cat), traj(cat)
+        loss = vloss.mpjpe(p_cat[:bsz], y_pos) + vloss.weighted_mpjpe(t_cat[:bsz], y_traj, 1 / y_traj[:, :, :, 2])
+        recon = project_to_2d(p_cat[bsz:] + t_cat[bsz:], cam)
+        loss = loss + vloss.mpjpe(recon, target)
+        dists = p_cat[:, :, 1:] - p_cat[:, :, parents[1:]]
+        bone = torch.mean(torch.norm(dists, dim=3), dim=1)
+        loss = loss + torch.mean(torch.abs(torch.mean(bone[:bsz], dim=0) - torch.mean(bone[bsz:], dim=0)))
+        loss.backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {"workload": "cfg5: semi-supervised step, arc 3,3,3 C=1024, pose + trajectory models, 64 labelled + 64 unlabelled "
+                        "windows, mpjpe + weighted mpjpe + project_to_2d back-projection + bone-length loss, fwd + bwd",
+            "ms_per_step": ms, "math": "f32 kernels (below the split-fp16 engine's size threshold)"}
+
+
 def instrumented(step, ops, n_prof, math):
     """Per-kernel-family roofline, measured live with HIP events on the launch stream around every C-ABI GEMM call."""
     recs = []
@@ -444,6 +494,8 @@ def main():
         del y_a
         torch.cuda.empty_cache()
 
+    if rank == 0 and world == 1:
+        out["cfg5_semi_supervised_step"] = semi_supervised_step_latency(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["mpjpe_vs_ref"] = cpu_baseline(dev)
     if rank == 0 and world == 1 and not args.no_rocm_ref:
