@@ -116,6 +116,9 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
     seed, offset = mod._next_dropout_state() if p > 0 else (0, 0)
     mod._stats_epoch += 1            # running statistics are about to change (written by raw pointer)
     saved = []
+    sync = mod.__dict__.get("_vp3d_sync_bn")         # dp.SyncBatchNorm: statistics over the global batch
+    if sync is not None:
+        sync.begin_step(x3.shape[0], x3.device)
 
     def layer(idx, h, residual=None):
         spec = plan.convs[idx]
@@ -127,7 +130,7 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
         m_rows = b * spec.t_out(h.shape[1])
         stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
         y = ops.conv_fwd(h, wt, spec, stats=stats)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         a = ops.bn_act_fwd(y, coef, drop, residual)
         if save:
@@ -197,6 +200,9 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # epilogue time of the compute-bound GEMM (+0.21 ms everywhere, +0.10 / -0.11 ms in auto mode): 10.19 / 10.17 vs
     # 10.18 ms -- no gain, so the separate kernels stay the default.
     fuse_mode = os.environ.get("VP3D_FUSE_ACT_BWD", "0")
+    sync = mod.__dict__.get("_vp3d_sync_bn")
+    if sync is not None:
+        fuse_mode = "0"                              # the fused epilogue reduces with per-replica statistics
 
     def upstream(idx):
         return (L[idx].y, L[idx].coef, L[idx].drop)
@@ -239,7 +245,7 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
         if fused is not None:
             dy, dgam, dbet = ops.bn_act_bwd_fused(fused, s.y, s.coef, out_dgamma=o_g, out_dbeta=o_bt)
         else:
-            dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt)
+            dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt, sync=sync)
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
 

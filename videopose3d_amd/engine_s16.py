@@ -124,6 +124,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     bounds = S.new_bounds(2 * n_layers + 1, dev)   # [0,n): activations, [n,2n): weights, 2n: input
     saved: List[_Saved] = []
     b = x3.shape[0]
+    sync = mod.__dict__.get("_vp3d_sync_bn")         # dp.SyncBatchNorm: statistics (and their bounds) over the global batch
+    if sync is not None:
+        sync.begin_step(b, dev)
 
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
     xin, spec0, kpad = engine._expand_input(plan, x3)
@@ -147,7 +150,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     t_len = plan.lengths(t_in0)
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
-    S.act_bounds_multi(bns, m_all, res_from, p, bounds)
+    S.act_bounds_multi(bns, m_all if sync is None else [sync.rows_total(m_) for m_ in m_all], res_from, p, bounds)
 
     h_prev = None          # S16 block input (residual source)
     a = x_rows
@@ -160,7 +163,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         assert m_rows == m_all[idx]
         stats = ops.stat_buffers(m_rows, spec.c_out, dev)
         y = S.conv_nt(a, wf, spec, stats=stats)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:
@@ -233,7 +236,8 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         if o_g is None or o_bt is None:
             o_g = o_bt = None
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
-                                            out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0)   # expand: no dgrad
+                                            out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0,   # expand: no dgrad
+                                            sync=mod.__dict__.get("_vp3d_sync_bn"))
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
         return dy, dy_t

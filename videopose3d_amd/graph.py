@@ -73,6 +73,8 @@ class GraphedTrainStep:
         m = self.model
         if not m.training:
             raise Vp3dError("GraphedTrainStep: call model.train() first")
+        if m.__dict__.get("_vp3d_sync_bn") is not None:
+            raise Vp3dError("GraphedTrainStep: synchronised BatchNorm puts collectives inside the step; not captured")
         if m._drop_counter is None:
             m._drop_counter = torch.zeros(1, dtype=torch.int64, device=x.device)
         e = _Entry()

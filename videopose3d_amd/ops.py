@@ -384,8 +384,39 @@ def bn_fold(bn: torch.nn.BatchNorm1d) -> Tuple[torch.Tensor, torch.Tensor]:
     return buf[0], buf[1]
 
 
-def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats) -> torch.Tensor:
-    """Returns a [4, C] tensor: scale, shift, mean, invstd.  Updates the running buffers in place."""
+def _bn_finalize_sync(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync) -> torch.Tensor:
+    """Synchronised statistics (dp.SyncBatchNorm): local finalize without the running update, fp64 merge of the per-rank
+    (mean, var) over the process group, then scale / shift / running buffers from the GLOBAL statistics."""
+    c = bn.num_features
+    buf = torch.empty((4, c), dtype=torch.float32, device=bn.weight.device)
+    check(_lib.lib().vp3d_bn_finalize(
+        _stream(), c, m_rows, stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+        float(bn.eps), 0.0, None, None, None, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()),
+        "vp3d_bn_finalize")
+    eps = float(bn.eps)
+    var_l = (1.0 / buf[3].double() ** 2 - eps).clamp_min(0.0)
+    mean_g, var_g, n_tot = sync.merge_stats(buf[2], var_l, m_rows)
+    invstd = torch.rsqrt(var_g + eps)
+    scale = bn.weight.detach().double() * invstd
+    buf[0] = scale.float()
+    buf[1] = (bn.bias.detach().double() - mean_g * scale).float()
+    buf[2] = mean_g.float()
+    buf[3] = invstd.float()
+    if bn.track_running_stats and bn.running_mean is not None:
+        mom = float(bn.momentum) if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked.item()) + 1)
+        with torch.no_grad():
+            bn.running_mean.mul_(1.0 - mom).add_((mom * mean_g).float())
+            bn.running_var.mul_(1.0 - mom).add_((mom * var_g * (n_tot / (n_tot - 1.0).clamp_min(1.0))).float())
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    return buf
+
+
+def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None) -> torch.Tensor:
+    """Returns a [4, C] tensor: scale, shift, mean, invstd.  Updates the running buffers in place.
+    sync: a dp.SyncBatchNorm -> statistics over the global batch."""
+    if sync is not None:
+        return _bn_finalize_sync(bn, m_rows, stats, sync)
     c = bn.num_features
     if m_rows <= 1:
         # same failure as torch.nn.functional.batch_norm in training mode
@@ -422,8 +453,16 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
     return out
 
 
+def _sync_sums(dgam, dbet, sync):
+    """Global (sum g*xhat, sum g) scaled by local/global rows, so that the apply kernels' 1/M_local becomes 1/M_global."""
+    g = torch.stack([dgam, dbet])
+    sync.sum_(g)
+    g.mul_(sync.frac)
+    return g[0], g[1]
+
+
 def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
-               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
+               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None, sync=None):
     """Returns (dy, dgamma, dbeta) for a = dropout(relu(bn(y))); dgamma / dbeta are written into the given
     contiguous fp32 [C] tensors when provided (gradient sink)."""
     _chk(go, "go")
@@ -449,9 +488,10 @@ def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Opti
         dgam, dbet = dgb[0], dgb[1]
     check(L.vp3d_bn_bwd_finalize(_stream(), c, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr()),
           "vp3d_bn_bwd_finalize")
+    a_g, a_b = (dgam, dbet) if sync is None else _sync_sums(dgam, dbet, sync)   # the parameter gradients stay local sums
     dy = torch.empty_like(y)
-    check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
-                              dbet.data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
+    check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, a_g.data_ptr(),
+                              a_b.data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
     return dy, dgam, dbet
 
 

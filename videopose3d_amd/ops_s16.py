@@ -237,7 +237,7 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
 
 
 def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
-               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True):
+               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True, sync=None):
     """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows [None unless want_rows: only dgrad reads them],
     dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy."""
     ops._chk(go, "go")
@@ -261,10 +261,17 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
         dgam, dbet = dgb[0], dgb[1]
     check(L.vp3d_bn_bwd_finalize_s16(ops._stream(), c, m, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr(), sc,
                                      go_bound.data_ptr(), float(p), dy_bound.data_ptr()), "vp3d_bn_bwd_finalize_s16")
+    a_g, a_b = dgam, dbet
+    if sync is not None:                 # dp.SyncBatchNorm: global sums in the apply kernel and in the bound of dy
+        a_g, a_b = ops._sync_sums(dgam, dbet, sync)
+        dy_bound = new_bound(y.device)
+        check(L.vp3d_dy_bound(ops._stream(), c, sync.rows_total(m), sc, (a_g / sync.frac).contiguous().data_ptr(),
+                              (a_b / sync.frac).contiguous().data_ptr(), go_bound.data_ptr(), float(p), dy_bound.data_ptr()),
+              "vp3d_dy_bound")
     dy = torch.empty_like(y) if want_rows else None
     dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device)
-    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, dgam.data_ptr(),
-                                  dbet.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(), dyt.shape[1]),
+    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, a_g.data_ptr(),
+                                  a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(), dyt.shape[1]),
           "vp3d_bn_bwd_apply_s16")
     return (S16(dy, dy_bound) if dy is not None else None), S16(dyt, dy_bound), dgam, dbet
 
