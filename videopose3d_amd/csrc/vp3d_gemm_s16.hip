@@ -153,6 +153,24 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
       for (int j = 0; j < CB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
   }
+  // Pin the interleave (hipcc otherwise sinks every ds_read to just before its first use: read -> wait -> 2 MFMA -> read
+  // ..., exposing the LDS latency a dozen times per K-tile): all fragment reads of k-step 0 up front, the reads of k-step
+  // 1 one at a time behind the first MFMAs of step 0.  Masks: 0x008 MFMA, 0x100 DS read.
+  constexpr int R = 2 * (RB + CB), MQ = 3 * RB * CB;       // fragment reads / MFMAs per k-step
+  __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+  if constexpr (STEPS == 2) {
+    constexpr int NI = R < MQ ? R : MQ;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (R > NI) __builtin_amdgcn_sched_group_barrier(0x100, R - NI, 0);
+    if constexpr (MQ > NI) __builtin_amdgcn_sched_group_barrier(0x008, MQ - NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MQ, 0);
+  } else {
+    __builtin_amdgcn_sched_group_barrier(0x008, MQ, 0);
+  }
 }
 
 // position in the launch order -> tile (the fp32 kernel's XCD-aware order: workgroup id b runs on XCD b%8; every
@@ -353,6 +371,15 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       const char* sN = smem + st * C::STAGE_B;       // tile it+1 (a harmless zero-page tile past the end)
       load_frags<RB, CB, BK / 16, ROWB>(sN + a_row, sN + C::A_B + b_row, off0, off1, nxt);
       mma_frags<RB, CB, BK / 16>(cur, acc);
+      // pinned interleave: the next tile's fragment reads ride one by one behind this tile's first MFMAs
+      constexpr int NR = 2 * (RB + CB) * (BK / 16), NM = 3 * RB * CB * (BK / 16), NI = NR < NM ? NR : NM;
+#pragma unroll
+      for (int q = 0; q < NI; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if constexpr (NR > NI) __builtin_amdgcn_sched_group_barrier(0x100, NR - NI, 0);
+      if constexpr (NM > NI) __builtin_amdgcn_sched_group_barrier(0x008, NM - NI, 0);
     };
     int it = 0;
     for (; it + 1 < nkt; it += 2) {
@@ -798,7 +825,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
       const int64_t ta = (int64_t)(m_split / 256) * n256, tb = (int64_t)((M - m_split + 127) / 128) * n128;
       const int64_t pcb = (tb + 255) / 256;
       const double hybrid = (double)((ta + 255) / 256) * (nk * 2.55 + 5.0) + 5.0 + (double)pcb * (nk * (pcb >= 2 ? 0.74 : 0.85) + 2.0);
-      if (hybrid < single * 0.97) best_cfg = 30;
+      if (hybrid < single * 0.92) best_cfg = 30;
     }
   }
   *cfg_out = best_cfg;
