@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 102
+#define VP3D_VERSION 103
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -218,16 +218,28 @@ int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound);
  * strided conv that consumes the tensor, 1 otherwise; M % taps == 0), S16 rows along m, ld_t >= roundup(M/taps, 64)
  * 4-byte units, columns [M/taps, roundup(M/taps, 64)) zero-filled.  Bounds are device floats (see vp3d_s16). */
 /* out = [res +] dropout(relu(y*scale + shift)) as S16 with the exponent of *out_bound; res (S16, exponent of *res_bound)
- * is addressed as in vp3d_bn_act_fwd; out_f32 (may be NULL) additionally receives the plain fp32 values */
+ * is addressed as in vp3d_bn_act_fwd; out_f32 (may be NULL) additionally receives the plain fp32 values.
+ * act_bits (may be NULL; M*C/8 bytes): the "activation bits" the backward passes read instead of regenerating the
+ * dropout mask (model.py:28's mask, which autograd would have saved): bit e of the byte at
+ * ((c/64)*M + m)*8 + (c%64)/8  =  [y*scale+shift > 0 and element (m, c - c%8 + e) kept],  c % 8 == 0. */
 int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
                         int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
-                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps);
-/* dy of vp3d_bn_bwd_apply as S16 rows (dy, may be NULL when only the transposed copy is wanted) + transposed copy (taps = 1) */
+                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps,
+                        uint8_t* act_bits);
+/* dy of vp3d_bn_bwd_apply as S16 rows (dy, may be NULL when only the transposed copy is wanted) + transposed copy
+ * (taps = 1).  act_bits != NULL: the mask and the ReLU predicate come from the forward's activation bits (drop only
+ * supplies p); NULL: they are regenerated from (drop, y, scale, shift) */
 int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
-                          const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
-                          void* dy, void* t_out, int64_t ld_t);
+                          const vp3d_dropout* drop, const uint8_t* act_bits, const float* dgamma, const float* dbeta,
+                          const float* out_bound, void* dy, void* t_out, int64_t ld_t);
+/* vp3d_bn_bwd_reduce on the activation bits: partials[(i*2 + {0,1})*C + c] = partial sums over the rows of block i of
+ * g and g*xhat, g = go * keep_scale * bit;  *nparts rows (call with partials == NULL to query), then
+ * vp3d_bn_bwd_finalize / vp3d_bn_bwd_finalize_s16.  keep_scale = 1/(1-p) (1 without dropout).  C % 64 == 0. */
+int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                            const float* mean, const float* invstd, const uint8_t* act_bits, float keep_scale,
+                            float* partials, int32_t* nparts);
 /* fp32 rows -> S16 rows (out, may be NULL) and / or the transposed S16 copy (t_out, may be NULL; taps = 1) */
 int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,
                  void* out, int64_t ld_out, void* t_out, int64_t ld_t);

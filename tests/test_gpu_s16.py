@@ -123,12 +123,14 @@ def test_weight_packs_match_reference_layout():
     assert torch.equal(dd, S.join(wf).view(128, 3, 64).permute(2, 1, 0).reshape(64, 3 * 128))
 
 
-@pytest.mark.parametrize("taps,p", [(1, 0.0), (3, 0.25)])
-def test_activation_forward_and_backward_producers(taps, p):
+@pytest.mark.parametrize("taps,p,use_bits,c", [(1, 0.0, False, 128), (3, 0.25, False, 128), (1, 0.0, True, 128),
+                                               (3, 0.25, True, 128), (3, 0.25, True, 192), (1, 0.5, True, 1024)])
+def test_activation_forward_and_backward_producers(taps, p, use_bits, c):
     """vp3d_bn_act_fwd_s16 / vp3d_bn_bwd_apply_s16 against the fp32 streaming kernels (same Philox mask), including the
-    transposed copies in the layout the strided conv's wgrad reduces over."""
+    transposed copies in the layout the strided conv's wgrad reduces over; with use_bits the backward reads the forward's
+    activation bits (vp3d_bn_bwd_reduce_bits + the BITS apply kernel) instead of regenerating mask and ReLU predicate."""
     g = torch.Generator().manual_seed(11)
-    b, t, c = 6, 9, 128
+    b, t = 6, 9
     y = torch.randn(b, t, c, generator=g).to(DEV)
     coef = torch.stack([1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g),
                         0.05 * torch.randn(c, generator=g), 1 + 0.1 * torch.rand(c, generator=g)]).to(DEV)
@@ -138,10 +140,19 @@ def test_activation_forward_and_backward_producers(taps, p):
     a32 = ops.bn_act_fwd(y, coef, drop, (res, rs))
     bd = S.new_bound(DEV)
     bd[0] = float(a32.abs().max()) * 1.5
-    a, a_t = S.bn_act_fwd(y, coef, drop, (S.split(res), rs), bd, t_taps=taps)
-    assert float((S.join(a) - a32).abs().max()) < float(bd.max()) * 2.0 ** -20
-    at = S.join(a_t)
     m = b * t
+    bits = S.new_act_bits(m, c, DEV) if use_bits else None
+    a, a_t = S.bn_act_fwd(y, coef, drop, (S.split(res), rs), bd, t_taps=taps, act_bits=bits)
+    assert float((S.join(a) - a32).abs().max()) < float(bd.max()) * 2.0 ** -20
+    if use_bits:       # bit e of byte ((c/64)*M + m)*8 + (c%64)/8  ==  [bn(y) > 0 and kept]
+        z = y.double() * coef[0].double() + coef[1].double()
+        keep = ops.dropout_mask(m * c, drop, DEV).view(b, t, c) != 0 if drop is not None else torch.ones_like(z, dtype=torch.bool)
+        want = ((z > 0) & keep).view(m, c // 64, 8, 8)                      # [m][tile][byte][bit]
+        sure = (z.abs() > 1e-6).view(m, c // 64, 8, 8)                      # (fp32 fma rounding may flip a z ~ 0)
+        got = bits.view(c // 64, m, 8)
+        unpacked = torch.stack([(got >> e) & 1 for e in range(8)], dim=-1).bool()      # [tile][m][byte][bit]
+        assert torch.equal(unpacked.permute(1, 0, 2, 3) & sure, want & sure)
+    at = S.join(a_t)
     assert at.shape == (taps * c, S.t_pitch(m, taps))
     expect = S.join(a).reshape(m // taps, taps, c).permute(1, 2, 0).reshape(taps * c, m // taps)
     assert torch.equal(at[:, :m // taps], expect)
@@ -151,9 +162,12 @@ def test_activation_forward_and_backward_producers(taps, p):
     dy32, dg32, db32 = ops.bn_act_bwd(go, y, coef, drop)
     gb = S.amax(go)
     dyb = S.new_bound(DEV)
-    dy, dy_t, dg, db = S.bn_act_bwd(go, gb, y, coef, drop, p, dyb)
+    dy, dy_t, dg, db = S.bn_act_bwd(go, gb, y, coef, drop, p, dyb, act_bits=bits)
     assert float(dyb.max()) >= float(dy32.abs().max())              # the Samuelson bound is a bound
-    assert torch.equal(dg, dg32) and torch.equal(db, db32)
+    if use_bits:                                                    # other summation order than the fp32 pass
+        assert torch.allclose(dg, dg32, rtol=1e-5, atol=1e-9) and torch.allclose(db, db32, rtol=1e-5, atol=1e-9)
+    else:
+        assert torch.equal(dg, dg32) and torch.equal(db, db32)
     assert float((S.join(dy) - dy32).abs().max()) < float(dyb.max()) * 2.0 ** -20
     assert torch.equal(S.join(dy_t)[:, :m], S.join(dy).reshape(m, c).t().contiguous())
 

@@ -79,9 +79,10 @@ SIGNATURES = {
     "vp3d_split_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vp3d_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
     "vp3d_bn_act_fwd_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                      _vp, _vp, _vp, _vp, _i64, _i32]),
+                                      _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vp3d_bn_bwd_apply_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp, _vp, _vp,
-                                        _i64]),
+                                        _vp, _i64]),
+    "vp3d_bn_bwd_reduce_bits": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _P(_i32)]),
     "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
     "vp3d_amax_multi": (C.c_int, [_vp, _i32, _P(_vp), _P(_i64), _vp]),
@@ -138,8 +139,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 102:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (102); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 103:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (103); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

@@ -43,6 +43,29 @@ __device__ __forceinline__ void tile_store_t(const float* tile, const TOut& t, i
   }
 }
 
+// 8 consecutive per-channel parameters (two 16-byte loads when the array allows it)
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&o)[8]) {
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = a[e];
+      o[4 + e] = b[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = p[e];
+  }
+}
+
+// "activation bits": one byte per (row, 8 consecutive channels), bit e = [bn(y) > 0 and the element was kept by the
+// dropout]: written by the forward producer, read by the two backward passes instead of regenerating the Philox mask
+// (10 integer multiplies per element and pass).  Stored per 64-channel tile so that a block's bytes are contiguous:
+// byte of (row m, channels c..c+7) at ((c / 64) * M + m) * 8 + (c % 64) / 8.
+__device__ __forceinline__ int64_t act_bits_index(int c, int64_t m, int M) {
+  return ((int64_t)(c >> 6) * M + m) * 8 + ((c & 63) >> 3);
+}
+
 struct ResS16 {
   const float* res;           // S16 rows
   const float* bound;
@@ -56,7 +79,8 @@ struct ResS16 {
 __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const float* __restrict__ y,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         DropP d, ResS16 rm, const float* __restrict__ out_bound,
-                                                        float* __restrict__ out, float* __restrict__ out_f32, TOut t) {
+                                                        float* __restrict__ out, float* __restrict__ out_f32, TOut t,
+                                                        uint8_t* __restrict__ act_bits) {
   drop_resolve(d);
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
@@ -65,11 +89,8 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
   const int R = taps * 64;
   const int64_t m0 = (int64_t)blockIdx.y * R;
   float sc[8], sh[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = scale[c + e];
-    sh[e] = shift[c + e];
-  }
+  load8(scale + c, sc);
+  load8(shift + c, sh);
   const float inv = s16_pow2(-s16_exp_of(out_bound));
   const float rscale = rm.res != nullptr ? s16_pow2(s16_exp_of(rm.bound)) : 0.f;
   for (int r = rsub; r < R; r += 32) {
@@ -98,12 +119,15 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
             rm.res + ((int64_t)b * rm.r_t + (int64_t)tt * rm.r_stride + rm.r_off) * rm.r_ld + c);
         s16_join8(rp[0], rp[1], rscale, rv);
       }
+      uint32_t bits = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float yy = e < 4 ? y0[e] : y1[e - 4];
         const float z = fmaf(yy, sc[e], sh[e]);
         v[e] = rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f));
+        bits |= (z > 0.f && mk[e] != 0.f) ? (1u << e) : 0u;
       }
+      if (act_bits != nullptr) act_bits[((int64_t)blockIdx.x * M + m) * 8 + g8] = (uint8_t)bits;
       if (out_f32 != nullptr) {
         *reinterpret_cast<f32x4*>(out_f32 + e0) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(out_f32 + e0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -131,76 +155,169 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
 
 // ---------------------------------------------------------------------------------------------------------
 // dy = scale*(g - dbeta/M - xhat*dgamma/M),  g = go*keep*[z>0]   ->  S16 rows (+ transposed, taps = 1)
+// BITS: keep*[z>0] comes from the forward producer's activation bits (no Philox, no z); otherwise it is regenerated.
+// A block walks the 64-row tiles ty = blockIdx.y, blockIdx.y + gridDim.y, ... of its 64-channel strip, so the
+// per-channel constants are loaded once per block.
 // ---------------------------------------------------------------------------------------------------------
+template <bool BITS>
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const float* __restrict__ go,
                                                           const float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, DropP d,
+                                                          const uint8_t* __restrict__ act_bits, float keep_scale,
                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                           const float* __restrict__ out_bound, float* __restrict__ dy,
                                                           TOut t) {
-  drop_resolve(d);
+  if (!BITS) drop_resolve(d);
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
-  const int64_t m0 = (int64_t)blockIdx.y * 64;
   const float inv_m = 1.0f / (float)M;
-  float sc[8], sh[8], mu[8], is[8], kb[8], kg[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
-    kb[e] = dbeta[c + e] * inv_m;
-    kg[e] = dgamma[c + e] * inv_m;
-  }
   const float inv = s16_pow2(-s16_exp_of(out_bound));
-  for (int r = rsub; r < 64; r += 32) {
-    const int64_t m = m0 + r;
-    float v[8];
-    if (m < M) {
-      const int64_t e0 = m * C + c;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(go + e0);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(go + e0 + 4);
-      const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + e0);
-      const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
-      float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-      if (d.on) {
-        float a[4], b[4];
-        drop4(d, (uint64_t)(e0 >> 2), a);
-        drop4(d, (uint64_t)(e0 >> 2) + 1, b);
+  // v = A*g + B + Cx*(y - mu):   A = scale*inv, B = -A*dbeta/M, Cx = -A*invstd*dgamma/M
+  float ka[8], kb[8], kc[8], mu[8], sc[8], sh[8];
+  {
+    float is[8], dg[8], db[8];
+    load8(scale + c, sc);
+    load8(mean + c, mu);
+    load8(invstd + c, is);
+    load8(dgamma + c, dg);
+    load8(dbeta + c, db);
+    if (!BITS) load8(shift + c, sh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          mk[e] = a[e];
-          mk[4 + e] = b[e];
+    for (int e = 0; e < 8; ++e) {
+      ka[e] = sc[e] * inv;
+      kb[e] = -ka[e] * (db[e] * inv_m);
+      kc[e] = -ka[e] * (is[e] * (dg[e] * inv_m));
+    }
+  }
+  const int ntiles = (M + 63) >> 6;
+  for (int ty = blockIdx.y; ty < ntiles; ty += gridDim.y) {
+    const int64_t m0 = (int64_t)ty * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = rsub + it * 32;
+      const int64_t m = m0 + r;
+      float v[8];
+      if (m < M) {
+        const int64_t e0 = m * C + c;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(go + e0);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(go + e0 + 4);
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + e0);
+        const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
+        float mk[8];
+        if (BITS) {
+          const uint32_t bits = act_bits[((int64_t)blockIdx.x * M + m) * 8 + g8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mk[e] = ((bits >> e) & 1u) ? keep_scale : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mk[e] = 1.f;
+          if (d.on) {
+            float a[4], b[4];
+            drop4(d, (uint64_t)(e0 >> 2), a);
+            drop4(d, (uint64_t)(e0 >> 2) + 1, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              mk[e] = a[e];
+              mk[4 + e] = b[e];
+            }
+          }
         }
-      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float yy = e < 4 ? y0[e] : y1[e - 4];
-        const float gg = e < 4 ? g0[e] : g1[e - 4];
-        const float z = fmaf(yy, sc[e], sh[e]);
-        const float g = z > 0.f ? gg * mk[e] : 0.f;
-        const float xh = (yy - mu[e]) * is[e];
-        v[e] = sc[e] * (g - kb[e] - xh * kg[e]) * inv;
-      }
-      if (dy != nullptr) {                          // (the expand conv needs no dgrad: only the transposed copy is written)
-        f16x8 hi, lo;
-        s16_split8(v, 1.f, hi, lo);
-        f16x8* o = reinterpret_cast<f16x8*>(dy + e0);
-        o[0] = hi;
-        o[1] = lo;
-      }
-    } else {
+        for (int e = 0; e < 8; ++e) {
+          const float yy = e < 4 ? y0[e] : y1[e - 4];
+          const float gg = e < 4 ? g0[e] : g1[e - 4];
+          float g = gg * mk[e];
+          if (!BITS) g = fmaf(yy, sc[e], sh[e]) > 0.f ? g : 0.f;
+          v[e] = fmaf(kc[e], yy - mu[e], fmaf(ka[e], g, kb[e]));
+        }
+        if (dy != nullptr) {                        // (the expand conv needs no dgrad: only the transposed copy is written)
+          f16x8 hi, lo;
+          s16_split8(v, 1.f, hi, lo);
+          f16x8* o = reinterpret_cast<f16x8*>(dy + e0);
+          o[0] = hi;
+          o[1] = lo;
+        }
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      if (t.ptr != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+      }
     }
     if (t.ptr != nullptr) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+      __syncthreads();
+      tile_store_t(tile, t, C, c0, m0);
+      __syncthreads();
     }
   }
-  if (t.ptr == nullptr) return;
-  __syncthreads();
-  tile_store_t(tile, t, C, c0, (int64_t)blockIdx.y * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm-backward column sums with the activation bits:  per channel  sum(g), sum(g * xhat),  g = go*keep*[z>0].
+// Thread = 4 channels (one 16-byte load per array and row: a wave reads 1 KB runs) x the rows rsub, rsub + step, ...;
+// the block folds its row sub-groups through LDS (fixed order) and writes ONE partial row:
+// partials[(blockIdx.y*2 + {0,1})*C + c].
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const float* __restrict__ go,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const uint8_t* __restrict__ act_bits, float keep_scale,
+                                                            float* __restrict__ partials, int lanes_per_row,
+                                                            int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int lr = threadIdx.x % lanes_per_row, rsub = threadIdx.x / lanes_per_row;
+  const int c = (blockIdx.x * lanes_per_row + lr) * 4;
+  const bool live = rsub < rows_per_block && c < C;
+  float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    float mu[4], is[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mu[e] = mean[c + e];
+      is[e] = invstd[c + e];
+    }
+    const uint8_t* bp = act_bits + ((int64_t)(c >> 6) * M) * 8 + ((c & 63) >> 3);
+    const int sh = c & 4;
+    const int row_step = gridDim.y * rows_per_block;
+#pragma unroll 8
+    for (int m = blockIdx.y * rows_per_block + rsub; m < M; m += row_step) {
+      const int64_t e0 = (int64_t)m * C + c;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(go + e0);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+      const uint32_t bits = (uint32_t)bp[(int64_t)m * 8] >> sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = ((bits >> e) & 1u) ? gv[e] * keep_scale : 0.f;
+        sg[e] += g;
+        sgx[e] = fmaf(g, (yv[e] - mu[e]) * is[e], sgx[e]);
+      }
+    }
+  }
+  if (rows_per_block > 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(e * 2 + 0) * 256 + threadIdx.x] = sg[e];
+      red[(e * 2 + 1) * 256 + threadIdx.x] = sgx[e];
+    }
+    __syncthreads();
+    if (rsub == 0 && c < C) {
+      for (int r = 1; r < rows_per_block; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sg[e] += red[(e * 2 + 0) * 256 + r * lanes_per_row + lr];
+          sgx[e] += red[(e * 2 + 1) * 256 + r * lanes_per_row + lr];
+        }
+      }
+    }
+  }
+  if (rsub == 0 && c < C) {
+    *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 0) * C + c) = f32x4{sg[0], sg[1], sg[2], sg[3]};
+    *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 1) * C + c) = f32x4{sgx[0], sgx[1], sgx[2], sgx[3]};
+  }
 }
 
 // fp32 rows [M][C] (pitch ld_src) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
@@ -509,7 +626,8 @@ extern "C" {
 int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const void* res, const float* res_bound,
                         int32_t t_dst, int32_t r_t, int32_t r_stride, int32_t r_off, int32_t r_ld,
-                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps) {
+                        const float* out_bound, void* out, float* out_f32, void* t_out, int64_t ld_t, int32_t taps,
+                        uint8_t* act_bits) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && y && scale && shift && out && out_bound &&
                    (out_f32 == nullptr || aligned16(out_f32)),
                "bn_act_fwd_s16: bad argument (needs C %% 64 == 0)");
@@ -524,26 +642,56 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   const int R = 64 * t.taps;
   const size_t lds = t_out ? (size_t)R * TPITCH * 4 : 0;
   hipLaunchKernelGGL(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
-                     (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, out_f32, t);
+                     (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, out_f32, t, act_bits);
   return check_launch("bn_act_fwd_s16");
 }
 
 int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
-                          const vp3d_dropout* drop, const float* dgamma, const float* dbeta, const float* out_bound,
-                          void* dy, void* t_out, int64_t ld_t) {
+                          const vp3d_dropout* drop, const uint8_t* act_bits, const float* dgamma, const float* dbeta,
+                          const float* out_bound, void* dy, void* t_out, int64_t ld_t) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && y && scale && shift && mean && invstd &&
                    dgamma && dbeta && out_bound && (dy || t_out),
                "bn_bwd_apply_s16: bad argument (needs C %% 64 == 0)");
   VP3D_REQUIRE(aligned16(go) && aligned16(y) && aligned16(dy), "bn_bwd_apply_s16: 16-byte aligned buffers required");
   int rc = check_t("bn_bwd_apply_s16", t_out, ld_t, 1, M);
   if (rc) return rc;
+  if (drop) VP3D_REQUIRE(drop->p >= 0.f && drop->p < 1.f, "bn_bwd_apply_s16: dropout p=%f", drop->p);
   const DropP d = make_drop(drop);
   TOut t{(float*)t_out, ld_t, 1};
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
-  hipLaunchKernelGGL(k_bn_bwd_apply_s16, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream,
-                     (int)M, C, go, y, scale, shift, mean, invstd, d, dgamma, dbeta, out_bound, (float*)dy, t);
+  const int64_t ntiles = (M + 63) / 64, gx = C / 64;
+  int64_t per_block = gx * ntiles / 2048;       // tiles per block: amortise the per-channel constants, keep >= 2048 blocks
+  per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
+  const dim3 grid((unsigned)gx, (unsigned)((ntiles + per_block - 1) / per_block));
+  if (act_bits != nullptr)
+    hipLaunchKernelGGL((k_bn_bwd_apply_s16<true>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale, shift,
+                       mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply_s16<false>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale,
+                       shift, mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t);
   return check_launch("bn_bwd_apply_s16");
+}
+
+int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                            const float* mean, const float* invstd, const uint8_t* act_bits, float keep_scale,
+                            float* partials, int32_t* nparts) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && nparts,
+               "bn_bwd_reduce_bits: bad argument (needs C %% 64 == 0)");
+  const int c4 = C / 4;
+  const int lpr = c4 < 256 ? c4 : 256;
+  const int rpb = 256 / lpr;
+  const int gx = (c4 + lpr - 1) / lpr;
+  int64_t gy = (M + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);     // >= 16 rows per thread ...
+  const int64_t cap = 512 / gx > 0 ? 512 / gx : 1;                     // ... and at most ~512 blocks (2 per CU)
+  gy = gy > cap ? cap : gy;
+  *nparts = (int32_t)gy;
+  if (partials == nullptr) return VP3D_OK;      // size query
+  VP3D_REQUIRE(go && y && mean && invstd && act_bits && aligned16(go) && aligned16(y) && aligned16(partials),
+               "bn_bwd_reduce_bits: null or unaligned pointer");
+  hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
+                     invstd, act_bits, keep_scale, partials, lpr, rpb);
+  return check_launch("bn_bwd_reduce_bits");
 }
 
 int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,

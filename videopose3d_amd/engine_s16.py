@@ -21,6 +21,7 @@ tile exactly (T == receptive field, what run.py trains on).  ``supported()`` tel
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -106,10 +107,12 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 # training (strided model)
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad")
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits")
 
-    def __init__(self, x_t, y, coef, drop, wd, t_in, kpad):
+    def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits):
         self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
+        self.bits = bits          # activation bits ([bn(y) > 0 and kept], 1 bit / element): what backward reads instead
+                                  # of regenerating the Philox mask
 
 
 def forward_train(mod, x3: torch.Tensor, save: bool):
@@ -151,6 +154,10 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
     S.act_bounds_multi(bns, m_all if sync is None else [sync.rows_total(m_) for m_ in m_all], res_from, p, bounds)
+    c_all = [plan.convs[idx].c_out for idx in range(n_layers)]
+    use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
+    bits_all = S.new_act_bits(sum(m_ * c_ for m_, c_ in zip(m_all, c_all)) // c_all[0], c_all[0], dev) if use_bits else None
+    bits_at = 0
 
     h_prev = None          # S16 block input (residual source)
     a = x_rows
@@ -168,12 +175,17 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         residual = None
         if idx >= 2 and idx % 2 == 0:
             residual = (h_prev, plan.res[idx // 2 - 1])
+        bits = None
         if save:
-            saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0))
+            if use_bits:
+                bits = bits_all[bits_at:bits_at + m_rows * spec.c_out // 8]
+                bits_at += bits.numel()
+            saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0, bits))
         if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
-            a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True)
+            a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:
-            a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0)
+            a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0,
+                                  act_bits=bits)
         if idx % 2 == 0:
             h_prev = a
     out = engine._shrink(mod, h_last)
@@ -237,7 +249,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             o_g = o_bt = None
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
                                             out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0,   # expand: no dgrad
-                                            sync=mod.__dict__.get("_vp3d_sync_bn"))
+                                            sync=mod.__dict__.get("_vp3d_sync_bn"), act_bits=s.bits)
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
         return dy, dy_t

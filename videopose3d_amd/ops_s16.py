@@ -208,9 +208,10 @@ def act_bound(bn: torch.nn.BatchNorm1d, m_rows: int, p: float, res_bound: Option
 
 
 def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tuple[S16, ResSpec]], out_bound: torch.Tensor,
-               t_taps: int = 0, want_f32: bool = False):
+               t_taps: int = 0, want_f32: bool = False, act_bits: Optional[torch.Tensor] = None):
     """a = [res +] dropout(relu(bn(y))) as S16 rows [B,T,C] (+ the transposed copy for the consuming conv's wgrad when
-    t_taps > 0: [t_taps*C][roundup(M/t_taps, 64)])."""
+    t_taps > 0: [t_taps*C][roundup(M/t_taps, 64)]).  act_bits (uint8 [M*C/8], see new_act_bits) receives the
+    [bn(y) > 0 and kept] bits for bn_act_bwd."""
     ops._chk(y, "y")
     b, t, c = y.shape
     m = b * t
@@ -230,16 +231,24 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
     check(_lib.lib().vp3d_bn_act_fwd_s16(ops._stream(), m, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                          C.byref(drop) if drop is not None else None, *rargs, out_bound.data_ptr(),
                                          out.data_ptr(), ops._p(f32), ops._p(tt), tt.shape[1] if tt is not None else 0,
-                                         max(t_taps, 1)), "vp3d_bn_act_fwd_s16")
+                                         max(t_taps, 1), ops._p(act_bits)), "vp3d_bn_act_fwd_s16")
     if want_f32:
         return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None), f32
     return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
 
 
+def new_act_bits(m_rows: int, c: int, device) -> torch.Tensor:
+    """Buffer for the activation bits of an [m_rows, c] activation (1 bit per element)."""
+    assert c % 64 == 0
+    return torch.empty(m_rows * c // 8, dtype=torch.uint8, device=device)
+
+
 def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
-               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True, sync=None):
+               dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True, sync=None,
+               act_bits: Optional[torch.Tensor] = None):
     """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows [None unless want_rows: only dgrad reads them],
-    dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy."""
+    dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy.  With the forward's
+    act_bits the two passes read the mask / ReLU predicate (1 bit per element) instead of regenerating them."""
     ops._chk(go, "go")
     ops._chk(y, "y")
     b, t, c = y.shape
@@ -248,12 +257,21 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     L = _lib.lib()
     dref = C.byref(drop) if drop is not None else None
     nparts = C.c_int32(0)
-    check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, None, None, None, None, None, None, None, None, C.byref(nparts)),
-          "vp3d_bn_bwd_reduce(query)")
-    parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
     sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
-    check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
-                               C.byref(nparts)), "vp3d_bn_bwd_reduce")
+    if act_bits is not None:
+        assert act_bits.numel() * 8 == m * c and act_bits.dtype == torch.uint8
+        keep_scale = 1.0 / (1.0 - p) if drop is not None else 1.0
+        check(L.vp3d_bn_bwd_reduce_bits(ops._stream(), m, c, None, None, None, None, None, 1.0, None, C.byref(nparts)),
+              "vp3d_bn_bwd_reduce_bits(query)")
+        parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
+        check(L.vp3d_bn_bwd_reduce_bits(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), mu, inv, act_bits.data_ptr(),
+                                        keep_scale, parts.data_ptr(), C.byref(nparts)), "vp3d_bn_bwd_reduce_bits")
+    else:
+        check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, None, None, None, None, None, None, None, None, C.byref(nparts)),
+              "vp3d_bn_bwd_reduce(query)")
+        parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
+        check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
+                                   C.byref(nparts)), "vp3d_bn_bwd_reduce")
     if out_dgamma is not None and out_dbeta is not None:
         dgam, dbet = out_dgamma, out_dbeta
     else:
@@ -270,8 +288,9 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
               "vp3d_dy_bound")
     dy = torch.empty_like(y) if want_rows else None
     dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device)
-    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, a_g.data_ptr(),
-                                  a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(), dyt.shape[1]),
+    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, ops._p(act_bits),
+                                  a_g.data_ptr(), a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(),
+                                  dyt.shape[1]),
           "vp3d_bn_bwd_apply_s16")
     return (S16(dy, dy_bound) if dy is not None else None), S16(dyt, dy_bound), dgam, dbet
 
