@@ -348,6 +348,47 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(int splits, int c_out, int
   }
 }
 
+// the same with 16-byte accesses: thread = (co, 4 consecutive ci); per tap and split one 16-byte load along ci (the loads
+// of all taps and up to 4 splits are independent), then the interleaved [ci][k] run of 4*TAPS floats as 16-byte stores
+template <int TAPS>
+__global__ void __launch_bounds__(256) k_wgrad_reduce_v4(int splits, int c_out, int c_in, const float* __restrict__ partials,
+                                                         int ld_part, float* __restrict__ dw) {
+  const int cq = c_in >> 2;
+  const int64_t total = (int64_t)c_out * cq;
+  const int64_t mat = (int64_t)c_out * ld_part;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t co = i / cq;
+    const int ci = (int)(i - co * cq) * 4;
+    const float* src = partials + co * (int64_t)ld_part + ci;
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      f32x4 v[4][TAPS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(src + (int64_t)(s + u) * mat + (int64_t)k * c_in);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)               // same summation order as the scalar kernel
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc[k] += v[u][k];
+    }
+    for (; s < splits; ++s)
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) acc[k] += *reinterpret_cast<const f32x4*>(src + (int64_t)s * mat + (int64_t)k * c_in);
+    float o[4 * TAPS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) o[j * TAPS + k] = acc[k][j];
+    f32x4* dst = reinterpret_cast<f32x4*>(dw + (co * c_in + ci) * TAPS);
+#pragma unroll
+    for (int q = 0; q < TAPS; ++q) dst[q] = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+  }
+}
+
 // out[n] = sum_m g[m*ld + n]
 __global__ void __launch_bounds__(256) k_colsum(int64_t M, int N, const float* __restrict__ g, int ld, float* out) {
   __shared__ float red[256];
@@ -597,8 +638,16 @@ int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t ld_pa
                       int32_t c_in, int32_t taps, float* dw) {
   VP3D_REQUIRE(partials && dw && splits > 0 && c_out > 0 && c_in > 0 && taps > 0 && ld_part >= taps * c_in,
                "wgrad_reduce: bad argument");
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
-                     splits, c_out, c_in, taps, partials, ld_part, dw);
+  const bool vec = c_in % 4 == 0 && ld_part % 4 == 0 && aligned16(partials) && aligned16(dw) && (taps == 1 || taps == 3);
+  if (vec && taps == 3)
+    hipLaunchKernelGGL((k_wgrad_reduce_v4<3>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
+                       splits, c_out, c_in, partials, ld_part, dw);
+  else if (vec)
+    hipLaunchKernelGGL((k_wgrad_reduce_v4<1>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
+                       splits, c_out, c_in, partials, ld_part, dw);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
+                       splits, c_out, c_in, taps, partials, ld_part, dw);
   return check_launch("wgrad_reduce");
 }
 
