@@ -33,8 +33,10 @@ def sweep(tag, m, n, k, raw):
     rm = RowMap(1, m, m, 1, 0, 0, 1)
     flops = 2.0 * m * n * k
     res = []
-    for cfg in (20, 22):
+    for cfg in (20, 22, 30):
         for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+            if cfg == 30 and s > 1:
+                continue
             if s > 1 and (k // 32) // s < 4:
                 continue
             if s * m * n * 4 > 2e9:
@@ -51,6 +53,7 @@ def sweep(tag, m, n, k, raw):
                 continue
             res.append((ms, cfg, s))
     res.sort()
+    print("   all: " + " ".join("c%d/s%d=%.0f" % (c_, s_, ms_ * 1e3) for ms_, c_, s_ in sorted(res, key=lambda r: (r[1], r[2]))), flush=True)
     pc, ps = S.plan(m, n, k, raw)
     planned = [r for r in res if r[1] == pc and r[2] == ps]
     print("%-16s M=%6d N=%5d K=%6d  best c%d s%-2d %7.3f ms %6.1f TF | 2nd c%d s%-2d %7.3f | plan c%d s%-2d %s" % (

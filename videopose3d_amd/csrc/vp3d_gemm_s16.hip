@@ -181,16 +181,28 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
   }
 }
 
-// position in the launch order -> tile (the fp32 kernel's XCD-aware order: workgroup id b runs on XCD b%8; every
-// XCD walks whole m-tiles with up to 8 column tiles back to back, so its ~64 concurrent tiles form an 8x8 patch)
-__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int& tile_m, int& tile_n) {
+// position in the launch order -> tile.  Workgroup id b runs on XCD b % 8 (round-robin dispatch), and every XCD has its
+// own L2, so XCD x gets a CONTIGUOUS eighth [x*per_xcd, (x+1)*per_xcd) of a linear tile order in which consecutive tiles
+// form compact patches: column blocks of up to 8 tiles, inside a block m-tile by m-tile (the ~32-64 tiles an XCD runs at
+// a time are a 4..8 x 8 patch: ~12 operand panels for 32 tiles).  Equal shares matter: handing out whole m-tiles per XCD
+// (the fp32 kernel's order) leaves e.g. 108 m-tiles as 14/14/14/14/13/13/13/13 -- a sixth round on four XCDs.
+__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int per_xcd, int& tile_m, int& tile_n) {
   const int xcd = bid & 7, q = bid >> 3;
+  const int L = xcd * per_xcd + q;
+  if (q >= per_xcd || L >= m_tiles * n_tiles) return false;
   const int gn = min(n_tiles, 8);
-  const int m_groups = (m_tiles + 7) >> 3;
-  const int inner = q % gn, rest = q / gn;
-  tile_n = (rest / m_groups) * gn + inner;
-  tile_m = (rest % m_groups) * 8 + xcd;
-  return tile_m < m_tiles && tile_n < n_tiles;
+  const int full = (n_tiles / gn) * gn;              // columns in full blocks
+  const int in_full = m_tiles * full;
+  if (L < in_full) {
+    const int blk = L / (m_tiles * gn), r = L - blk * (m_tiles * gn);
+    tile_m = r / gn;
+    tile_n = blk * gn + (r - tile_m * gn);
+  } else {
+    const int gl = n_tiles - full, r = L - in_full;
+    tile_m = r / gl;
+    tile_n = full + (r - tile_m * gl);
+  }
+  return true;
 }
 
 template <class C>
@@ -211,7 +223,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const int split = blockIdx.x / p.pos_full;
   const int bid = blockIdx.x - split * p.pos_full;
   int tile_m, tile_n;
-  if (!tile_of(bid, p.m_tiles, p.n_tiles, tile_m, tile_n)) return;
+  if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos_full >> 3, tile_m, tile_n)) return;
   const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;      // this launch covers rows [m_begin, m_end)
 
   for (int r = tid; r < BM; r += C::NT) {
@@ -772,9 +784,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   a.m_end = m_end < 0 ? a.M : m_end;
   a.m_tiles = (a.m_end - a.m_begin + C::BM - 1) / C::BM;
   a.n_tiles = (a.N + C::BN - 1) / C::BN;
-  const int gn = a.n_tiles < 8 ? a.n_tiles : 8;
-  const int m_groups = (a.m_tiles + 7) / 8, n_groups = (a.n_tiles + gn - 1) / gn;
-  const int positions = 8 * gn * m_groups * n_groups;
+  const int positions = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);       // 8 equal XCD shares (tile_of)
   const int nkt = a.K / C::BKE;
   a.pos_full = positions;
   a.tail_pos = 0;
@@ -786,11 +796,24 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
 
 }  // namespace
 
-// Tile configuration and split-K factor of an [M,N,K] S16 GEMM: cost model in microseconds fitted to MI355X
-// measurements (tools/s16_tune.py).  A CU works through ceil(workgroups/256) workgroups; per 32-element K-tile a
-// 128x128 tile takes ~0.74 us of a CU when two workgroups share it (0.85 us alone), a 256x256 tile ~2.55 us (2.1 us
-// when fewer than 256 are in flight); the finishing pass of a split forward/dgrad launch streams the partial
-// matrices (mostly Infinity-Cache resident) once each way, a raw (wgrad) launch leaves that to vp3d_wgrad_reduce.
+// Tile configuration and split-K factor of an [M,N,K] S16 GEMM: cost model in microseconds, least-squares fit (10 % rms)
+// to the tools/s16_tune.py sweep on MI355X (22 shapes of the training step x 2 tilings x up to 10 split factors; its
+// picks are within 1.5 % of the measured optimum summed over the step).  A CU works through ceil(workgroups/256)
+// workgroups ("rounds"); per 32-element K-tile a 128x128 tile takes 0.66 us of a CU when two workgroups share it
+// (0.86 us alone) + 3.4 us per tile; a 256x256 tile 2.22 us (1.68-2.22 us when at most one round is in flight: fewer
+// waves compete for the LDS-DMA path) + 8.3 us per tile (row table, first DMA latency, epilogue).  The finishing pass
+// of a split forward/dgrad launch streams the partial matrices (mostly Infinity-Cache resident) once each way, a raw
+// (wgrad) launch leaves that to vp3d_wgrad_reduce.
+constexpr double kLaunchUs = 3.1;
+static double cost_128(int64_t wgs, double nk) {
+  const int64_t per_cu = (wgs + 255) / 256;
+  return (double)per_cu * (nk * (per_cu >= 2 ? 0.655 : 0.862) + 3.44);
+}
+static double cost_256(int64_t wgs, double nk) {
+  const int64_t per_cu = (wgs + 255) / 256;
+  const double fill = wgs < 256 ? (double)wgs / 256.0 : 1.0;
+  return (double)per_cu * (nk * (per_cu >= 2 ? 2.22 : 1.68 + 0.54 * fill) + 8.3);
+}
 // rows [0, m_split) = the largest whole number of m-tiles whose 256x256 tiles fit in whole rounds of 256 (0: no such split)
 static int hybrid_split_rows(int M, int N) {
   const int n256 = (N + 255) / 256;
@@ -807,14 +830,13 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
   for (int cfg = 0; cfg < 2; ++cfg) {
     const int bt = cfg == 0 ? 128 : 256;
     const int64_t tiles = (int64_t)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
-    for (int s = 1; s <= (allow_split ? 32 : 1); ++s) {
-      if (s > 1 && (nkt / s < 6 || cfg != 0)) break;                // the 256x256 configuration only pays unsplit
-      const int64_t per_cu = (tiles * s + 255) / 256;
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};     // the factors the sweep measured
+    for (int si = 0; si < (allow_split ? 10 : 1); ++si) {
+      const int s = kSplits[si];
+      if (s > 1 && nkt / s < 6) break;
       const double nk = (double)((nkt + s - 1) / s);
-      double cost = 5.0;
-      if (cfg == 0) cost += (double)per_cu * (nk * (per_cu >= 2 ? 0.74 : 0.85) + 2.0);
-      else cost += (double)per_cu * (nk * (per_cu >= 2 ? 2.55 : 2.1) + 5.0);
-      if (s > 1) cost += (raw ? 0.0 : 4.0) + (double)s * (double)M * (double)N * (raw ? 4.0 : 8.0) / 8.0e6;
+      double cost = kLaunchUs + (cfg == 0 ? cost_128(tiles * s, nk) : cost_256(tiles * s, nk));
+      if (s > 1) cost += (raw ? 0.0 : 5.5) + (double)s * (double)M * (double)N * (raw ? 4.0 : 8.0) / 7.4e6;
       if (cost < best * 0.98) {
         best = cost;
         best_cfg = cfg == 0 ? 20 : 22;              // buffer-descriptor DMA variants (the launcher falls back for >= 2 GiB operands)
@@ -829,12 +851,11 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
     if (m_split > 0 && m_split < M) {
       const int n256 = (N + 255) / 256, n128 = (N + 127) / 128;
       const double nk = (double)nkt;
-      const int64_t tiles = (int64_t)((M + 255) / 256) * n256;
-      const double single = (double)((tiles + 255) / 256) * (nk * 2.55 + 5.0);
       const int64_t ta = (int64_t)(m_split / 256) * n256, tb = (int64_t)((M - m_split + 127) / 128) * n128;
-      const int64_t pcb = (tb + 255) / 256;
-      const double hybrid = (double)((ta + 255) / 256) * (nk * 2.55 + 5.0) + 5.0 + (double)pcb * (nk * (pcb >= 2 ? 0.74 : 0.85) + 2.0);
-      if (hybrid < single * 0.92) best_cfg = 30;
+      // (the two launches serialise, which the sum under-counts by ~10 %: measured hybrid / single = 0.96 where the sum
+      // says 0.91 [M 27,648 x N 3072 x K 1024], 1.07 where it says 0.955 [M 27,648 x N 1024 x K 3072])
+      const double hybrid = 2.0 * kLaunchUs + cost_256(ta, nk) + cost_128(tb, nk);
+      if (hybrid < best * 0.93) best_cfg = 30;
     }
   }
   *cfg_out = best_cfg;
