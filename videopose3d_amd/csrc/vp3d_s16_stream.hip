@@ -563,7 +563,9 @@ __global__ void __launch_bounds__(1024) k_act_bounds_multi(ActBoundsMulti a) {
 
 // BN backward finalize (dgamma, dbeta from the partial sums, fp64) + the bound of dy in the same launch:
 // |dy_c| <= |scale_c| * (g + |dbeta_c|/M + sqrt(M-1)*|dgamma_c|/M),  g = go_bound / (1-p)
-constexpr int FIN_CH = 16, FIN_GROUPS = 64;
+// (256-thread blocks of <= 32 VGPRs: they fit beside the two 240-VGPR waves per SIMD of a 256x256 wgrad GEMM running on
+// the second stream -- 1024-thread blocks waited 80-140 us for whole workgroups of that GEMM to retire)
+constexpr int FIN_CH = 16, FIN_GROUPS = 16;
 __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize_bound(
     int C, const float* __restrict__ partials, int nparts, float* dgamma, float* dbeta, const float* __restrict__ scale,
     const float* __restrict__ go_bound, float inv_keep, float inv_m, float sqrt_m1, float* __restrict__ dy_bound) {
@@ -574,7 +576,7 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize_bound(
   const int c = blockIdx.x * FIN_CH + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-#pragma unroll 4
+#pragma unroll 8
     for (int p = g; p < nparts; p += FIN_GROUPS) {
       a1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
       a2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
