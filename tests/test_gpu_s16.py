@@ -45,6 +45,9 @@ CASES = [  # (B, T, spec, cfg, splits)
     (300, 27, ConvSpec(64, 300, 3, 1, 3), 30, 1),       # hybrid: 256x256 tiles on whole rounds + 128x128 on the rest (M = 2700)
     (1200, 81, ConvSpec(64, 512, 3, 1, 3), 30, 1),      # hybrid with a real split (M = 32400: 254 tiles + tail rows)
     (2, 300, ConvSpec(64, 64, 5, 1, 1), 0, 1),          # 5 adjacent taps ("dense"-style)
+    (11, 67, ConvSpec(64, 1344, 1), 20, 1),             # 11 column tiles: a full block of 8 + a ragged block of 3 (tile order)
+    (11, 67, ConvSpec(64, 2368, 1), 22, 1),             # 10 column tiles of 256 (8 + 2), 3 row tiles: 30 tiles over 8 XCDs
+    (11, 67, ConvSpec(192, 2368, 1), 22, 2),            # ... with split-K (positions of a split are a multiple of 8)
 ]
 
 
