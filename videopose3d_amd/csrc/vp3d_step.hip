@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_mpjpe(int64_t n, int dim, cons
                                                         const float* __restrict__ t, const float* __restrict__ w,
                                                         float inv_n, float* __restrict__ grad, double* __restrict__ part,
                                                         float* __restrict__ loss) {
-  __shared__ double red[LOSS_THREADS];
+  __shared__ double red[LOSS_THREADS / 64];
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int d = DIM > 0 ? DIM : dim;
@@ -126,15 +126,17 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_mpjpe(int64_t n, int dim, cons
       for (int c = 0; c < d; ++c) grad[i * d + c] = df[c] * k;
     }
   }
-  red[threadIdx.x] = acc;
+  // fixed-shape reduction: xor butterfly inside each wave, then the 16 wave sums in order (one barrier instead of the
+  // ten of a 1024-wide LDS tree: the kernel is pure latency)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int o = LOSS_THREADS / 2; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    if (gridDim.x == 1) loss[0] = (float)(red[0] * (double)inv_n);
-    else part[blockIdx.x] = red[0];
+    double tot = 0.0;
+    for (int i = 0; i < LOSS_THREADS / 64; ++i) tot += red[i];
+    if (gridDim.x == 1) loss[0] = (float)(tot * (double)inv_n);
+    else part[blockIdx.x] = tot;
   }
 }
 
