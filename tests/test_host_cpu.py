@@ -162,3 +162,29 @@ def test_engine_selection_by_arithmetic_and_size():
         V.set_default_math("bf16")
         V.default_math()
     V.set_default_math(None)
+
+
+def test_s16_planner_returns_launchable_plans_and_keeps_the_tuned_picks():
+    """vp3d_nt_s16_plan is a host function: every plan must be launchable (known tiling, 1 <= splits <= K/32, a split only
+    when allowed and then from the measured set), and the picks the tools/s16_tune.py sweep found best on the large
+    shapes of the cfg3 step are pinned (balanced tile order -> 256x256 + split-K for wgrad, hybrid for
+    the first block's dgrad)."""
+    import random
+    from videopose3d_amd import ops_s16 as S
+    rnd = random.Random(5)
+    for _ in range(300):
+        m = rnd.choice([1, 63, 64, 1000, 1024, 3072, 9216, 27648, 82944, 240640])
+        n = rnd.choice([32, 51, 64, 128, 1024, 3072])
+        k = 32 * rnd.choice([1, 2, 4, 32, 96, 288, 864, 2592])
+        for raw in (False, True):
+            cfg, splits = S.plan(m, n, k, raw)
+            assert cfg in (20, 22, 30)
+            assert 1 <= splits <= k // 32 and splits in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+            assert cfg != 30 or splits == 1
+    assert S.plan(27648, 3072, 1024, False) == (30, 1)       # first block's dgrad: whole rounds 256x256 + 128x128 rest
+    assert S.plan(27648, 1024, 3072, False) == (22, 1)
+    assert S.plan(1024, 3072, 27648, True) == (22, 16)       # wgrad: 256x256 tiles x 16 K-slices = 3 full rounds
+    assert S.plan(1024, 1024, 27648, True) == (22, 16)
+    assert S.plan(1024, 128, 82944, True) == (20, 32)        # expand wgrad
+    assert S.plan(1024, 1024, 1024, False)[0] == 20          # the T_out = 1 tail stays on 128x128 tiles
+    assert S.plan(240640, 1024, 3072, False) == (22, 1)      # cfg2 eval
