@@ -411,14 +411,18 @@ __global__ void __launch_bounds__(256) k_pack_weight_s16(int c_out, int c_in, in
 // ---------------------------------------------------------------------------------------------------------
 // bounds
 // ---------------------------------------------------------------------------------------------------------
+// maximum over a 1024-thread block, returned to every thread (xor butterfly per wave + the 16 wave maxima through LDS:
+// two barriers instead of the eleven of an LDS tree -- these kernels are pure latency)
 __device__ __forceinline__ float block_max_1024(float m, float* red) {
-  red[threadIdx.x] = m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __syncthreads();                                   // readers of a previous call are done with red[]
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  return red[0];
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
+  return r;
 }
 
 // |dropout(relu(bn(y)))| <= (|gamma|*sqrt(M-1) + |beta|) / (1-p)   (Samuelson), plus the residual's bound
@@ -467,6 +471,7 @@ __global__ void __launch_bounds__(256) k_amax_multi(AmaxMulti a) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? n >> 2 : 0;
   const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+#pragma unroll 4
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const f32x4 v = s4[i];
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -753,8 +758,8 @@ int vp3d_amax_multi(vp3d_stream_t stream, int32_t n_tensors, const float* const*
     }
   }
   a.bounds = bounds;
-  int64_t blocks = (nmax + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1024 ? blocks : 1024;
+  int64_t blocks = (nmax + 256 * 32 - 1) / (256 * 32);           // >= 8 float4 per thread of the largest tensor
+  blocks = blocks < 512 ? blocks : 512;
   hipLaunchKernelGGL(k_amax_multi, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("amax_multi");
 }
