@@ -146,6 +146,7 @@ def test_engine_selection_by_arithmetic_and_size():
     assert big.math == V.default_math()
     big.math = "f16x3"
     assert engine.use_s16(big, 243, True, batch=1024)
+    assert engine.use_s16(big, 243, True, batch=128)                      # 45 GFLOP: already pays (tools/small_modes.py)
     assert not engine.use_s16(big, 243, True, batch=64)                   # launch-latency regime
     assert not engine.use_s16(big, 243, True, need_dx=True, batch=1024)   # input gradients: fp32 engine
     assert not engine.use_s16(big, 244, True, batch=1024)                 # windows that do not tile

@@ -297,10 +297,11 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
 
 # Below this much forward conv work per call the step is bound by launch latency, not by the matrix pipes, and the
 # split-fp16 engine's extra producers / bound kernels cost more than its GEMMs save (measured on MI355X,
-# tools/small_modes.py: arc 3,3,3,3,3 training crosses over between B = 128 and 256, B = 2 evaluation between 485 and
-# 742 input frames; arc 3,3,3 stays on the fp32 kernels up to B = 1024).  VP3D_S16_MIN_GFLOP overrides both (0 = always).
+# tools/small_modes.py: arc 3,3,3,3,3 training crosses over between B = 64 [23 GFLOP: 1.83 vs 2.15 ms] and B = 128
+# [45 GFLOP: 2.50 vs 2.15 ms], B = 2 evaluation between 485 and 742 input frames [27 / 44 GFLOP]; arc 3,3,3 stays on
+# the fp32 kernels up to B = 1024 [36 GFLOP: 1.58 vs 1.91 ms]).  VP3D_S16_MIN_GFLOP overrides both (0 = always).
 _min_gf = os.environ.get("VP3D_S16_MIN_GFLOP")
-S16_MIN_FORWARD_FLOPS = {True: float(_min_gf or 60.0) * 1e9, False: float(_min_gf or 35.0) * 1e9}   # [training]
+S16_MIN_FORWARD_FLOPS = {True: float(_min_gf or 40.0) * 1e9, False: float(_min_gf or 35.0) * 1e9}   # [training]
 
 
 def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Optional[int] = None) -> bool:
