@@ -316,3 +316,47 @@ def test_model_level_parity_is_scale_invariant(scale):
         xe = (torch.randn(3, 60, 17, 2, device=DEV) * 0.5).clamp(-1, 1) * scale
         a, q = ev16(xe), ev32(xe)
     assert float((a - q).abs().max() / (q.abs().max() + 1e-30)) < 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_s16_backward_bucket_exchange_through_rccl_single_rank():
+    """The split-fp16 backward reports finished gradient groups from its SECOND stream (where the weight-gradient GEMMs
+    run; the last group from the main stream after the join): every bucket's all-reduce is launched during backward
+    and the synced gradients equal those of a plain step (world 1: the all-reduce is the identity)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from videopose3d_amd import dp, engine
+    from videopose3d_amd.loss import mpjpe
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(9)
+        a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.25, channels=256).to(DEV).train()
+        b = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.25, channels=256).to(DEV).train()
+        b.load_state_dict(a.state_dict())
+        for m in (a, b):
+            m.math = "f16x3"
+            m._drop_seed, m._drop_calls = 77, 0
+            assert engine.use_s16(m, 27, True, batch=32)
+        x = torch.randn(32, 27, 17, 2, device=DEV)
+        tgt = torch.randn(32, 1, 17, 3, device=DEV)
+        sync = dp.FlatGradSync(b.parameters(), direct_module=b, bucket_bytes=1 << 20, always_reduce=True)
+        assert len(sync.buckets) >= 2
+        for _ in range(2):
+            a.zero_grad(set_to_none=True)
+            mpjpe(a(x), tgt).backward()
+            sync.zero_grad()
+            mpjpe(b(x), tgt).backward()
+            assert len(sync._handles) == len(sync.buckets)       # every bucket was launched DURING backward
+            sync.sync()
+            torch.cuda.synchronize()
+            for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+                assert torch.equal(pa.grad, pb.grad), k
+    finally:
+        dist.destroy_process_group()
