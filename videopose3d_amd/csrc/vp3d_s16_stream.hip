@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
         v[e] = rv[e] + (z > 0.f ? z * mk[e] : (z != z ? z : 0.f));
         bits |= (z > 0.f && mk[e] != 0.f) ? (1u << e) : 0u;
       }
-      if (act_bits != nullptr) act_bits[((int64_t)blockIdx.x * M + m) * 8 + g8] = (uint8_t)bits;
+      if (act_bits != nullptr) act_bits[act_bits_index(c, m, M)] = (uint8_t)bits;
       if (out_f32 != nullptr) {
         *reinterpret_cast<f32x4*>(out_f32 + e0) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(out_f32 + e0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
         const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
         float mk[8];
         if (BITS) {
-          const uint32_t bits = act_bits[((int64_t)blockIdx.x * M + m) * 8 + g8];
+          const uint32_t bits = act_bits[act_bits_index(c, m, M)];
 #pragma unroll
           for (int e = 0; e < 8; ++e) mk[e] = ((bits >> e) & 1u) ? keep_scale : 0.f;
         } else {
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
       mu[e] = mean[c + e];
       is[e] = invstd[c + e];
     }
-    const uint8_t* bp = act_bits + ((int64_t)(c >> 6) * M) * 8 + ((c & 63) >> 3);
+    const uint8_t* bp = act_bits + act_bits_index(c, 0, M);
     const int sh = c & 4;
     const int row_step = gridDim.y * rows_per_block;
 #pragma unroll 8
@@ -647,6 +647,7 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   ResS16 rm{(const float*)res, res_bound, t_dst > 0 ? t_dst : 1, r_t, r_stride, r_off, r_ld};
   TOut t{(float*)t_out, ld_t, t_out ? taps : 1};
   const int R = 64 * t.taps;
+  VP3D_REQUIRE((M + R - 1) / R <= 65535, "bn_act_fwd_s16: more than 65535 row tiles (M=%lld)", (long long)M);
   const size_t lds = t_out ? (size_t)R * TPITCH * 4 : 0;
   hipLaunchKernelGGL(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
                      (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, out_f32, t, act_bits);
@@ -670,7 +671,9 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
   const int64_t ntiles = (M + 63) / 64, gx = C / 64;
   int64_t per_block = gx * ntiles / 2048;       // tiles per block: amortise the per-channel constants, keep >= 2048 blocks
   per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
-  const dim3 grid((unsigned)gx, (unsigned)((ntiles + per_block - 1) / per_block));
+  int64_t gy = (ntiles + per_block - 1) / per_block;
+  gy = gy > 65535 ? 65535 : gy;                 // (the kernel strides over the tiles)
+  const dim3 grid((unsigned)gx, (unsigned)gy);
   if (act_bits != nullptr)
     hipLaunchKernelGGL((k_bn_bwd_apply_s16<true>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale, shift,
                        mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t);
@@ -709,6 +712,7 @@ int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, i
   int rc = check_t("split_t", t_out, ld_t, 1, M);
   if (rc) return rc;
   TOut t{(float*)t_out, ld_t, 1};
+  VP3D_REQUIRE((M + 63) / 64 <= 65535, "split_t: more than 65535 row tiles (M=%lld)", (long long)M);
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
   hipLaunchKernelGGL(k_split_t, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
                      src, ld_src, bound, (float*)out, ld_out, t);
