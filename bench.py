@@ -385,6 +385,23 @@ def main():
     dtype = ("f32 (products on split-fp16 MFMA: 22+ bit operands, exact fp16 products, fp32 accumulate)" if math == "f16x3"
              else "f32")
 
+    # opt-in of round 1 (not the library default yet, so not `value`): weight gradients from the S16 rows
+    # (vp3d_wgrad_rows_s16: no transposed copies), same step otherwise
+    rows_opt = None
+    if math == "f16x3" and os.environ.get("VP3D_WGRAD_ROWS", "0") != "1":
+        os.environ["VP3D_WGRAD_ROWS"] = "1"
+        try:                                  # informational: never lets the headline line fail
+            dt_r = time_steps(step, 3, args.steps)
+            rows_opt = {"what": "the same step with VP3D_WGRAD_ROWS=1 (opt-in: C x C weight gradients read the S16 rows of dy "
+                                "and of the layer input, ds_read_b64_tr_b16 transposes on the LDS read; the producers write "
+                                "no transposed copies for them)",
+                        "ms_per_step": dt_r / args.steps * 1e3, "frames_per_s": world * B * args.steps / dt_r,
+                        "speedup_vs_default": dt / dt_r}
+        except Exception as e:  # noqa: BLE001
+            rows_opt = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            os.environ["VP3D_WGRAD_ROWS"] = "0"
+
     out = {
         "metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -444,6 +461,8 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- the same step on the exact-fp32 MFMA kernels (every rank: the step holds collectives) -------------
+    if rows_opt is not None:
+        out["wgrad_rows_opt_in"] = rows_opt
     if math != "f32" and not args.no_f32:
         model, sync, step = build("f32")
         k32 = max(5, args.steps // 2)

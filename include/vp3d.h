@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 103
+#define VP3D_VERSION 104
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -240,6 +240,16 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
 int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                             const float* mean, const float* invstd, const uint8_t* act_bits, float keep_scale,
                             float* partials, int32_t* nparts);
+/* Weight gradient of a (strided) conv straight from S16 ROWS -- no transposed copies: the kernel transposes on the LDS
+ * read (ds_read_b64_tr_b16).  Replaces autograd's conv weight gradient (model.py:178-180 backward) like
+ * vp3d_tconv_nt_s16 in raw-partials mode does:
+ *   partials[s][co][tap*c_in + ci] = sum over the rows m of K-slice s of  dy[m][co] * x[m*taps + tap][ci]
+ * dy: [M][ld_dy] S16 (exponent of *dy_bound), x: [M*taps][ld_x] S16 (exponent of *x_bound; for a conv of stride == taps
+ * these are simply the rows of its input), partials: splits * c_out * taps*c_in floats, summed and un-packed by
+ * vp3d_wgrad_reduce(partials, taps*c_in, splits, c_out, c_in, taps, dw).  c_out, c_in % 256 == 0, operands < 2 GiB. */
+int vp3d_wgrad_rows_s16(vp3d_stream_t stream, int64_t M, const void* dy, int64_t ld_dy, int32_t c_out,
+                        const float* dy_bound, const void* x, int64_t ld_x, int32_t taps, int32_t c_in,
+                        const float* x_bound, int32_t splits, float* partials);
 /* fp32 rows -> S16 rows (out, may be NULL) and / or the transposed S16 copy (t_out, may be NULL; taps = 1) */
 int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,
                  void* out, int64_t ld_out, void* t_out, int64_t ld_t);

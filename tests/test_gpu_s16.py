@@ -360,3 +360,42 @@ def test_s16_backward_bucket_exchange_through_rccl_single_rank():
                 assert torch.equal(pa.grad, pb.grad), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b,t,c_out,c_in,taps", [(8, 9, 256, 256, 3), (5, 13, 512, 256, 1), (64, 27, 256, 512, 3)])
+def test_wgrad_from_rows_vs_fp64(b, t, c_out, c_in, taps):
+    """vp3d_wgrad_rows_s16 (weight gradient straight from the S16 rows of dy and of the conv input, transposing on the
+    LDS read) against an fp64 reference on the decoded operands, for ragged row counts (K tail of the 32-row tiles),
+    several K-slices, strided (taps = 3) and 1x1 convs."""
+    g = torch.Generator().manual_seed(21)
+    dy = (torch.randn(b, t, c_out, generator=g) * 3e-4).to(DEV)
+    x = torch.relu(torch.randn(b, t * taps, c_in, generator=g)).to(DEV)
+    dys, xs = S.split(dy), S.split(x)
+    dw = S.wgrad_rows(dys, xs, c_out, c_in, taps)
+    assert dw.shape == (c_out, c_in, taps)
+    dd, xd = S.join(dys).double().reshape(b * t, c_out), S.join(xs).double().reshape(b * t, taps, c_in)
+    ref = torch.einsum("mo,mki->oik", dd, xd)
+    den = torch.einsum("mo,mki->oik", dd.abs(), xd.abs())
+    assert float(((dw.double() - ref).abs() / (den + 1e-30)).max()) < GEMM_TOL
+
+
+def test_model_gradients_with_rows_form_wgrad(monkeypatch):
+    """VP3D_WGRAD_ROWS=1: the C x C weight gradients come from vp3d_wgrad_rows_s16 and no transposed copies are written
+    for them; every gradient matches the default (transposed-copy) path up to summation order."""
+    import copy
+    from videopose3d_amd import engine_s16
+    torch.manual_seed(4)
+    m_a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.25, channels=256).to(DEV).train()
+    m_b = copy.deepcopy(m_a)
+    for m in (m_a, m_b):
+        m.math = "f16x3"
+        m._drop_seed, m._drop_calls = 31, 0
+    x = (torch.randn(48, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+    tgt = torch.randn(48, 1, 17, 3, device=DEV) * 0.3
+    torch.mean(torch.norm(m_a(x) - tgt, dim=3)).backward()
+    monkeypatch.setenv("VP3D_WGRAD_ROWS", "1")
+    assert engine_s16.wgrad_from_rows(256, 256)
+    y_b = m_b(x)
+    torch.mean(torch.norm(y_b - tgt, dim=3)).backward()
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert float((pa.grad - pb.grad).abs().max() / (pa.grad.abs().max() + 1e-30)) < 2e-5, k

@@ -82,6 +82,7 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vp3d_bn_bwd_apply_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp, _vp, _vp,
                                         _vp, _i64]),
+    "vp3d_wgrad_rows_s16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "vp3d_bn_bwd_reduce_bits": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _P(_i32)]),
     "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
@@ -139,8 +140,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 103:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (103); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 104:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (104); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

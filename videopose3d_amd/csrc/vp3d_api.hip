@@ -255,6 +255,13 @@ int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound) {
   return launch_amax((hipStream_t)stream, n, src, bound);
 }
 
+int vp3d_wgrad_rows_s16(vp3d_stream_t stream, int64_t M, const void* dy, int64_t ld_dy, int32_t c_out,
+                        const float* dy_bound, const void* x, int64_t ld_x, int32_t taps, int32_t c_in,
+                        const float* x_bound, int32_t splits, float* partials) {
+  return launch_wgrad_rows_s16((hipStream_t)stream, M, (const float*)dy, ld_dy, c_out, dy_bound, (const float*)x, ld_x, taps,
+                               c_in, x_bound, splits, partials);
+}
+
 int vp3d_tconv_dgrad(vp3d_stream_t stream, const vp3d_rowmap* map, const float* dy, int32_t lddy, int32_t c_out,
                      const float* wt, int32_t ldw, int32_t w_tap_stride, int32_t n_out, float* dx,
                      int64_t dx_bpitch, int32_t lddx, const vp3d_epilogue* epi, const float* zeros, float* splitk_ws,

@@ -796,6 +796,161 @@ __global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict
   if (threadIdx.x == 0) s16_atomic_bound(bound, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_tn_s16: weight gradient from the S16 ROWS of dy and of the layer input (both k-major, k = row m), transposing on
+// the LDS read (ds_read_b64_tr_b16) instead of consuming producer-written transposed copies:
+//     part[split][na][tap*C_in + ci] = sum_{m in slice}  A[m][na] * B[m*taps + tap][ci]
+// A stage holds 32 rows x 256 channels of each operand: one 1-KiB LDS-DMA piece per row (whole 1-KiB runs of the 4-KB
+// HBM rows), rows at a 1040-byte LDS pitch.  Fragment of v_mfma_f32_32x32x16_f16 (lane = column lane % 32, k-half
+// lane / 32, 8 k values) = two transpose reads of 4 k each: per 16-lane group the 16 source addresses form a
+// [4 rows][16 channels] tile and lane i receives channel i of the four rows (measured semantics:
+// profiles/r01_tr_b16_probe.txt).  Rows per read: {0,1,8,9} + 2h (second read: + 4) of the 16-row k-step -- with the
+// pitch == 4 dwords (mod 64 banks) the four rows of a read fall on disjoint banks; the k order inside a step is a
+// permutation, the same for both operands, so the products pair up.  256x256 tile, 8 waves of 128x64, 2-stage ring.
+// Prototype measurements (tools/ubench/wgrad_tr.hip): 0.419 ms for M 27,648 x 1024 x 3072 (NT on copies: 0.438).
+// ---------------------------------------------------------------------------------------------------------
+typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+constexpr int TN_BM = 256, TN_BN = 256, TN_BK = 32, TN_NT = 512, TN_PITCH = 1040;
+constexpr int TN_OP_B = TN_BK * TN_PITCH, TN_STAGE_B = 2 * TN_OP_B, TN_SMEM_B = 2 * TN_STAGE_B;
+
+struct TnArgs {
+  const float* A;          // dy rows  [Mk][lda]   (S16, 4-byte units)
+  const float* B;          // x rows   [Mk*taps][ldb]
+  float* part;             // [splits][NA][NB]
+  const float* bound_a;
+  const float* bound_b;
+  int Mk, lda, ldb, NA, NB, taps, c_in;
+  uint32_t a_bytes, b_bytes;
+  int m_tiles, n_tiles, pos, splits, kt_per_split;
+};
+
+__device__ __forceinline__ f16x8 tn_frag(const char* p) {   // 8 k values of one column: two transpose reads, 4 rows apart
+  const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+  const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p + 4 * TN_PITCH));
+  const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+__global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
+  constexpr int RB = 4, CB = 2;
+  __shared__ __attribute__((aligned(16))) char smem[TN_SMEM_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / 4, wn = w % 4;
+  const int split = blockIdx.x / p.pos;
+  const int bid = blockIdx.x - split * p.pos;
+  int tile_m, tile_n;
+  if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos >> 3, tile_m, tile_n)) return;
+  const int na0 = tile_m * TN_BM, nb0 = tile_n * TN_BN;
+  const int tap = nb0 / p.c_in, ci0 = nb0 - tap * p.c_in;        // a column tile lies inside one tap (C_in % 256 == 0)
+  const int nkt_all = (p.Mk + TN_BK - 1) / TN_BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int nkt = max(0, min(nkt_all, kt_begin + p.kt_per_split) - kt_begin);
+
+  f32x16 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS-DMA: wave w owns rows 4w .. 4w+3 of both operands; rows >= Mk lie beyond num_records and arrive as zeros
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  int a_vo[4], b_vo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = (int64_t)kt_begin * TN_BK + w * 4 + i;
+    const int64_t ao = (r * p.lda + na0) * 4 + lane * 16, bo = ((r * p.taps + tap) * p.ldb + ci0) * 4 + lane * 16;
+    a_vo[i] = ao < (int64_t)p.a_bytes ? (int)ao : kOob;
+    b_vo[i] = bo < (int64_t)p.b_bytes ? (int)bo : kOob;
+  }
+  const int a_step = TN_BK * p.lda * 4, b_step = TN_BK * p.taps * p.ldb * 4;
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * TN_STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) blds16(rsA, a_vo[i], sA + (w * 4 + i) * TN_PITCH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) blds16(rsB, b_vo[i], sA + TN_OP_B + (w * 4 + i) * TN_PITCH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // (offsets past the end stay past the end: operands are < 2 GiB, kOob = 2^31)
+      a_vo[i] = (unsigned)a_vo[i] + (unsigned)a_step < 0x80000000u ? a_vo[i] + a_step : kOob;
+      b_vo[i] = (unsigned)b_vo[i] + (unsigned)b_step < 0x80000000u ? b_vo[i] + b_step : kOob;
+    }
+  };
+
+  const int g = lane >> 4, sl = lane & 15, h = g >> 1;
+  const int rsel = ((sl >> 2) & 1) + 8 * ((sl >> 3) & 1) + 2 * h;          // {0,1,8,9}[sl >> 2] + 2h
+  const int off_lane = rsel * TN_PITCH + (g & 1) * 64 + ((sl & 3) >> 1) * 32 + ((sl & 3) & 1) * 8;
+  const int a_off = wm * (RB * 32) * 4 + off_lane;
+  const int b_off = TN_OP_B + wn * (CB * 32) * 4 + off_lane;
+
+  if (nkt > 0) {
+    issue(0);
+    int st = 0;
+    for (int it = 0; it < nkt; ++it) {
+      wait_vmcnt<0>();
+      __syncthreads();
+      const char* sS = smem + st * TN_STAGE_B;
+      // All fragment reads of the tile first, THEN the LDS-DMA of the next tile (other stage), then the MFMAs: hipcc
+      // cannot prove that a transpose read does not alias an LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of
+      // the first read that follows one -- issued ahead of the reads (as k_nt_s16 does) the DMA would be waited for
+      // before this tile's compute instead of overlapping it.
+      f16x8 ah[2][RB], al[2][RB], bh[2][CB], bl[2][CB];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          ah[ks][i] = tn_frag(sS + a_off + i * 128 + ks * 16 * TN_PITCH);
+          al[ks][i] = tn_frag(sS + a_off + i * 128 + ks * 16 * TN_PITCH + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          bh[ks][j] = tn_frag(sS + b_off + j * 128 + ks * 16 * TN_PITCH);
+          bl[ks][j] = tn_frag(sS + b_off + j * 128 + ks * 16 * TN_PITCH + 16);
+        }
+      }
+      if (it + 1 < nkt) issue(st ^ 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+      }
+      st ^= 1;
+    }
+  }
+
+  // raw, scaled partial matrix of this K-slice (vp3d_wgrad_reduce sums the slices): 128-B runs per store
+  const float scale = s16_pow2(s16_exp_of(p.bound_a) + s16_exp_of(p.bound_b));
+  float* out = p.part + (int64_t)split * p.NA * p.NB;
+  const int hh = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        const int na = na0 + (wm * RB + i) * 32 + r, nb = nb0 + (wn * CB + j) * 32 + cl;
+        out[(int64_t)na * p.NB + nb] = acc[i][j][reg] * scale;
+      }
+}
+
 template <class C>
 int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m_end = -1) {
   a.m_begin = m_begin;
@@ -956,6 +1111,30 @@ int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int
   hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, groups, C / 8, src, ld_src,
                      dst, ld_dst, bound);
   return check_launch("split_rows");
+}
+
+// dW partials from S16 rows (k_tn_s16).  c_out, c_in multiples of 256; both operands below 2 GiB.
+int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld_dy, int32_t c_out, const float* dy_bound,
+                          const float* x, int64_t ld_x, int32_t taps, int32_t c_in, const float* x_bound, int32_t splits,
+                          float* part) {
+  const int64_t a_bytes = Mk * ld_dy * 4, b_bytes = Mk * taps * ld_x * 4;
+  VP3D_REQUIRE(Mk > 0 && dy && x && part && dy_bound && x_bound && taps >= 1 && c_out > 0 && c_in > 0 && c_out % 256 == 0 &&
+                   c_in % 256 == 0 && ld_dy >= c_out && ld_x >= c_in && ld_dy % 8 == 0 && ld_x % 8 == 0 && aligned16(dy) &&
+                   aligned16(x) && aligned16(part),
+               "wgrad_rows_s16: needs c_out, c_in %% 256 == 0 and 16-byte aligned S16 rows");
+  VP3D_REQUIRE(a_bytes < ((int64_t)1 << 31) && b_bytes < ((int64_t)1 << 31), "wgrad_rows_s16: operands must stay below 2 GiB");
+  const int nkt = (int)((Mk + TN_BK - 1) / TN_BK);
+  VP3D_REQUIRE(splits >= 1 && splits <= nkt, "wgrad_rows_s16: splits=%d for %d K-tiles", splits, nkt);
+  TnArgs a;
+  a.A = dy; a.B = x; a.part = part; a.bound_a = dy_bound; a.bound_b = x_bound;
+  a.Mk = (int)Mk; a.lda = (int)ld_dy; a.ldb = (int)ld_x; a.NA = c_out; a.NB = taps * c_in; a.taps = taps; a.c_in = c_in;
+  a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
+  a.m_tiles = c_out / TN_BM; a.n_tiles = a.NB / TN_BN;
+  a.pos = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);
+  a.splits = splits;
+  a.kt_per_split = (nkt + splits - 1) / splits;
+  hipLaunchKernelGGL(k_tn_s16, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
+  return check_launch("wgrad_rows_s16");
 }
 
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound) {

@@ -107,12 +107,20 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 # training (strided model)
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits")
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows")
 
-    def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits):
+    def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits, x_rows=None):
         self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
+        self.x_rows = x_rows      # rows-form wgrad (wgrad_from_rows): the layer input as S16 rows instead of x_t
         self.bits = bits          # activation bits ([bn(y) > 0 and kept], 1 bit / element): what backward reads instead
                                   # of regenerating the Philox mask
+
+
+def wgrad_from_rows(c_out: int, c_in: int) -> bool:
+    """Opt-in (VP3D_WGRAD_ROWS=1, round-1 status: validated against the default path, not yet the default): the C x C
+    weight gradients read the S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16) and the producers stop
+    writing transposed copies for them; the expand conv (K-padded im2row operand) keeps the transposed form."""
+    return os.environ.get("VP3D_WGRAD_ROWS", "0") == "1" and S.wgrad_rows_supported(c_out, c_in)
 
 
 def forward_train(mod, x3: torch.Tensor, save: bool):
@@ -141,9 +149,12 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     t_in0 = x3.shape[1]
     del xin
 
+    rows_form = [idx >= 1 and wgrad_from_rows(plan.convs[idx].c_out, plan.convs[idx].c_in) for idx in range(n_layers)]
+
     def next_taps(idx):
-        """taps of the conv that consumes the activation of layer idx (its wgrad reduces over the transposed copy)."""
-        return plan.convs[idx + 1].taps if idx + 1 < n_layers else 0
+        """taps of the conv that consumes the activation of layer idx (its wgrad reduces over the transposed copy);
+        0: no consumer, or a consumer whose wgrad reads the rows themselves."""
+        return plan.convs[idx + 1].taps if idx + 1 < n_layers and not rows_form[idx + 1] else 0
 
     # per-step prologue for ALL layers, one launch each: weight maxima -> S16 weight packs; activation bounds
     ws = [c.weight.detach() for c in convs]
@@ -180,7 +191,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
             if use_bits:
                 bits = bits_all[bits_at:bits_at + m_rows * spec.c_out // 8]
                 bits_at += bits.numel()
-            saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0, bits))
+            saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0, bits,
+                                x_rows=a if rows_form[idx] else None))
         if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:
@@ -259,7 +271,10 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             o_g = o_bt = None
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
                                             out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0,   # expand: no dgrad
-                                            sync=mod.__dict__.get("_vp3d_sync_bn"), act_bits=s.bits)
+                                            sync=mod.__dict__.get("_vp3d_sync_bn"), act_bits=s.bits,
+                                            want_t=s.x_rows is None)
+        if s.x_rows is not None:
+            dy_t = dy                                # rows-form wgrad reads the rows
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
         return dy, dy_t
@@ -270,18 +285,23 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         out = view(convs[idx].weight)
         n_cols = L[idx].kpad if L[idx].kpad else spec.taps * spec.c_in
         m_rows = L[idx].y.shape[0] * L[idx].y.shape[1]
+
+        def gemm():
+            if L[idx].x_rows is not None:
+                return S.wgrad_rows(dy_t, L[idx].x_rows, spec.c_out, spec.c_in, spec.taps, out=out)
+            return S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
         if side is not None and on_side:
             # nothing inside backward consumes dW: it runs beside the next layer's HBM-bound BatchNorm-backward kernels
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                dw = S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
+                dw = gemm()
             if out is None:
                 dw.record_stream(main)
-            keep.append((dy_t, L[idx].x_t, dw))
+            keep.append((dy_t, L[idx].x_t, L[idx].x_rows, dw))
         else:
-            dw = S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
+            dw = gemm()
         grads[3 * idx] = sunk(dw, out)
 
     def dgrad(idx, dy, residual, amax_out):

@@ -172,6 +172,47 @@ def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, ou
     return out
 
 
+def wgrad_rows_supported(c_out: int, c_in: int) -> bool:
+    return c_out % 256 == 0 and c_in % 256 == 0
+
+
+def _wgrad_rows_splits(m_rows: int, c_out: int, n_cols: int) -> int:
+    """K-slices of the 256x256 rows-form wgrad GEMM: the S16 planner's 256x256 cost terms (plan_nt_s16)."""
+    tiles, nkt = (c_out // 256) * (n_cols // 256), (m_rows + 31) // 32
+    best, best_s = None, 1
+    for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+        if s > 1 and nkt // s < 6:
+            break
+        wgs = tiles * s
+        per_cu, nk = (wgs + 255) // 256, (nkt + s - 1) // s
+        rate = 2.22 if per_cu >= 2 else 1.68 + 0.54 * min(1.0, wgs / 256.0)
+        cost = per_cu * (nk * rate + 8.3) + s * c_out * n_cols * 4.0 / 7.4e6
+        if best is None or cost < best * 0.98:
+            best, best_s = cost, s
+    return best_s
+
+
+def wgrad_rows(dy: S16, x: S16, c_out: int, c_in: int, taps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [c_out, c_in, taps] (reference layout) from the S16 ROWS dy [.., c_out] (M rows) and x [.., c_in] (M*taps rows:
+    the input rows of a conv of stride == taps): vp3d_wgrad_rows_s16 transposes on the LDS read, so no transposed copies
+    of either operand are needed; split-K partials are summed and un-packed by vp3d_wgrad_reduce."""
+    dd, xd = dy.data, x.data
+    m = dd.numel() // c_out
+    assert dd.shape[-1] == c_out and xd.shape[-1] == c_in and xd.numel() // c_in == m * taps, (dd.shape, xd.shape, taps)
+    dev = dd.device
+    n_cols = taps * c_in
+    splits = _wgrad_rows_splits(m, c_out, n_cols)
+    ws = torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dev)
+    ops._timed_call("tconv_wgrad", 2.0 * m * c_out * n_cols, _lib.lib().vp3d_wgrad_rows_s16, ops._stream(), m, dd.data_ptr(),
+                    c_out, c_out, dy.bound_ptr(), xd.data_ptr(), c_in, taps, c_in, x.bound_ptr(), splits, ws.data_ptr(),
+                    nbytes=4.0 * (dd.numel() + xd.numel() + c_out * n_cols))
+    if out is None:
+        out = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dev)
+    check(_lib.lib().vp3d_wgrad_reduce(ops._stream(), ws.data_ptr(), n_cols, splits, c_out, c_in, taps, out.data_ptr()),
+          "vp3d_wgrad_reduce")
+    return out
+
+
 def t_pitch(m_rows: int, taps: int = 1) -> int:
     return (m_rows // taps + 63) // 64 * 64
 
@@ -245,7 +286,7 @@ def new_act_bits(m_rows: int, c: int, device) -> torch.Tensor:
 
 def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
                dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True, sync=None,
-               act_bits: Optional[torch.Tensor] = None):
+               act_bits: Optional[torch.Tensor] = None, want_t: bool = True):
     """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows [None unless want_rows: only dgrad reads them],
     dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy.  With the forward's
     act_bits the two passes read the mask / ReLU predicate (1 bit per element) instead of regenerating them."""
@@ -286,13 +327,14 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
         check(L.vp3d_dy_bound(ops._stream(), c, sync.rows_total(m), sc, (a_g / sync.frac).contiguous().data_ptr(),
                               (a_b / sync.frac).contiguous().data_ptr(), go_bound.data_ptr(), float(p), dy_bound.data_ptr()),
               "vp3d_dy_bound")
+    assert want_rows or want_t
     dy = torch.empty_like(y) if want_rows else None
-    dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device)
+    dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device) if want_t else None   # (wgrad_rows needs none)
     check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, ops._p(act_bits),
-                                  a_g.data_ptr(), a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), dyt.data_ptr(),
-                                  dyt.shape[1]),
+                                  a_g.data_ptr(), a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), ops._p(dyt),
+                                  dyt.shape[1] if dyt is not None else 0),
           "vp3d_bn_bwd_apply_s16")
-    return (S16(dy, dy_bound) if dy is not None else None), S16(dyt, dy_bound), dgam, dbet
+    return (S16(dy, dy_bound) if dy is not None else None), (S16(dyt, dy_bound) if dyt is not None else None), dgam, dbet
 
 
 def join(x: S16) -> torch.Tensor:
