@@ -245,8 +245,8 @@ static float run(int Mk, int NA, int taps, int c_in, int splits, bool check) {
     CK(hipMemcpy(hP.data(), part, hP.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0.0;
     int bad = 0;
-    for (int na = 0; na < NA; na += 3)
-      for (int nb = 0; nb < NB; nb += 5) {
+    for (int na = 0; na < NA; na += (NA > 512 ? 13 : 3))
+      for (int nb = 0; nb < NB; nb += (NB > 2048 ? 17 : 5)) {
         const int tap = nb / c_in, ci = nb % c_in;
         double ref = 0.0, den = 0.0;
         for (int m = 0; m < Mk; ++m) {
@@ -271,7 +271,11 @@ static float run(int Mk, int NA, int taps, int c_in, int splits, bool check) {
   return best;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {                          // "./wgrad_tr big": correctness at the step's tile geometry (4 x 12 tiles, 16 K-slices)
+    run(2000, 1024, 3, 1024, 16, true);
+    return 0;
+  }
   run(200, 256, 2, 256, 2, true);          // ragged K (200 rows), two taps, two K-slices
   run(1000, 512, 3, 512, 3, true);
   for (int s : {8, 16, 24}) run(27648, 1024, 3, 1024, s, false);      // first block's strided conv (NT today: 438 us)
