@@ -2,7 +2,6 @@
 pass, ragged shapes, epilogues, BatchNorm slab statistics, amax), the S16 producers (row split, transposed copies,
 weight packs, activation forward / backward) and the device-side bounds -- against fp64 references built with torch on
 the CPU/GPU.  Tolerance of the GEMM: |err| <= 1e-6 * sum|a||b| (22+ bit operands; the fp32-MFMA kernel sits at ~1e-7)."""
-import numpy as np
 import pytest
 import torch
 

@@ -7,7 +7,6 @@ import pytest
 import torch
 
 from oracle import step_oracle as S
-from oracle import temporal_oracle as O
 from tests.util import (GEN_CASES, GOLDEN, JOINTS_LEFT, JOINTS_RIGHT, KPS_LEFT, KPS_RIGHT, gen_case_meta,
                         load_npz_groups, load_step_dataset, mpjpe_np, rel_err)
 

@@ -3,7 +3,6 @@ loud failure without a GPU."""
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videopose3d_amd import ops
-from videopose3d_amd.plan import ConvSpec, ResSpec
+from videopose3d_amd.plan import ConvSpec
 dev = "cuda:0"
 C = 1024
 

@@ -3,7 +3,6 @@ forward activation producer, BatchNorm-backward reduce + apply, with the dropout
 the forward's activation bits.  GB/s = algorithmic bytes (every operand once) / time."""
 import os
 import sys
-import time
 
 import torch
 

@@ -17,7 +17,6 @@ Differences a caller sees (INTEGRATION.md shows the two-line run.py change):
 from __future__ import annotations
 
 import ctypes as C
-from itertools import zip_longest
 from typing import Optional, Sequence, Tuple
 
 import numpy as np

@@ -11,7 +11,6 @@ checkpoints (run.py:600-608) load into it and its checkpoints load into ``torch.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
 
 import torch
 

@@ -7,7 +7,7 @@ slices of ``_forward_blocks`` (:132 crop, :191 strided pick) as data that the en
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List
 
 
 @dataclass(frozen=True)
