@@ -162,7 +162,7 @@ def make_semi():
     loss, back-projection through project_to_2d, bone-length term), reference classes on CPU."""
     torch.manual_seed(11)
     gen = torch.Generator().manual_seed(111)
-    fw, C, B = [3, 3, 3], 32, 6
+    fw, C, B = [3, 3, 3], 64, 6
     pos = TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=C)
     traj = TemporalModelOptimized1f(17, 2, 1, fw, dropout=0.0, channels=C)
     pad = (pos.receptive_field() - 1) // 2
@@ -210,7 +210,7 @@ def make_train_loop():
     BN-momentum decay, then the train->eval state_dict hand-off (run.py:426) and an eval forward."""
     torch.manual_seed(21)
     gen = torch.Generator().manual_seed(211)
-    fw, C, B = [3, 3, 3], 32, 12
+    fw, C, B = [3, 3, 3], 64, 12
     tr = TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=C)
     ev = TemporalModel(17, 2, 17, fw, dropout=0.0, channels=C)
     out = {}
@@ -245,22 +245,53 @@ def make_train_loop():
     print("wrote train_loop losses", losses)
 
 
+CASES = [
+    # name, kind, filter widths, causal, channels, extra keyword arguments of make_case
+    ("dil_333_c32", "dilated", [3, 3, 3], False, 32, dict(extra_t=11)),
+    ("dil_333_c32_causal", "dilated", [3, 3, 3], True, 32, dict(extra_t=5, seed=1)),
+    ("dil_33333_c32", "dilated", [3, 3, 3, 3, 3], False, 32, dict(batch=2, extra_t=7, seed=2)),
+    ("dil_353_c48_dense", "dilated", [3, 5, 3], False, 48, dict(dense=True, extra_t=4, seed=3)),
+    ("dil_333_c32_traj", "dilated", [3, 3, 3], False, 32, dict(j_out=1, seed=4, extra_t=2)),
+    ("dil_333_c32_drop", "dilated", [3, 3, 3], False, 32, dict(dropout=0.25, extra_t=3, seed=5)),
+    ("str_333_c32", "strided", [3, 3, 3], False, 32, dict(batch=5)),
+    ("str_333_c32_causal", "strided", [3, 3, 3], True, 32, dict(batch=4, seed=1)),
+    ("str_33333_c32", "strided", [3, 3, 3, 3, 3], False, 32, dict(batch=4, seed=2, momentum=0.03)),
+    ("str_353_c48_j15", "strided", [3, 5, 3], False, 48, dict(j_in=15, batch=6, seed=3)),
+    ("str_333_c32_drop", "strided", [3, 3, 3], False, 32, dict(dropout=0.25, batch=8, seed=5)),
+    ("str_333_c128", "strided", [3, 3, 3], False, 128, dict(batch=16, seed=6)),
+    ("dil_333_c128", "dilated", [3, 3, 3], False, 128, dict(batch=2, extra_t=30, seed=6)),
+    # round 2: channel counts the split-fp16 engine accepts (C % 64 == 0), so that the "f16x3" half of the GPU parity
+    # suite executes k_nt_s16 / the S16 producers on reference-generated vectors: both arcs x causal x {64, 128},
+    # dropout masks, the trajectory model (J_out = 1), a width-5 arc, and the dilated class (training + eval)
+    ("str_333_c64", "strided", [3, 3, 3], False, 64, dict(batch=12, seed=0)),
+    ("str_333_c64_causal", "strided", [3, 3, 3], True, 64, dict(batch=10, seed=1)),
+    ("str_33333_c64", "strided", [3, 3, 3, 3, 3], False, 64, dict(batch=6, seed=2)),
+    ("str_33333_c64_causal", "strided", [3, 3, 3, 3, 3], True, 64, dict(batch=6, seed=0, momentum=0.03)),
+    ("str_333_c128_causal", "strided", [3, 3, 3], True, 128, dict(batch=16, seed=1)),
+    ("str_33333_c128_causal", "strided", [3, 3, 3, 3, 3], True, 128, dict(batch=8, seed=2)),
+    ("str_333_c64_drop", "strided", [3, 3, 3], False, 64, dict(dropout=0.25, batch=16, seed=5)),
+    ("str_333_c64_causal_drop", "strided", [3, 3, 3], True, 64, dict(dropout=0.25, batch=16, seed=7)),
+    ("str_333_c64_traj", "strided", [3, 3, 3], False, 64, dict(j_out=1, batch=8, seed=4)),
+    ("str_353_c64", "strided", [3, 5, 3], False, 64, dict(batch=6, seed=3)),
+    ("dil_333_c64", "dilated", [3, 3, 3], False, 64, dict(batch=3, extra_t=9, seed=0)),
+    ("dil_333_c64_causal", "dilated", [3, 3, 3], True, 64, dict(batch=3, extra_t=6, seed=1)),
+    ("dil_33333_c64_causal", "dilated", [3, 3, 3, 3, 3], True, 64, dict(batch=2, extra_t=5, seed=2)),
+    ("dil_333_c64_drop", "dilated", [3, 3, 3], False, 64, dict(dropout=0.25, batch=3, extra_t=4, seed=5)),
+    ("dil_353_c64_dense", "dilated", [3, 5, 3], False, 64, dict(dense=True, batch=2, extra_t=3, seed=3)),
+]
+EXTRA = {"kat": make_kat, "camera": make_camera, "semi_step": make_semi, "train_loop": make_train_loop}
+
+
 if __name__ == "__main__":
+    # python tests/golden/make_golden.py            -> everything
+    # python tests/golden/make_golden.py NAME ...   -> only the named fixtures (case names, kat, camera, semi_step, train_loop)
     torch.set_num_threads(4)
-    make_case("dil_333_c32", "dilated", [3, 3, 3], False, 32, extra_t=11)
-    make_case("dil_333_c32_causal", "dilated", [3, 3, 3], True, 32, extra_t=5, seed=1)
-    make_case("dil_33333_c32", "dilated", [3, 3, 3, 3, 3], False, 32, batch=2, extra_t=7, seed=2)
-    make_case("dil_353_c48_dense", "dilated", [3, 5, 3], False, 48, dense=True, extra_t=4, seed=3)
-    make_case("dil_333_c32_traj", "dilated", [3, 3, 3], False, 32, j_out=1, seed=4, extra_t=2)
-    make_case("dil_333_c32_drop", "dilated", [3, 3, 3], False, 32, dropout=0.25, extra_t=3, seed=5)
-    make_case("str_333_c32", "strided", [3, 3, 3], False, 32, batch=5)
-    make_case("str_333_c32_causal", "strided", [3, 3, 3], True, 32, batch=4, seed=1)
-    make_case("str_33333_c32", "strided", [3, 3, 3, 3, 3], False, 32, batch=4, seed=2, momentum=0.03)
-    make_case("str_353_c48_j15", "strided", [3, 5, 3], False, 48, j_in=15, batch=6, seed=3)
-    make_case("str_333_c32_drop", "strided", [3, 3, 3], False, 32, dropout=0.25, batch=8, seed=5)
-    make_case("str_333_c128", "strided", [3, 3, 3], False, 128, batch=16, seed=6)
-    make_case("dil_333_c128", "dilated", [3, 3, 3], False, 128, batch=2, extra_t=30, seed=6)
-    make_kat()
-    make_camera()
-    make_semi()
-    make_train_loop()
+    want = set(sys.argv[1:])
+    known = {c[0] for c in CASES} | set(EXTRA)
+    assert want <= known, sorted(want - known)
+    for name, kind, fw, causal, channels, kw in CASES:
+        if not want or name in want:
+            make_case(name, kind, fw, causal, channels, **kw)
+    for name, fn in EXTRA.items():
+        if not want or name in want:
+            fn()

@@ -10,21 +10,10 @@ from oracle import step_oracle as S
 from tests.util import (GEN_CASES, GOLDEN, JOINTS_LEFT, JOINTS_RIGHT, KPS_LEFT, KPS_RIGHT, gen_case_meta,
                         load_npz_groups, load_step_dataset, mpjpe_np, rel_err)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("math_mode")]       # tests/conftest.py: once per GEMM arithmetic
 
 
-@pytest.fixture(autouse=True, params=["f16x3", "f32"])
-def math_mode(request):
-    """Every test of this module runs once per GEMM arithmetic: "f16x3" (split-fp16 MFMA wherever engine_s16 supports
-    the configuration, fp32 elsewhere) and "f32" (fp32 MFMA everywhere) -- same oracle, same tolerances."""
-    import videopose3d_amd as _V
-    from videopose3d_amd import engine as _E
-    keep = dict(_E.S16_MIN_FORWARD_FLOPS)
-    _E.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})     # the small test models must not fall below the
-    _V.set_default_math(request.param)                            # engine's "big enough to be compute-bound" threshold
-    yield request.param
-    _V.set_default_math(None)
-    _E.S16_MIN_FORWARD_FLOPS.update(keep)
+ONCE = pytest.mark.single_arithmetic          # index / byte / loss / optimizer kernels: no GEMM arithmetic involved
 DEV = "cuda:0"
 
 
@@ -47,6 +36,7 @@ def _make_gen(m, cams, p3, p2, **kw):
                             joints_right=JOINTS_RIGHT, device=DEV, **kw)
 
 
+@ONCE
 @pytest.mark.parametrize("name", GEN_CASES)
 def test_chunked_generator_bit_exact_vs_reference(name):
     z, cams, p3, p2 = load_step_dataset()
@@ -68,6 +58,7 @@ def test_chunked_generator_bit_exact_vs_reference(name):
     assert b == m["n"]
 
 
+@ONCE
 def test_chunked_generator_endless_and_random_state():
     from videopose3d_amd.generators import ChunkedGenerator
     z, cams, p3, p2 = load_step_dataset()
@@ -87,20 +78,26 @@ def test_chunked_generator_endless_and_random_state():
     assert c.random_state() is c.random
 
 
+@ONCE
 def test_chunked_generator_shards_partition_every_batch():
+    from videopose3d_amd import dp
     z, cams, p3, p2 = load_step_dataset()
     m = gen_case_meta(z, "c1")
     full = [tuple(t.clone() for t in b) for b in _make_gen(m, cams, p3, p2).next_epoch()]
     world = 3
     parts = [list(_make_gen(m, cams, p3, p2, shard=(r, world)).next_epoch()) for r in range(world)]
-    for k, (cam, b3, b2) in enumerate(full):
+    kept = [k for k, b in enumerate(full) if dp.shardable(b[2].shape[0], world)]
+    assert len(kept) >= len(full) - 1 and all(len(p) == len(kept) for p in parts)    # only a short last batch may go
+    for j_kept, k in enumerate(kept):
+        cam, b3, b2 = full[k]
         for j, ref in enumerate((cam, b3, b2)):
-            got = torch.cat([parts[r][k][j] for r in range(world) if parts[r][k][j] is not None])
+            got = torch.cat([parts[r][j_kept][j] for r in range(world)])
             assert torch.equal(got, ref), (k, j)
-        sizes = [parts[r][k][2].shape[0] for r in range(world)]
-        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == b2.shape[0]
+        sizes = [parts[r][j_kept][2].shape[0] for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == b2.shape[0] and min(sizes) >= dp.MIN_SHARD
 
 
+@ONCE
 def test_unchunked_generator_bit_exact_vs_reference():
     from videopose3d_amd.generators import UnchunkedGenerator
     z, cams, p3, p2 = load_step_dataset()
@@ -120,6 +117,7 @@ def test_unchunked_generator_bit_exact_vs_reference():
     assert next(iter(u.next_epoch()))[2].shape[0] == 2
 
 
+@ONCE
 def test_gather_full_size_batch_vs_oracle():
     """BASELINE-size batch (B=1024 windows of 243 frames): the device gather vs the numpy restatement."""
     from videopose3d_amd.generators import ChunkedGenerator
@@ -141,6 +139,7 @@ def test_gather_full_size_batch_vs_oracle():
 # ---------------------------------------------------------------------------------------------------------
 # loss + TTA
 # ---------------------------------------------------------------------------------------------------------
+@ONCE
 def test_mpjpe_vs_reference_golden():
     from videopose3d_amd.loss import mpjpe, weighted_mpjpe
     z = np.load(GOLDEN + "/step_loss.npz")
@@ -173,6 +172,7 @@ def test_mpjpe_vs_reference_golden():
         assert abs(float(mpjpe(_t(z["pos/p"]), _t(z["pos/t"]))) - float(z["pos/loss"])) < 1e-6
 
 
+@ONCE
 def test_mpjpe_rejects_cpu_tensors():
     from videopose3d_amd import Vp3dError
     from videopose3d_amd.loss import mpjpe
@@ -180,6 +180,7 @@ def test_mpjpe_rejects_cpu_tensors():
         mpjpe(torch.zeros(2, 1, 17, 3), torch.zeros(2, 1, 17, 3))
 
 
+@ONCE
 def test_tta_average_vs_reference_golden():
     from videopose3d_amd.generators import tta_average
     z = np.load(GOLDEN + "/step_loss.npz")
@@ -198,6 +199,7 @@ def _adam_params(z):
     return [torch.nn.Parameter(_t(z["p0_%d" % i])) for i in range(int(z["n_params"]))]
 
 
+@ONCE
 def test_flat_adam_vs_torch_optim_golden():
     from videopose3d_amd.optim import FlatAdam
     z = np.load(GOLDEN + "/step_adam.npz")
@@ -224,6 +226,7 @@ def test_flat_adam_vs_torch_optim_golden():
         assert rel_err(_np(st["max_exp_avg_sq"]), z["vmax_%d" % i]) < 1e-6
 
 
+@ONCE
 def test_flat_adam_checkpoint_round_trip_with_torch_adam():
     """run.py:600-608 saves optimizer.state_dict(); run.py:262-263 loads it back."""
     from videopose3d_amd.optim import FlatAdam
@@ -301,8 +304,8 @@ def test_fused_training_loop_vs_reference_golden():
     from videopose3d_amd.optim import FlatAdam
     g = load_npz_groups("train_loop")
     fw = [3, 3, 3]
-    tr = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=32)
-    ev = V.TemporalModel(17, 2, 17, fw, dropout=0.0, channels=32)
+    tr = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=64)
+    ev = V.TemporalModel(17, 2, 17, fw, dropout=0.0, channels=64)
     tr.load_state_dict({k: torch.from_numpy(v) for k, v in g["sd0"].items()})
     tr, ev = tr.to(DEV), ev.to(DEV)
     xs, ys = _t(g["xs"]), _t(g["ys"])

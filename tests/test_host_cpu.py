@@ -203,3 +203,72 @@ def test_rows_form_wgrad_split_choice_is_launchable():
     assert S._wgrad_rows_splits(27648, 1024, 3072) == 16        # 48 tiles x 16 slices = 3 rounds (measured best)
     assert S._wgrad_rows_splits(27648, 1024, 1024) == 16        # 16 tiles x 16 slices = 1 round
     assert S.wgrad_rows_supported(1024, 1024) and not S.wgrad_rows_supported(1024, 128)
+
+
+def test_common_model_shadow_import_resolves_as_integration_md_says(tmp_path):
+    """INTEGRATION.md section 2 (option A): with <repo>/videopose3d_amd ahead of a VideoPose3D checkout on sys.path,
+    run.py:21's ``from common.model import *`` must bind OUR classes while every other ``common.*`` module still comes
+    from the checkout.  The checkout is a stand-in tree here (plus the real /root/reference when it exists)."""
+    import subprocess
+    import sys
+    fake = tmp_path / "VideoPose3D"
+    (fake / "common").mkdir(parents=True)
+    (fake / "common" / "generators.py").write_text("WHO = 'reference generators'\n")
+    (fake / "common" / "loss.py").write_text("WHO = 'reference loss'\n")
+    (fake / "common" / "model.py").write_text("raise ImportError('the reference model module must be shadowed')\n")
+    code = ("from common.model import *\n"
+            "import common.model, common.generators, common.loss, videopose3d_amd.model as M\n"
+            "assert TemporalModel is M.TemporalModel and TemporalModelOptimized1f is M.TemporalModelOptimized1f\n"
+            "assert TemporalModelBase is M.TemporalModelBase\n"
+            "print(common.model.__file__); print(common.generators.__file__); print(common.loss.__file__)\n")
+    trees = [str(fake)] + (["/root/reference"] if os.path.exists("/root/reference/common/generators.py") else [])
+    for tree in trees:
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "videopose3d_amd"), ROOT, tree]))
+        r = subprocess.run([sys.executable, "-c", code], cwd=tree, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        mod, gen, loss = r.stdout.strip().splitlines()[-3:]
+        assert os.path.samefile(mod, os.path.join(ROOT, "videopose3d_amd", "common", "model.py"))
+        assert os.path.samefile(gen, os.path.join(tree, "common", "generators.py"))
+        assert os.path.samefile(loss, os.path.join(tree, "common", "loss.py"))
+
+
+def test_sharded_generator_drops_a_last_batch_that_cannot_feed_every_rank():
+    """A short last batch (generators.py:57,104) that would leave a rank with 0 or 1 samples is dropped on ALL ranks of a
+    sharded generator (a rank without a batch would skip backward and with it the gradient collectives; one sample
+    cannot pass training-mode BatchNorm at T_out = 1); anything larger is split into contiguous balanced slices."""
+    from videopose3d_amd import dp
+    from videopose3d_amd.generators import ChunkedGenerator
+    assert dp.shardable(16, 8) and not dp.shardable(15, 8) and dp.shardable(2, 1) and not dp.shardable(1, 1)
+    g = ChunkedGenerator.__new__(ChunkedGenerator)        # row arithmetic only: no device, no dataset
+    g.batch_size = 1024
+    n_pairs = 3 * 1024 + 11                               # last batch: 11 chunks
+    for world in (1, 2, 4, 8):
+        spans = []
+        for rank in range(world):
+            g.shard = (rank, world)
+            assert g._batch_rows(1, n_pairs) == tuple(1024 + v for v in dp.shard_bounds(1024, rank, world))
+            spans.append(g._batch_rows(3, n_pairs))
+        if 11 >= 2 * world:
+            assert spans[0][0] == 3072 and spans[-1][1] == n_pairs
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and min(b - a for a, b in spans) >= 2
+        else:
+            assert spans == [None] * world                # dropped everywhere, never on some ranks only
+    g.shard = None
+    assert g._batch_rows(3, n_pairs) == (3072, n_pairs)   # the unsharded generator keeps the reference's short batch
+
+
+def test_direct_gradient_sink_refuses_a_second_backward_pass():
+    """FlatGradSync(direct_module=...) overwrites gradients: two backward passes between zero_grad() calls must raise
+    instead of silently dropping the first pass (also with world == 1, where no collective would notice)."""
+    from videopose3d_amd import dp
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=32)
+    sync = dp.FlatGradSync(m.parameters(), world=1, direct_module=m)
+    n_groups = len(m.backward_param_groups())
+    for _ in range(2):
+        sync.zero_grad()
+        for k in range(n_groups):
+            sync.group_done(k)
+    with pytest.raises(V.Vp3dError):
+        sync.group_done(0)
+    sync.zero_grad()
+    sync.group_done(0)

@@ -78,3 +78,12 @@ def gen_case_meta(z, name):
     bs, cl, pad, shift, aug, shuf, cams, nb, nf = (int(v) for v in z[name + "/meta"])
     return dict(batch_size=bs, chunk_length=cl, pad=pad, causal_shift=shift, augment=bool(aug), shuffle=bool(shuf),
                 cams=bool(cams), num_batches=nb, num_frames=nf, n=int(z[name + "/n"]))
+
+
+def s16_or_skip(mode, model, t_in, training, need_dx=False):
+    """Under the f16x3 id a configuration the split-fp16 engine does not implement is skipped, not silently re-run on
+    the fp32 kernels (it is covered under the f32 id)."""
+    import pytest
+    from videopose3d_amd import engine
+    if mode == "f16x3" and not engine.use_s16(model, t_in, training, need_dx):
+        pytest.skip("engine_s16.supported() rejects this configuration: covered under the f32 id")

@@ -1,7 +1,6 @@
 """ctypes binding of libvp3d.so (C ABI declared in include/vp3d.h).
 
-The library is hand-written HIP for gfx950 and is built in-tree by ``__graft_entry__.build()`` /
-``python -m videopose3d_amd.build``.  There is NO fallback: if the shared object is missing or a call
+The library is hand-written HIP for gfx950 and is built in-tree by ``__graft_entry__.build()`` (``python __graft_entry__.py``).  There is NO fallback: if the shared object is missing or a call
 fails, an exception is raised -- the product path never silently routes around the HIP kernels.
 """
 from __future__ import annotations

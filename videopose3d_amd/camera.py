@@ -26,6 +26,7 @@ class _ProjectFn(torch.autograd.Function):
                                                 out.data_ptr()), "vp3d_project_to_2d_fwd")
         ctx.save_for_backward(Xc, camc)
         ctx.linear = int(linear)
+        ctx.x_dtype = X.dtype
         return out
 
     @staticmethod
@@ -37,7 +38,7 @@ class _ProjectFn(torch.autograd.Function):
         dX = torch.empty_like(Xc)
         check(_lib.lib().vp3d_project_to_2d_bwd(_stream(), n, ppc, Xc.data_ptr(), camc.data_ptr(), g.data_ptr(),
                                                 ctx.linear, dX.data_ptr()), "vp3d_project_to_2d_bwd")
-        return dX, None, None
+        return dX.to(ctx.x_dtype), None, None
 
 
 def _project(X, camera_params, linear):
@@ -47,6 +48,9 @@ def _project(X, camera_params, linear):
     assert X.shape[0] == camera_params.shape[0]
     if not X.is_cuda:
         raise _lib.Vp3dError("project_to_2d: the HIP path needs CUDA/HIP tensors (no CPU fallback)")
+    if not camera_params.is_cuda or camera_params.device != X.device:
+        raise _lib.Vp3dError("project_to_2d: camera_params is on %s but X is on %s (the kernel reads both by device "
+                             "pointer)" % (camera_params.device, X.device))
     with torch.cuda.device(X.device):
         return _ProjectFn.apply(X, camera_params, linear)
 

@@ -36,6 +36,16 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+MIN_SHARD = 2            # training-mode BatchNorm needs more than one row per channel (T_out = 1: rows == samples)
+
+
+def shardable(n_items: int, world: int) -> bool:
+    """True when a global batch of n_items gives EVERY rank at least MIN_SHARD samples.  The short last batch of an
+    epoch (generators.py:57,104) may not: sharded generators drop such a batch on all ranks alike (a rank with 0 or 1
+    samples cannot run the training step, and a rank that skips backward must not skip the collectives)."""
+    return n_items >= MIN_SHARD * world
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous slice [lo, hi) of a global batch of n_items for `rank` (balanced; the short last batch of an
     epoch, generators.py:57,104, gives some ranks one item fewer)."""
@@ -115,6 +125,7 @@ class FlatGradSync:
                 if (starts[g + 1] - starts[lo_g]) * esz >= bucket_bytes or g == len(self._group_sizes) - 1:
                     self.buckets.append((g, starts[lo_g], starts[g + 1]))
                     lo_g = g + 1
+        self._seen = set()           # backward groups reported since zero_grad() (a repeat = a second backward pass)
         self._done = 0               # groups finished in the current backward
         self._launched = 0           # buckets already handed to the collective
         self._handles = []
@@ -137,6 +148,7 @@ class FlatGradSync:
         re-weighted by local_count/global_count before it is summed)."""
         assert not self._handles, "zero_grad() while a gradient exchange is in flight: call sync() first"
         self.flat.zero_()
+        self._seen.clear()
         if any(p.grad is None for p in self.params):
             self._attach()
             self._views = {id(p): p.grad for p in self.params}
@@ -159,6 +171,14 @@ class FlatGradSync:
 
     def group_done(self, k: int):
         """Called by the engine's backward when every gradient of backward group k has been written."""
+        if k in self._seen:
+            # the direct sink OVERWRITES the flat views: a second backward pass before zero_grad() (two model calls in
+            # one step, gradient accumulation) would silently drop the first pass's gradients
+            from ._lib import Vp3dError
+            raise Vp3dError("FlatGradSync(direct_module=...): a second backward pass reached the gradient sink before "
+                            "zero_grad(); the direct sink overwrites gradients (no accumulation). Call zero_grad() before "
+                            "every backward, or build the FlatGradSync without direct_module")
+        self._seen.add(k)
         if not self._reduce or not self.buckets:
             return
         self._done = max(self._done, k + 1)
@@ -180,10 +200,12 @@ class FlatGradSync:
             assert self._launched == 0 or self._weight == w, \
                 "buckets were already exchanged during backward: pass the sample counts to zero_grad() instead"
             self._weight = w
-        if self._launched == 0:
-            self._launch(0, self.numel)                      # nothing overlapped: one whole-buffer all-reduce
+        # Every rank must issue the SAME sequence of collectives whatever its backward reported (a rank that skipped
+        # backward, e.g. on an empty shard, reports nothing): with buckets the exchange is always bucket by bucket.
+        if not self.buckets:
+            self._launch(0, self.numel)                      # no backward-order layout: one whole-buffer all-reduce
         else:
-            while self._launched < len(self.buckets):        # groups the backward did not report (none in practice)
+            while self._launched < len(self.buckets):        # buckets the backward did not (yet) hand over
                 _, lo, hi = self.buckets[self._launched]
                 self._launch(lo, hi)
                 self._launched += 1

@@ -12,6 +12,7 @@ with act = dropout(relu(bn(.))).
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import List, Optional
 
@@ -316,10 +317,17 @@ def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Option
     return batch is None or mod._plan.forward_flops(batch, t_in) >= S16_MIN_FORWARD_FLOPS[bool(training)]
 
 
+# Which GEMM engine served the calls of this process: {"s16_eval", "f32_eval", "s16_train", "f32_train"} -> count.  The
+# parity suite asserts on it (a test that claims to cover the split-fp16 kernels must have executed them).
+ENGINE_CALLS = collections.Counter()
+
+
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
     if use_s16(mod, x3.shape[1], False, batch=x3.shape[0]):
         from . import engine_s16
+        ENGINE_CALLS["s16_eval"] += 1
         return engine_s16.forward_eval(mod, x3)
+    ENGINE_CALLS["f32_eval"] += 1
     return _forward_eval_f32(mod, x3)
 
 
@@ -327,10 +335,12 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     """Returns (out3, saved); saved is None unless `save` (it records which arithmetic produced it)."""
     if use_s16(mod, x3.shape[1], True, need_dx, batch=x3.shape[0]):
         from . import engine_s16
+        ENGINE_CALLS["s16_train"] += 1
         out, saved = engine_s16.forward_train(mod, x3, save)
         if saved is not None:
             saved["s16"] = True
         return out, saved
+    ENGINE_CALLS["f32_train"] += 1
     return _forward_train_f32(mod, x3, save)
 
 

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .dp import shard_bounds
+from .dp import shard_bounds, shardable
 
 
 def flip_permutation(n_joints: int, left: Optional[Sequence[int]], right: Optional[Sequence[int]]) -> np.ndarray:
@@ -175,14 +175,13 @@ class ChunkedGenerator:
         return self.augment
 
     def next_pairs(self):
-        if self.state is None:
-            if self.shuffle:
-                pairs = self.random.permutation(self.pairs)
-            else:
-                pairs = self.pairs
-            return 0, pairs
-        else:
-            return self.state
+        """(first batch index, chunk table of the epoch to run): the parked position of an endless generator if there
+        is one, else a new epoch -- shuffled with the generator's RandomState, which therefore advances exactly once per
+        epoch (generators.py:89-97; the bit-exact batch tests pin the stream)."""
+        parked = self.state
+        if parked is not None:
+            return parked
+        return 0, (self.random.permutation(self.pairs) if self.shuffle else self.pairs)
 
     def _device_table(self, pairs: np.ndarray) -> torch.Tensor:
         """One upload of the epoch's chunk table (12 B per chunk); batches then only take slices of it."""
@@ -191,31 +190,36 @@ class ChunkedGenerator:
             self._table = (pairs, torch.from_numpy(tab).to(self._res.device))
         return self._table[1]
 
-    def next_epoch(self):
-        enabled = True
-        while enabled:
-            start_idx, pairs = self.next_pairs()
-            table = self._device_table(pairs)
-            for b_i in range(start_idx, self.num_batches):
-                lo, hi = b_i * self.batch_size, min((b_i + 1) * self.batch_size, len(pairs))
-                if self.shard is not None:
-                    s_lo, s_hi = shard_bounds(hi - lo, self.shard[0], self.shard[1])
-                    lo, hi = lo + s_lo, lo + s_hi
-                if hi > lo:
-                    cam, b3, b2 = self._res.gather(table[lo:hi], hi - lo, self.chunk_length, self.pad,
-                                                   self.causal_shift, self._perm2, self._perm3)
-                else:                                            # a rank may get nothing of a short last batch
-                    cam = b3 = None
-                    b2 = torch.empty((0, self.chunk_length + 2 * self.pad, self._res.j2, self._res.f2),
-                                     dtype=torch.float32, device=self._res.device)
-                if self.endless:
-                    self.state = (b_i + 1, pairs)
-                yield cam, b3, b2
+    def _batch_rows(self, b_i: int, n_pairs: int):
+        """Row range [lo, hi) of batch b_i in the epoch's chunk table for this generator (its shard of the batch when
+        sharded), or None when a sharded generator has to drop the batch (short last batch: see dp.shardable)."""
+        lo = b_i * self.batch_size
+        hi = min(lo + self.batch_size, n_pairs)
+        if self.shard is None:
+            return lo, hi
+        rank, world = self.shard
+        if not shardable(hi - lo, world):
+            return None
+        s_lo, s_hi = shard_bounds(hi - lo, rank, world)
+        return lo + s_lo, lo + s_hi
 
-            if self.endless:
-                self.state = None
-            else:
-                enabled = False
+    def next_epoch(self):
+        """Yields (cam, batch_3d, batch_2d) device tensors batch by batch; an endless generator keeps going over new
+        epochs and parks its position after every batch (generators.py:99-166 semantics, run.py:330-343 usage)."""
+        while True:
+            first, order = self.next_pairs()
+            table = self._device_table(order)
+            for b_i in range(first, self.num_batches):
+                rows = self._batch_rows(b_i, len(order))
+                if self.endless:
+                    self.state = (b_i + 1, order)
+                if rows is None:
+                    continue
+                yield self._res.gather(table[rows[0]:rows[1]], rows[1] - rows[0], self.chunk_length, self.pad,
+                                       self.causal_shift, self._perm2, self._perm3)
+            self.state = None
+            if not self.endless:
+                return
 
 
 class UnchunkedGenerator:

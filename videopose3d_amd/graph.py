@@ -55,6 +55,7 @@ class GraphedTrainStep:
         out3, saved = engine.forward_train(m, x.view(b, tt, -1), save=True)
         pred = out3.view(b, -1, m.num_joints_out, 3)
         lval, gout = vloss._mpjpe_call(pred, t, None, True)
+        self.sync._seen.clear()                       # every (captured) step overwrites the flat gradients: its own zero_grad
         reduce = self.sync._reduce
         self.sync._reduce = False                     # no collectives inside the step: sync.sync() exchanges afterwards
         try:
@@ -66,8 +67,12 @@ class GraphedTrainStep:
 
     def _key(self, x, t):
         m = self.model
+        # the captured launches hold raw device addresses: parameters re-pointed after a capture (optim.FlatAdam adopting
+        # them into its flat buffer, model.to(), a new FlatGradSync) must re-capture, not replay on stale pointers
+        addrs = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers()) + \
+            (self.sync.flat.data_ptr(),)
         return (tuple(x.shape), tuple(t.shape), x.device.index, m.math, float(m.drop.p), m.expand_bn.momentum,
-                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]))
+                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]), hash(addrs))
 
     def _capture(self, x, t) -> _Entry:
         m = self.model

@@ -134,7 +134,7 @@ class FlatAdam(torch.optim.Optimizer):
                 loss = closure()
         g = self.param_groups[0]
         for p in self._ps:
-            if p.grad is None or p.grad.data_ptr() != self._sync.view_for(p).data_ptr():
+            if self._sync.view_for(p) is None:       # .grad is None or no longer the flat view
                 raise _lib.Vp3dError("FlatAdam: a parameter's .grad is no longer the flat-buffer view (use "
                                      "optimizer.zero_grad() of this class, not set_to_none on the module)")
         self._ensure_state()
