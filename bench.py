@@ -314,6 +314,55 @@ def instrumented(step, ops, n_prof, math):
     return roof, kernels
 
 
+def relaunch_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` without an external launcher: start N ranks of this script through
+    torch.distributed.run on one node (rendezvous on 127.0.0.1, a free port) and hand back its exit code; rank 0 of the
+    children prints the ONE JSON line on the inherited stdout.  Under an external launcher (WORLD_SIZE set: the driver's
+    `python -m torch.distributed.run ... bench.py --gpus N`) this is never reached."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks of one node
+    env.setdefault("OMP_NUM_THREADS", "1")                  # N python ranks share the host's cores: no oneDNN/OpenMP pools
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """--dry-run: the distributed control flow of the benchmark without any GPU work (CPU test of the launcher and of
+    the barrier / max-over-ranks timing contract): rendezvous (gloo), W + K empty steps between barriers, rank 0 prints
+    the JSON skeleton with value null."""
+    from videopose3d_amd import dp
+    rank, world, _ = dp.init_from_env("gloo")
+    assert world == args.gpus, (world, args.gpus)
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
+                          "barrier_to_barrier_s": dt}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,7 +373,12 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 MFMA comparison sections")
     ap.add_argument("--math", default=None, help="arithmetic of the headline: f16x3 (default) or f32")
     ap.add_argument("--no-rocm-ref", action="store_true", help="skip the PyTorch-ROCm (MIOpen) reference-path baseline (~75 s)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / barrier control flow only, no GPU work (CPU test hook)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))       # bare `python bench.py --gpus N`: one rank per GPU, ourselves
+    if args.dry_run:
+        return dry_run(args)
 
     import videopose3d_amd as V
     from videopose3d_amd import TemporalModel, TemporalModelOptimized1f, dp, ops
@@ -332,7 +386,7 @@ def main():
     # VP3D_DIST_BACKEND / VP3D_BENCH_DEVICE are test hooks: "gloo" + device 0 let the N > 1 control flow (matched
     # collectives on every rank, no deadlock) be exercised on a box with a single GPU; the driver never sets them.
     rank, world, local = dp.init_from_env(os.environ.get("VP3D_DIST_BACKEND", "nccl"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch one rank per GPU" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     local = int(os.environ.get("VP3D_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
@@ -385,22 +439,20 @@ def main():
     dtype = ("f32 (products on split-fp16 MFMA: 22+ bit operands, exact fp16 products, fp32 accumulate)" if math == "f16x3"
              else "f32")
 
-    # opt-in of round 1 (not the library default yet, so not `value`): weight gradients from the S16 rows
-    # (vp3d_wgrad_rows_s16: no transposed copies), same step otherwise
+    # the transposed-copy form of the C x C weight gradients (round 1's default; VP3D_WGRAD_ROWS=0), same step otherwise
     rows_opt = None
-    if math == "f16x3" and os.environ.get("VP3D_WGRAD_ROWS", "0") != "1":
-        os.environ["VP3D_WGRAD_ROWS"] = "1"
+    if math == "f16x3" and os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and os.environ.get("VP3D_BENCH_AB", "0") == "1":
+        os.environ["VP3D_WGRAD_ROWS"] = "0"
         try:                                  # informational: never lets the headline line fail
             dt_r = time_steps(step, 3, args.steps)
-            rows_opt = {"what": "the same step with VP3D_WGRAD_ROWS=1 (opt-in: C x C weight gradients read the S16 rows of dy "
-                                "and of the layer input, ds_read_b64_tr_b16 transposes on the LDS read; the producers write "
-                                "no transposed copies for them)",
+            rows_opt = {"what": "the same step with VP3D_WGRAD_ROWS=0 (weight gradients as NT GEMMs over transposed S16 copies "
+                                "written by the producers: round 1's default)",
                         "ms_per_step": dt_r / args.steps * 1e3, "frames_per_s": world * B * args.steps / dt_r,
-                        "speedup_vs_default": dt / dt_r}
+                        "slowdown_vs_default": dt_r / dt}
         except Exception as e:  # noqa: BLE001
             rows_opt = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
-            os.environ["VP3D_WGRAD_ROWS"] = "0"
+            os.environ["VP3D_WGRAD_ROWS"] = "1"
 
     out = {
         "metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": value, "unit": "frames/s",
@@ -462,7 +514,7 @@ def main():
 
     # ---- the same step on the exact-fp32 MFMA kernels (every rank: the step holds collectives) -------------
     if rows_opt is not None:
-        out["wgrad_rows_opt_in"] = rows_opt
+        out["wgrad_transposed_copies"] = rows_opt
     if math != "f32" and not args.no_f32:
         model, sync, step = build("f32")
         k32 = max(5, args.steps // 2)

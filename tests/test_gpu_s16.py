@@ -379,8 +379,8 @@ def test_wgrad_from_rows_vs_fp64(b, t, c_out, c_in, taps):
 
 
 def test_model_gradients_with_rows_form_wgrad(monkeypatch):
-    """VP3D_WGRAD_ROWS=1: the C x C weight gradients come from vp3d_wgrad_rows_s16 and no transposed copies are written
-    for them; every gradient matches the default (transposed-copy) path up to summation order."""
+    """The default (VP3D_WGRAD_ROWS=1): the C x C weight gradients come from vp3d_wgrad_rows_s16 and no transposed copies
+    are written for them; every gradient matches the transposed-copy form (VP3D_WGRAD_ROWS=0) up to summation order."""
     import copy
     from videopose3d_amd import engine_s16
     torch.manual_seed(4)
@@ -391,9 +391,11 @@ def test_model_gradients_with_rows_form_wgrad(monkeypatch):
         m._drop_seed, m._drop_calls = 31, 0
     x = (torch.randn(48, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
     tgt = torch.randn(48, 1, 17, 3, device=DEV) * 0.3
+    monkeypatch.setenv("VP3D_WGRAD_ROWS", "0")
+    assert not engine_s16.wgrad_from_rows(256, 256)
     torch.mean(torch.norm(m_a(x) - tgt, dim=3)).backward()
-    monkeypatch.setenv("VP3D_WGRAD_ROWS", "1")
-    assert engine_s16.wgrad_from_rows(256, 256)
+    monkeypatch.delenv("VP3D_WGRAD_ROWS")
+    assert engine_s16.wgrad_from_rows(256, 256) and not engine_s16.wgrad_from_rows(128, 128)
     y_b = m_b(x)
     torch.mean(torch.norm(y_b - tgt, dim=3)).backward()
     for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):

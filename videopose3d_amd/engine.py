@@ -167,6 +167,19 @@ def _wgrad_stream(device, default_on: bool = False) -> Optional[torch.cuda.Strea
     return st
 
 
+_fork_events = {}
+
+
+def _fork_event(device, slot: int) -> torch.cuda.Event:
+    """Reusable HIP event for the main -> wgrad-stream fork of layer `slot` (a fresh torch.cuda.Event() per layer and
+    step is an hipEventCreate/Destroy pair each: host time that N ranks on one node's cores do not have)."""
+    key = (torch.device(device).index, slot)
+    ev = _fork_events.get(key)
+    if ev is None:
+        ev = _fork_events[key] = torch.cuda.Event()
+    return ev
+
+
 def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     """Gradients in the order of ``param_list`` (+ optional input gradient).
 
@@ -254,7 +267,7 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
             # (optional second stream) forked AFTER this layer's dgrad has been queued on `main`
             out = view(convs[idx].weight)
             if side is not None:
-                ev = torch.cuda.Event()
+                ev = _fork_event(gout3.device, idx)
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):

@@ -117,10 +117,10 @@ class _Saved:
 
 
 def wgrad_from_rows(c_out: int, c_in: int) -> bool:
-    """Opt-in (VP3D_WGRAD_ROWS=1, round-1 status: validated against the default path, not yet the default): the C x C
-    weight gradients read the S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16) and the producers stop
-    writing transposed copies for them; the expand conv (K-padded im2row operand) keeps the transposed form."""
-    return os.environ.get("VP3D_WGRAD_ROWS", "0") == "1" and S.wgrad_rows_supported(c_out, c_in)
+    """Default since round 2 (VP3D_WGRAD_ROWS=0 restores the transposed-copy form): the C x C weight gradients read the
+    S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16, channels % 256 == 0) and the producers write no
+    transposed copies for them; the expand conv (K-padded im2row operand) and narrower models keep the transposed form."""
+    return os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in)
 
 
 def forward_train(mod, x3: torch.Tensor, save: bool):
@@ -292,7 +292,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             return S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
         if side is not None and on_side:
             # nothing inside backward consumes dW: it runs beside the next layer's HBM-bound BatchNorm-backward kernels
-            ev = torch.cuda.Event()
+            ev = engine._fork_event(dev, idx)
             ev.record(main)
             side.wait_event(ev)
             with torch.cuda.stream(side):
