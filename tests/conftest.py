@@ -30,6 +30,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.hookimpl(tryfirst=True, hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """Keeps each phase's report on the item (item.rep_call ...) so that fixtures can see how the test body ended."""
+    outcome = yield
+    rep = outcome.get_result()
+    setattr(item, "rep_" + rep.when, rep)
+
+
 @pytest.fixture(params=["f16x3", "f32"])
 def math_mode(request):
     """Model-level GPU tests run once per GEMM arithmetic: "f16x3" (split-fp16 MFMA, engine_s16) and "f32" (fp32 MFMA) --
@@ -46,12 +54,12 @@ def math_mode(request):
     _E.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})     # the small test models must not fall below the
     _V.set_default_math(request.param)                            # engine's "big enough to be compute-bound" threshold
     _E.ENGINE_CALLS.clear()
-    failed_before = request.session.testsfailed
     yield request.param
     calls = dict(_E.ENGINE_CALLS)
     _V.set_default_math(None)
     _E.S16_MIN_FORWARD_FLOPS.update(keep)
-    if request.session.testsfailed != failed_before or single:
+    rep = getattr(request.node, "rep_call", None)
+    if single or rep is None or not rep.passed:       # skipped / failed bodies have nothing to certify
         return
     s16 = calls.get("s16_train", 0) + calls.get("s16_eval", 0)
     f32 = calls.get("f32_train", 0) + calls.get("f32_eval", 0)
