@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 104
+#define VP3D_VERSION 105
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -240,6 +240,33 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
 int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                             const float* mean, const float* invstd, const uint8_t* act_bits, float keep_scale,
                             float* partials, int32_t* nparts);
+/* vp3d_bn_bwd_reduce_bits + vp3d_bn_bwd_finalize_s16 in ONE launch (replaces the reduction half of autograd's
+ * batch_norm backward, model.py:127,134 backward): the partial rows are summed by the last-arriving blocks (tickets, fp64,
+ * fixed order => deterministic), which also write dgamma / dbeta and max the bound of dy into dy_bound (zeroed by the
+ * caller).  Workspaces: partials [*nparts][2][C] floats, group_partials [*ngroups][2][C] doubles, tickets [*ntickets]
+ * int32 that must be ZERO on entry and are zero again on exit (keep one buffer per stream).  Call with partials == NULL
+ * to query the three sizes.  keep scale = 1/(1-p). */
+int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                               const float* mean, const float* invstd, const uint8_t* act_bits, float p,
+                               const float* scale, const float* go_bound, float* partials, double* group_partials,
+                               int32_t* tickets, float* dgamma, float* dbeta, float* dy_bound, int32_t* nparts,
+                               int32_t* ngroups, int32_t* ntickets);
+/* Backward of the expand layer without materialising dy (videopose3d_amd/engine_s16.py; replaces autograd's backward of
+ * model.py:74,127 for expand_conv / expand_bn when no input gradient is wanted).  With X = the im2row rows of the layer
+ * input incl. a bias column of ones (vp3d_im2row one_col) and G = go * keep * [bn(y) > 0]:
+ *   vp3d_act_mask_t_s16   G as a transposed S16 operand [C][ld_t] under the bound go_bound/(1-p), published in g_bound
+ *                         (32 floats, zeroed by the caller)
+ *   vp3d_tconv_nt_s16     raw partials of  P = G^T X [C][kpad]  and of  S = X^T X [kpad][kpad]  (K = rows)
+ *   vp3d_sum_slices       S as doubles (slice order)
+ *   vp3d_expand_bwd_s16   dbeta = P[:, one_col], dgamma = invstd (<W, P> - mean dbeta), and
+ *                         dW = A P + B sX + Cx (W S - mean sX)  (A = scale, B = -A dbeta/M, Cx = -A invstd dgamma/M,
+ *                         sX = S[:, one_col]) un-packed to Conv1d.weight layout [C][c_in][taps]. */
+int vp3d_act_mask_t_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
+                        const uint8_t* act_bits, float p, float* g_bound, void* t_out, int64_t ld_t);
+int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out);
+int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
+                        int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
+                        const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw);
 /* Weight gradient of a (strided) conv straight from S16 ROWS -- no transposed copies: the kernel transposes on the LDS
  * read (ds_read_b64_tr_b16).  Replaces autograd's conv weight gradient (model.py:178-180 backward) like
  * vp3d_tconv_nt_s16 in raw-partials mode does:
@@ -308,9 +335,11 @@ int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_
 
 /* Row staging for convs whose taps*C_in is not a multiple of 32 (expand_conv: 3*34 = 102): row m = (b,t) of `out`
  * receives the k_valid contiguous floats at x[(b*t_src + t*t_stride)*ldx] followed by zeros up to kpad, so that the
- * conv becomes a 1-tap GEMM over 16-byte-aligned kpad-wide rows (dil == 1 only: taps are adjacent rows). */
+ * conv becomes a 1-tap GEMM over 16-byte-aligned kpad-wide rows (dil == 1 only: taps are adjacent rows).
+ * one_col in [k_valid, kpad): that padding column holds 1 instead of 0 (a bias column -- the matching weight column
+ * is zero, so the forward is unchanged; vp3d_expand_bwd_s16 reads column sums from it); -1: none. */
 int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid,
-                int32_t kpad, float* out);
+                int32_t kpad, int32_t one_col, float* out);
 
 /* eval-mode BN folding: scale[c] = gamma/sqrt(running_var+eps), shift[c] = beta - running_mean*scale */
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,

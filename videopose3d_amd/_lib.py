@@ -83,6 +83,12 @@ SIGNATURES = {
                                         _vp, _i64]),
     "vp3d_wgrad_rows_s16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "vp3d_bn_bwd_reduce_bits": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _P(_i32)]),
+    "vp3d_bn_bwd_reduce_fin_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _P(_i32), _P(_i32), _P(_i32)]),
+    "vp3d_act_mask_t_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _i64]),
+    "vp3d_sum_slices": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "vp3d_expand_bwd_s16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp]),
     "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
     "vp3d_amax_multi": (C.c_int, [_vp, _i32, _P(_vp), _P(_i64), _vp]),
@@ -96,7 +102,7 @@ SIGNATURES = {
     "vp3d_tconv_wgrad": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "vp3d_wgrad_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vp3d_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32]),
-    "vp3d_im2row": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _vp]),
+    "vp3d_im2row": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _i32, _vp]),
     "vp3d_bn_fold": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vp3d_bn_finalize": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_bn_act_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -139,8 +145,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 104:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (104); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 105:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (105); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

@@ -406,8 +406,10 @@ __global__ void __launch_bounds__(256) k_colsum(int64_t M, int N, const float* _
 
 // out[m][0..kpad) = the k_valid contiguous floats starting at x[(b*t_src + t*t_stride)*ldx], zero padded.
 // (expand conv: taps*C_in = 102 contiguous floats per output row -> 128-wide rows the fast GEMM path can DMA)
+// one_col >= k_valid: that padding column holds 1 (a "bias column": a GEMM that reduces over the rows then also yields
+// the column sums of its other operand -- engine_s16's expand-layer backward reads sum(g) and colsum(x) from it)
 __global__ void __launch_bounds__(256) k_im2row(int M, int t_dst, int t_src, int t_stride, int ldx, int k_valid,
-                                                int kpad, const float* __restrict__ x, float* __restrict__ out) {
+                                                int kpad, int one_col, const float* __restrict__ x, float* __restrict__ out) {
   const int qpr = kpad >> 2;                          // float4 per output row
   const int64_t total = (int64_t)M * qpr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(256) k_im2row(int M, int t_dst, int t_src, int
     const float* src = x + ((int64_t)b * t_src + (int64_t)t * t_stride) * ldx;
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (k0 + e < k_valid) ? src[k0 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) v[e] = (k0 + e < k_valid) ? src[k0 + e] : (k0 + e == one_col ? 1.f : 0.f);
     *reinterpret_cast<f32x4*>(out + (int64_t)m * kpad + k0) = v;
   }
 }
@@ -658,8 +660,9 @@ int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int3
 }
 
 int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid,
-                int32_t kpad, float* out) {
+                int32_t kpad, int32_t one_col, float* out) {
   VP3D_REQUIRE(map && x && out, "im2row: null pointer");
+  VP3D_REQUIRE(one_col < 0 || (one_col >= k_valid && one_col < kpad), "im2row: the bias column must be a padding column");
   VP3D_REQUIRE(map->batch > 0 && map->t_dst > 0 && map->t_src > 0 && k_valid > 0 && kpad >= k_valid && kpad % 4 == 0 &&
                    aligned16(out), "im2row: bad sizes (k_valid=%d kpad=%d)", k_valid, kpad);
   VP3D_REQUIRE((int64_t)(map->t_dst - 1) * map->t_stride * ldx + k_valid <= (int64_t)map->t_src * ldx,
@@ -667,7 +670,7 @@ int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, in
   const int64_t M = (int64_t)map->batch * map->t_dst;
   VP3D_REQUIRE(M < ((int64_t)1 << 31), "im2row: more than 2^31 rows");
   hipLaunchKernelGGL(k_im2row, dim3(stream_grid(M * (kpad / 4))), dim3(256), 0, (hipStream_t)stream, (int)M, map->t_dst,
-                     map->t_src, map->t_stride, ldx, k_valid, kpad, x, out);
+                     map->t_src, map->t_stride, ldx, k_valid, kpad, one_col < 0 ? -1 : one_col, x, out);
   return check_launch("im2row");
 }
 

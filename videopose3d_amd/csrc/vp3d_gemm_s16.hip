@@ -1095,6 +1095,10 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break;
     case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break;   // measured alternatives
     case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break;
+    // two INDEPENDENT 4-wave workgroups of 128x64 sub-tiles per CU (3 x 16-element stages each: 2 x 74 KiB of LDS): the
+    // per-wave operand reuse of the 256x256 tiling, but one workgroup's epilogue / barrier waits run under the other's MFMAs
+    case 24: rc = launch_cfg<Cfg<2, 2, 4, 2, 3, 16, 0, 1>>(s, a, splits); break;   // 256x128
+    case 25: rc = launch_cfg<Cfg<2, 2, 2, 4, 3, 16, 0, 1>>(s, a, splits); break;   // 128x256
     default:
       set_error("nt_s16: unknown tile configuration %d", cfg);
       return VP3D_E_INVALID;

@@ -159,7 +159,10 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
 // A block walks the 64-row tiles ty = blockIdx.y, blockIdx.y + gridDim.y, ... of its 64-channel strip, so the
 // per-channel constants are loaded once per block.
 // ---------------------------------------------------------------------------------------------------------
-template <bool BITS>
+// MASK (with BITS): only g = go * keep * [z>0] is produced (no y, no per-channel constants), scaled by the exponent of
+// go_bound * keep_scale, which block (0,0) also publishes in mask_bound -- the operand of the expand layer's backward
+// GEMM (vp3d_expand_bwd_s16), which needs no dy at all.
+template <bool BITS, bool MASK = false>
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const float* __restrict__ go,
                                                           const float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ mean,
@@ -167,16 +170,29 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
                                                           const uint8_t* __restrict__ act_bits, float keep_scale,
                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                           const float* __restrict__ out_bound, float* __restrict__ dy,
-                                                          TOut t) {
+                                                          TOut t, float* __restrict__ mask_bound) {
   if (!BITS) drop_resolve(d);
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
   const float inv_m = 1.0f / (float)M;
-  const float inv = s16_pow2(-s16_exp_of(out_bound));
+  float inv;
+  if (MASK) {                                          // out_bound = the bound of go
+    const float gb = s16_load_bound(out_bound) * keep_scale;
+    inv = s16_pow2(-s16_exp_for_bound(gb));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) mask_bound[0] = gb;   // (slots 1.. stay zero)
+  } else {
+    inv = s16_pow2(-s16_exp_of(out_bound));
+  }
   // v = A*g + B + Cx*(y - mu):   A = scale*inv, B = -A*dbeta/M, Cx = -A*invstd*dgamma/M
   float ka[8], kb[8], kc[8], mu[8], sc[8], sh[8];
-  {
+  if (MASK) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ka[e] = inv;
+      kb[e] = kc[e] = mu[e] = sc[e] = sh[e] = 0.f;
+    }
+  } else {
     float is[8], dg[8], db[8];
     load8(scale + c, sc);
     load8(mean + c, mu);
@@ -203,8 +219,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
         const int64_t e0 = m * C + c;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(go + e0);
         const f32x4 g1 = *reinterpret_cast<const f32x4*>(go + e0 + 4);
-        const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + e0);
-        const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+        if (!MASK) {
+          y0 = *reinterpret_cast<const f32x4*>(y + e0);
+          y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
+        }
         float mk[8];
         if (BITS) {
           const uint32_t bits = act_bits[act_bits_index(c, m, M)];
@@ -230,7 +249,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
           const float gg = e < 4 ? g0[e] : g1[e - 4];
           float g = gg * mk[e];
           if (!BITS) g = fmaf(yy, sc[e], sh[e]) > 0.f ? g : 0.f;
-          v[e] = fmaf(kc[e], yy - mu[e], fmaf(ka[e], g, kb[e]));
+          v[e] = MASK ? g * ka[e] : fmaf(kc[e], yy - mu[e], fmaf(ka[e], g, kb[e]));
         }
         if (dy != nullptr) {                        // (the expand conv needs no dgrad: only the transposed copy is written)
           f16x8 hi, lo;
@@ -262,12 +281,48 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
 // the block folds its row sub-groups through LDS (fixed order) and writes ONE partial row:
 // partials[(blockIdx.y*2 + {0,1})*C + c].
 // ---------------------------------------------------------------------------------------------------------
+// Optional finalize fused into the reduction (fin.cnt != nullptr): the partial rows are folded by "last arrivers" -- the
+// last block of every group of fin.per_group blocks sums its group's rows (fp64, row order) into gpart[group], the last
+// group to finish sums the group rows (group order), writes dgamma / dbeta and max-es the bound of dy.  Fixed summation
+// tree => deterministic; no block ever waits (tickets, not spinning), so co-residency is not required.  This replaces
+// the separate [C]-sized finalize launch, whose few blocks waited 80-140 us for a CU slot behind the weight-gradient
+// GEMM that runs on the second stream (profiles/r01_s16_step_timeline.txt).
+struct BwdFin {
+  double* gpart;               // [groups][2][C]
+  int* cnt;                    // [gridDim.x][groups + 1] tickets, zero on entry, zero again on exit
+  float* dgamma;
+  float* dbeta;
+  const float* scale;
+  const float* go_bound;
+  float* dy_bound;
+  float inv_keep, inv_m, sqrt_m1;
+  int per_group;
+};
+
+// Ticket of a block that has finished writing its contribution: true for the block that arrives last.  Publish / consume
+// follow the agent-scope release -> relaxed atomic -> acquire hand-off (all stores of the block drained and released
+// before the ticket; the last arriver acquires before any thread of it reads the other blocks' rows).
+__device__ __forceinline__ bool last_arriver(int* counter, int expected, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const float* __restrict__ go,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const uint8_t* __restrict__ act_bits, float keep_scale,
                                                             float* __restrict__ partials, int lanes_per_row,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, BwdFin fin) {
   __shared__ float red[256 * 8];
   const int lr = threadIdx.x % lanes_per_row, rsub = threadIdx.x / lanes_per_row;
   const int c = (blockIdx.x * lanes_per_row + lr) * 4;
@@ -317,6 +372,66 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
   if (rsub == 0 && c < C) {
     *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 0) * C + c) = f32x4{sg[0], sg[1], sg[2], sg[3]};
     *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 1) * C + c) = f32x4{sgx[0], sgx[1], sgx[2], sgx[3]};
+  }
+  if (fin.cnt == nullptr) return;
+
+  // ---- fused finalize: stage 1 (group of rows) ---------------------------------------------------------------
+  const int per = fin.per_group;
+  const int ngroups = ((int)gridDim.y + per - 1) / per;
+  const int grp = (int)blockIdx.y / per;
+  const int row0 = grp * per, nrows = min(per, (int)gridDim.y - row0);
+  int* cnt = fin.cnt + (int64_t)blockIdx.x * (ngroups + 1);
+  int* flag = reinterpret_cast<int*>(red);
+  if (rows_per_block > 1) __syncthreads();             // (red[] was read above)
+  if (!last_arriver(cnt + grp, nrows, flag)) return;
+  const bool owner = rsub == 0 && c < C;
+  if (owner) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int r = row0; r < row0 + nrows; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 0) * C + c);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 1) * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] += (double)v[e];
+        b[e] += (double)w[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      fin.gpart[((int64_t)grp * 2 + 0) * C + c + e] = a[e];
+      fin.gpart[((int64_t)grp * 2 + 1) * C + c + e] = b[e];
+    }
+  }
+  // ---- stage 2 (groups) + finalize -----------------------------------------------------------------------------
+  if (!last_arriver(cnt + ngroups, ngroups, flag)) return;
+  float bmax = 0.f;
+  const float gmax = s16_load_bound(fin.go_bound) * fin.inv_keep;      // (whole waves take part in the bound's shuffle)
+  if (owner) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] += fin.gpart[((int64_t)g * 2 + 0) * C + c + e];
+        b[e] += fin.gpart[((int64_t)g * 2 + 1) * C + c + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float db = (float)a[e], dg = (float)b[e];
+      fin.dbeta[c + e] = db;
+      fin.dgamma[c + e] = dg;
+      bmax = fmaxf(bmax, fabsf(fin.scale[c + e]) * (gmax + fabsf(db) * fin.inv_m + fin.sqrt_m1 * fabsf(dg) * fin.inv_m));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+  __syncthreads();                                     // flag (red[0]) has been read by everyone
+  if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = bmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s16_atomic_bound(fin.dy_bound, fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])));
+    for (int i = 0; i <= ngroups; ++i) cnt[i] = 0;     // every block of this column strip has drawn its tickets
   }
 }
 
@@ -615,6 +730,89 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize_bound(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of the expand layer (conv -> BatchNorm -> ReLU -> dropout) WITHOUT materialising dy.  The layer has no data
+// gradient to produce and its conv is linear in a 128-column operand X (im2row rows with a bias column of ones), so with
+// G = go * keep * [z>0] (vp3d_act_mask_t_s16) everything follows from two small reductions over the rows,
+//     P = G^T X  [C][kpad]      and      S = X^T X  [kpad][kpad]      (S16 GEMMs, K = rows):
+//   dbeta_c  = sum g              = P[c][one]                        (the bias column)
+//   sum g*y  = <W_c, P[c]>        (y = X W^T)           ->  dgamma_c = invstd_c (sum g*y - mean_c dbeta_c)
+//   dy       = A g + B + Cx (y - mean),  A = scale, B = -A dbeta/M, Cx = -A invstd dgamma/M   (k_bn_bwd_apply_s16)
+//   dW[c][j] = sum_m dy[m][c] X[m][j] = A P[c][j] + B sX[j] + Cx ((W S)[c][j] - mean_c sX[j]),   sX[j] = S[j][one]
+// Replaces, for that layer, vp3d_bn_bwd_reduce_bits + finalize + vp3d_bn_bwd_apply_s16 (two passes over go and y,
+// one dy write: 2.4 GB for the cfg3 step) by one pass over go, and the weight-gradient un-pack.
+// ---------------------------------------------------------------------------------------------------------
+// out[i] = sum_s ws[s][i] (fp64 accumulation, slice order)
+__global__ void __launch_bounds__(256) k_sum_slices(int64_t n, int splits, const float* __restrict__ ws, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a = 0.0;
+  for (int s = 0; s < splits; ++s) a += (double)ws[(int64_t)s * n + i];
+  out[i] = a;
+}
+
+// block = 8 channels x 32 lanes, lane = 4 consecutive columns of the kpad <= 128 wide rows
+__global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv, int one, int c_in, int taps, int splits,
+                                                         const float* __restrict__ pws, const double* __restrict__ S,
+                                                         const float* __restrict__ wp, const float* __restrict__ scale,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         double inv_m, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ dw) {
+  __shared__ float w_s[8][128];
+  const int cl = threadIdx.x >> 5, jq = threadIdx.x & 31, j0 = jq * 4;
+  const int c = blockIdx.x * 8 + cl;
+  const bool live = c < C && j0 < kpad;
+  double P[4] = {0.0, 0.0, 0.0, 0.0};
+  float w4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    for (int s = 0; s < splits; ++s) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pws + ((int64_t)s * C + c) * kpad + j0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[e] += (double)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w4[e] = j0 + e < kv ? wp[(int64_t)c * kpad + j0 + e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w_s[cl][(j0 + e) & 127] = w4[e];
+  // per-channel sums over the 32 lanes of a channel (half a wave): sum g*y and the bias column
+  double sgy = 0.0, db = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sgy += (double)w4[e] * P[e];
+    db += (live && j0 + e == one) ? P[e] : 0.0;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    sgy += __shfl_xor(sgy, o);
+    db += __shfl_xor(db, o);
+  }
+  __syncthreads();
+  if (!live) return;
+  const double mu = (double)mean[c], is = (double)invstd[c], A = (double)scale[c];
+  const double dg = is * (sgy - mu * db);
+  if (jq == 0) {
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+  }
+  const double B = -A * db * inv_m, Cx = -A * is * dg * inv_m;
+  double T[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < kv; ++i) {
+    const double wi = (double)w_s[cl][i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[e] += wi * S[(int64_t)i * kpad + j0 + e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = j0 + e;
+    if (j >= kv) continue;
+    const double sx = S[(int64_t)j * kpad + one];
+    const double v = A * P[e] + B * sx + Cx * (T[e] - mu * sx);
+    const int k = j / c_in, ci = j - k * c_in;
+    dw[((int64_t)c * c_in + ci) * taps + k] = (float)v;
+  }
+}
+
 }  // namespace
 }  // namespace vp3d
 
@@ -676,11 +874,52 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
   const dim3 grid((unsigned)gx, (unsigned)gy);
   if (act_bits != nullptr)
     hipLaunchKernelGGL((k_bn_bwd_apply_s16<true>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale, shift,
-                       mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t);
+                       mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t, (float*)nullptr);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply_s16<false>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale,
-                       shift, mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t);
+                       shift, mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t, (float*)nullptr);
   return check_launch("bn_bwd_apply_s16");
+}
+
+int vp3d_act_mask_t_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
+                        const uint8_t* act_bits, float p, float* g_bound, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && go_bound && act_bits && g_bound && t_out &&
+                   p >= 0.f && p < 1.f && aligned16(go),
+               "act_mask_t_s16: bad argument (needs C %% 64 == 0, 16-byte aligned rows)");
+  int rc = check_t("act_mask_t_s16", t_out, ld_t, 1, M);
+  if (rc) return rc;
+  TOut t{(float*)t_out, ld_t, 1};
+  const size_t lds = (size_t)64 * TPITCH * 4;
+  const int64_t ntiles = (M + 63) / 64, gx = C / 64;
+  int64_t per_block = gx * ntiles / 2048;
+  per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
+  int64_t gy = (ntiles + per_block - 1) / per_block;
+  gy = gy > 65535 ? 65535 : gy;
+  DropP d{};
+  hipLaunchKernelGGL((k_bn_bwd_apply_s16<true, true>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, (int)M,
+                     C, go, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, d, act_bits, 1.0f / (1.0f - p), (const float*)nullptr, (const float*)nullptr, go_bound,
+                     (float*)nullptr, t, g_bound);
+  return check_launch("act_mask_t_s16");
+}
+
+int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out) {
+  VP3D_REQUIRE(n > 0 && splits > 0 && ws && out, "sum_slices: bad argument");
+  hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, splits, ws, out);
+  return check_launch("sum_slices");
+}
+
+int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
+                        int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
+                        const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw) {
+  const int kv = c_in * taps;
+  VP3D_REQUIRE(C > 0 && c_in > 0 && taps > 0 && kpad % 4 == 0 && kpad <= 128 && kv < kpad && one_col >= kv && one_col < kpad &&
+                   M > 0 && splits > 0 && p_partials && gram && w_packed && scale && mean && invstd && dgamma && dbeta && dw &&
+                   aligned16(p_partials),
+               "expand_bwd_s16: bad argument (kpad <= 128, a spare padding column for the bias)");
+  hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
+                     splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw);
+  return check_launch("expand_bwd_s16");
 }
 
 int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
@@ -700,8 +939,48 @@ int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const fl
   VP3D_REQUIRE(go && y && mean && invstd && act_bits && aligned16(go) && aligned16(y) && aligned16(partials),
                "bn_bwd_reduce_bits: null or unaligned pointer");
   hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
-                     invstd, act_bits, keep_scale, partials, lpr, rpb);
+                     invstd, act_bits, keep_scale, partials, lpr, rpb, BwdFin{});
   return check_launch("bn_bwd_reduce_bits");
+}
+
+int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
+                               const float* mean, const float* invstd, const uint8_t* act_bits, float p,
+                               const float* scale, const float* go_bound, float* partials, double* group_partials,
+                               int32_t* tickets, float* dgamma, float* dbeta, float* dy_bound, int32_t* nparts,
+                               int32_t* ngroups, int32_t* ntickets) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && nparts && ngroups && ntickets && p >= 0.f && p < 1.f,
+               "bn_bwd_reduce_fin_s16: bad argument (needs C %% 64 == 0)");
+  const int c4 = C / 4;
+  const int lpr = c4 < 256 ? c4 : 256;
+  const int rpb = 256 / lpr;
+  const int gx = (c4 + lpr - 1) / lpr;
+  int64_t gy = (M + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);     // the geometry of vp3d_bn_bwd_reduce_bits
+  const int64_t cap = 512 / gx > 0 ? 512 / gx : 1;
+  gy = gy > cap ? cap : gy;
+  int per = 1;                                         // ~sqrt(rows) rows per group: both last-arriver stages stay short
+  while (per * per < gy) ++per;
+  *nparts = (int32_t)gy;
+  *ngroups = (int32_t)((gy + per - 1) / per);
+  *ntickets = gx * (*ngroups + 1);
+  if (partials == nullptr) return VP3D_OK;             // size query
+  VP3D_REQUIRE(go && y && mean && invstd && act_bits && scale && go_bound && group_partials && tickets && dgamma && dbeta &&
+                   dy_bound && aligned16(go) && aligned16(y) && aligned16(partials) && aligned16(group_partials),
+               "bn_bwd_reduce_fin_s16: null or unaligned pointer");
+  BwdFin fin;
+  fin.gpart = group_partials;
+  fin.cnt = tickets;
+  fin.dgamma = dgamma;
+  fin.dbeta = dbeta;
+  fin.scale = scale;
+  fin.go_bound = go_bound;
+  fin.dy_bound = dy_bound;
+  fin.inv_keep = 1.0f / (1.0f - p);
+  fin.inv_m = 1.0f / (float)M;
+  fin.sqrt_m1 = sqrtf((float)(M > 1 ? M - 1 : 1));
+  fin.per_group = per;
+  hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
+                     invstd, act_bits, fin.inv_keep, partials, lpr, rpb, fin);
+  return check_launch("bn_bwd_reduce_fin_s16");
 }
 
 int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,

@@ -65,14 +65,15 @@ def folded_weights(mod):
     return packs
 
 
-def _expand_input(plan: StackPlan, x3: torch.Tensor):
+def _expand_input(plan: StackPlan, x3: torch.Tensor, one_col: int = -1):
     """expand_conv reads taps*C_in = 102 contiguous floats per output row: stage them as 128-wide zero-padded
-    rows (one cheap pass over the 34-channel input) so that the GEMM runs on the LDS-DMA fast path."""
+    rows (one cheap pass over the 34-channel input) so that the GEMM runs on the LDS-DMA fast path.  one_col: a
+    padding column set to 1 (engine_s16's expand-layer backward; the matching weight column is zero)."""
     spec = plan.convs[0]
     kpad = ops.padded_k(spec)
     if not kpad:
         return x3, spec, 0
-    return ops.im2row(x3, spec, kpad), ConvSpec(kpad, spec.c_out, 1, 1, 1), kpad
+    return ops.im2row(x3, spec, kpad, one_col), ConvSpec(kpad, spec.c_out, 1, 1, 1), kpad
 
 
 def _shrink(mod, h: torch.Tensor) -> torch.Tensor:

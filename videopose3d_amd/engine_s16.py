@@ -107,10 +107,11 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 # training (strided model)
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows")
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows", "one_col", "w_packed")
 
     def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits, x_rows=None):
         self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
+        self.one_col, self.w_packed = -1, None   # expand layer: bias column of the im2row rows, fp32 weight pack (shortcut)
         self.x_rows = x_rows      # rows-form wgrad (wgrad_from_rows): the layer input as S16 rows instead of x_t
         self.bits = bits          # activation bits ([bn(y) > 0 and kept], 1 bit / element): what backward reads instead
                                   # of regenerating the Philox mask
@@ -121,6 +122,17 @@ def wgrad_from_rows(c_out: int, c_in: int) -> bool:
     S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16, channels % 256 == 0) and the producers write no
     transposed copies for them; the expand conv (K-padded im2row operand) and narrower models keep the transposed form."""
     return os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in)
+
+
+def expand_shortcut_column(plan: StackPlan, sync) -> int:
+    """Padding column of the expand conv's im2row rows that carries the constant 1 of the no-dy backward of the expand
+    layer (expand_bwd below), or -1 when that backward is not used: no spare padding column, synchronised BatchNorm
+    (the formulas need the global sums between the two reductions), or VP3D_EXPAND_BWD=0."""
+    spec = plan.convs[0]
+    kpad, kv = ops.padded_k(spec), spec.taps * spec.c_in
+    if os.environ.get("VP3D_EXPAND_BWD", "1") == "0" or sync is not None or not kpad or kv >= kpad or kpad > 128:
+        return -1
+    return kv
 
 
 def forward_train(mod, x3: torch.Tensor, save: bool):
@@ -140,7 +152,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
         sync.begin_step(b, dev)
 
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
-    xin, spec0, kpad = engine._expand_input(plan, x3)
+    use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
+    one_col = expand_shortcut_column(plan, sync) if use_bits else -1
+    xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
     assert kpad, "the S16 path stages the expand conv through im2row"
     m0 = xin.shape[0] * xin.shape[1]
     xb = S.amax(xin, out=bounds[2 * n_layers])
@@ -159,14 +173,14 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     # per-step prologue for ALL layers, one launch each: weight maxima -> S16 weight packs; activation bounds
     ws = [c.weight.detach() for c in convs]
     S.amax_multi(ws, bounds[n_layers:])
-    packs = [(S.split(ops.pack_weight(ws[0], ld_out=kpad), bounds[n_layers]), None)]
+    w0_packed = ops.pack_weight(ws[0], ld_out=kpad)
+    packs = [(S.split(w0_packed, bounds[n_layers]), None)]
     packs += S.pack_weights_multi(ws[1:], bounds[n_layers + 1:], want_dgrad=save)
     t_len = plan.lengths(t_in0)
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
     S.act_bounds_multi(bns, m_all if sync is None else [sync.rows_total(m_) for m_ in m_all], res_from, p, bounds)
     c_all = [plan.convs[idx].c_out for idx in range(n_layers)]
-    use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
     bits_all = S.new_act_bits(sum(m_ * c_ for m_, c_ in zip(m_all, c_all)) // c_all[0], c_all[0], dev) if use_bits else None
     bits_at = 0
 
@@ -193,6 +207,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
                 bits_at += bits.numel()
             saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0, bits,
                                 x_rows=a if rows_form[idx] else None))
+            if idx == 0 and one_col >= 0:
+                saved[0].one_col, saved[0].w_packed = one_col, w0_packed
         if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:
@@ -245,6 +261,19 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             else:
                 sink.group_done(n_done[0])
         n_done[0] += 1
+
+    # X^T X of the expand layer's input (its no-dy backward, below): a small GEMM with nothing upstream -> second stream
+    gram_xx, gram_ev = None, None
+    if L[0].one_col >= 0:
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gram_xx = S.gram(L[0].x_t)
+                gram_xx.record_stream(main)
+                gram_ev = engine._fork_event(dev, -1)
+                gram_ev.record(side)
+        else:
+            gram_xx = S.gram(L[0].x_t)
 
     o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
     if side is not None:          # nothing in backward reads the shrink gradients: off the dependent chain as well (-0.7 %)
@@ -334,10 +363,25 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         wgrad(i1, dy1_t)
         group_done()
         del dy1, dy1_t
-    dy0, dy0_t = act_bwd(0, dh)
-    # the last weight gradient (expand conv) on the MAIN stream: it runs beside the tail of the first block's wgrad GEMM
-    # (still on the second stream) instead of queueing behind it (-0.4 %)
-    wgrad(0, dy0_t, on_side=False)
+    if L[0].one_col >= 0:
+        # expand layer without dy: G = dh * keep * [z > 0] (one pass over dh), P = G^T X, then dgamma / dbeta / dW from P,
+        # X^T X and the weights (vp3d_expand_bwd_s16) -- no reduce / finalize / apply passes over (dh, y) for this layer
+        spec0 = plan.convs[0]
+        g_t = S.act_mask_t(dh, bounds[0], L[0].bits, p if L[0].drop is not None else 0.0)
+        if gram_ev is not None:
+            main.wait_event(gram_ev)
+        o_w, o_g, o_bt = view(convs[0].weight), view(bns[0].weight), view(bns[0].bias)
+        if o_g is None or o_bt is None:
+            o_g = o_bt = None
+        m0 = L[0].y.shape[0] * L[0].y.shape[1]
+        dw0, dg0, db0 = S.expand_bwd(g_t, L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in, spec0.taps, L[0].one_col,
+                                     out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt)
+        grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)
+    else:
+        dy0, dy0_t = act_bwd(0, dh)
+        # the last weight gradient (expand conv) on the MAIN stream: it runs beside the tail of the first block's wgrad
+        # GEMM (still on the second stream) instead of queueing behind it (-0.4 %)
+        wgrad(0, dy0_t, on_side=False)
     if side is not None:
         main.wait_stream(side)
         keep.clear()

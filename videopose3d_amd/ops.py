@@ -142,16 +142,17 @@ def padded_k(spec: ConvSpec) -> int:
     return 0
 
 
-def im2row(x: torch.Tensor, spec: ConvSpec, kpad: int) -> torch.Tensor:
-    """[B,T_in,C_in] -> [B,T_out,kpad]: row (b,t) = the taps*C_in contiguous floats at x[b, t*stride], zero padded."""
+def im2row(x: torch.Tensor, spec: ConvSpec, kpad: int, one_col: int = -1) -> torch.Tensor:
+    """[B,T_in,C_in] -> [B,T_out,kpad]: row (b,t) = the taps*C_in contiguous floats at x[b, t*stride], zero padded
+    (one_col >= taps*C_in: that padding column holds 1)."""
     _chk(x, "x")
     assert spec.dil == 1
     b, t_in, c_in = x.shape
     t_out = spec.t_out(t_in)
     out = torch.empty((b, t_out, kpad), dtype=torch.float32, device=x.device)
     rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
-    check(_lib.lib().vp3d_im2row(_stream(), C.byref(rm), x.data_ptr(), c_in, spec.taps * c_in, kpad, out.data_ptr()),
-          "vp3d_im2row")
+    check(_lib.lib().vp3d_im2row(_stream(), C.byref(rm), x.data_ptr(), c_in, spec.taps * c_in, kpad, one_col,
+                                 out.data_ptr()), "vp3d_im2row")
     return out
 
 

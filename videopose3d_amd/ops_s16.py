@@ -7,6 +7,7 @@ float that bounds the tensor's magnitude (its exponent is derived from it inside
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -172,6 +173,63 @@ def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, ou
     return out
 
 
+def nt_raw(a_t: S16, b_t: S16) -> Tuple[torch.Tensor, int]:
+    """Raw split-K partials [splits][NA][NB] of  a_t @ b_t^T  for two transposed S16 operands [NA][Mp], [NB][Mp] (rows
+    along the reduction index): the weight-gradient GEMM without its un-pack.  Returns (partials, splits)."""
+    mp = a_t.data.shape[-1]
+    na, nb = a_t.data.shape[0], b_t.data.shape[0]
+    assert b_t.data.shape[-1] == mp
+    dev = a_t.data.device
+    cfg, splits = plan(na, nb, mp, raw=True)
+    o, ws = _opts(a_t, b_t, na, nb, mp, dev, None, cfg, splits, raw=True)
+    rm = RowMap(1, na, na, 1, 0, 0, 1)
+    ops._timed_call("tconv_wgrad", 2.0 * mp * na * nb, _lib.lib().vp3d_tconv_nt_s16,
+                    ops._stream(), C.byref(rm), a_t.data.data_ptr(), mp, mp, b_t.data.data_ptr(), mp, nb,
+                    None, 0, nb, None, ops.zeros_page(dev).data_ptr(), C.byref(o),
+                    nbytes=4.0 * (a_t.data.numel() + b_t.data.numel() + na * nb))
+    return ws, splits
+
+
+def act_mask_t(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float) -> S16:
+    """G = go * keep * [bn(y) > 0] as a transposed S16 operand [C][roundup(M, 64)] (the expand layer's backward)."""
+    ops._chk(go, "go")
+    b, t, c = go.shape
+    m = b * t
+    gt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=go.device)
+    gb = new_bound(go.device)
+    check(_lib.lib().vp3d_act_mask_t_s16(ops._stream(), m, c, go.data_ptr(), go_bound.data_ptr(), act_bits.data_ptr(), float(p),
+                                         gb.data_ptr(), gt.data_ptr(), gt.shape[1]), "vp3d_act_mask_t_s16")
+    return S16(gt, gb)
+
+
+def gram(x_t: S16) -> torch.Tensor:
+    """X^T X [kpad][kpad] as doubles from the transposed S16 copy of X (one small split-K GEMM + the slice sum)."""
+    ws, splits = nt_raw(x_t, x_t)
+    n = x_t.data.shape[0]
+    out = torch.empty((n, n), dtype=torch.float64, device=ws.device)
+    check(_lib.lib().vp3d_sum_slices(ops._stream(), n * n, splits, ws.data_ptr(), out.data_ptr()), "vp3d_sum_slices")
+    return out
+
+
+def expand_bwd(g_t: S16, x_t: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
+               taps: int, one_col: int, out_dw=None, out_dgamma=None, out_dbeta=None):
+    """(dW [C][c_in][taps], dgamma, dbeta) of the expand layer from G^T X, X^T X and the packed weight (see include/vp3d.h)."""
+    c, kpad = g_t.data.shape[0], x_t.data.shape[0]
+    dev = g_t.data.device
+    ws, splits = nt_raw(g_t, x_t)
+    dw = out_dw if out_dw is not None else torch.empty((c, c_in, taps), dtype=torch.float32, device=dev)
+    if out_dgamma is not None and out_dbeta is not None:
+        dgam, dbet = out_dgamma, out_dbeta
+    else:
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        dgam, dbet = dgb[0], dgb[1]
+    check(_lib.lib().vp3d_expand_bwd_s16(ops._stream(), c, c_in, taps, kpad, one_col, m_rows, splits, ws.data_ptr(),
+                                         gram_xx.data_ptr(), w_packed.data_ptr(), coef[0].data_ptr(), coef[2].data_ptr(),
+                                         coef[3].data_ptr(), dgam.data_ptr(), dbet.data_ptr(), dw.data_ptr()),
+          "vp3d_expand_bwd_s16")
+    return dw, dgam, dbet
+
+
 def wgrad_rows_supported(c_out: int, c_in: int) -> bool:
     return c_out % 256 == 0 and c_in % 256 == 0
 
@@ -278,6 +336,20 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
     return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
 
 
+_FUSED_FINALIZE = os.environ.get("VP3D_FUSED_BN_BWD_FINALIZE", "1") != "0"
+_ticket_pool = {}
+
+
+def _tickets(device, n: int) -> torch.Tensor:
+    """Zeroed int32 tickets of the last-arriver reductions, one buffer per (device, stream): the kernels leave them zero,
+    launches on one stream are ordered, so the buffer is allocated (and zeroed) once."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    t = _ticket_pool.get(key)
+    if t is None or t.numel() < n:
+        t = _ticket_pool[key] = torch.zeros(max(n, 256), dtype=torch.int32, device=device)
+    return t
+
+
 def new_act_bits(m_rows: int, c: int, device) -> torch.Tensor:
     """Buffer for the activation bits of an [m_rows, c] activation (1 bit per element)."""
     assert c % 64 == 0
@@ -299,7 +371,29 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     dref = C.byref(drop) if drop is not None else None
     nparts = C.c_int32(0)
     sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
-    if act_bits is not None:
+    if out_dgamma is not None and out_dbeta is not None:
+        dgam, dbet = out_dgamma, out_dbeta
+    else:
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        dgam, dbet = dgb[0], dgb[1]
+    fused_fin = act_bits is not None and sync is None and _FUSED_FINALIZE
+    if fused_fin:
+        # reduction + finalize + bound of dy in ONE launch (last-arriver blocks fold the partial rows): no [C]-sized kernel
+        # that waits for a CU slot behind the second stream's weight-gradient GEMM
+        assert act_bits.numel() * 8 == m * c and act_bits.dtype == torch.uint8
+        ngroups, ntick = C.c_int32(0), C.c_int32(0)
+        pp = float(p) if drop is not None else 0.0
+        check(L.vp3d_bn_bwd_reduce_fin_s16(ops._stream(), m, c, None, None, None, None, None, pp, None, None, None, None, None,
+                                           None, None, None, C.byref(nparts), C.byref(ngroups), C.byref(ntick)),
+              "vp3d_bn_bwd_reduce_fin_s16(query)")
+        parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
+        gparts = torch.empty((ngroups.value, 2, c), dtype=torch.float64, device=y.device)
+        check(L.vp3d_bn_bwd_reduce_fin_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), mu, inv, act_bits.data_ptr(), pp, sc,
+                                           go_bound.data_ptr(), parts.data_ptr(), gparts.data_ptr(),
+                                           _tickets(y.device, ntick.value).data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+                                           dy_bound.data_ptr(), C.byref(nparts), C.byref(ngroups), C.byref(ntick)),
+              "vp3d_bn_bwd_reduce_fin_s16")
+    elif act_bits is not None:
         assert act_bits.numel() * 8 == m * c and act_bits.dtype == torch.uint8
         keep_scale = 1.0 / (1.0 - p) if drop is not None else 1.0
         check(L.vp3d_bn_bwd_reduce_bits(ops._stream(), m, c, None, None, None, None, None, 1.0, None, C.byref(nparts)),
@@ -313,13 +407,9 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
         parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
         check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
                                    C.byref(nparts)), "vp3d_bn_bwd_reduce")
-    if out_dgamma is not None and out_dbeta is not None:
-        dgam, dbet = out_dgamma, out_dbeta
-    else:
-        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
-        dgam, dbet = dgb[0], dgb[1]
-    check(L.vp3d_bn_bwd_finalize_s16(ops._stream(), c, m, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr(), sc,
-                                     go_bound.data_ptr(), float(p), dy_bound.data_ptr()), "vp3d_bn_bwd_finalize_s16")
+    if not fused_fin:
+        check(L.vp3d_bn_bwd_finalize_s16(ops._stream(), c, m, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr(), sc,
+                                         go_bound.data_ptr(), float(p), dy_bound.data_ptr()), "vp3d_bn_bwd_finalize_s16")
     a_g, a_b = dgam, dbet
     if sync is not None:                 # dp.SyncBatchNorm: global sums in the apply kernel and in the bound of dy
         a_g, a_b = ops._sync_sums(dgam, dbet, sync)
