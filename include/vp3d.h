@@ -254,15 +254,16 @@ int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const
 /* Backward of the expand layer without materialising dy (videopose3d_amd/engine_s16.py; replaces autograd's backward of
  * model.py:74,127 for expand_conv / expand_bn when no input gradient is wanted).  With X = the im2row rows of the layer
  * input incl. a bias column of ones (vp3d_im2row one_col) and G = go * keep * [bn(y) > 0]:
- *   vp3d_act_mask_t_s16   G as a transposed S16 operand [C][ld_t] under the bound go_bound/(1-p), published in g_bound
- *                         (32 floats, zeroed by the caller)
- *   vp3d_tconv_nt_s16     raw partials of  P = G^T X [C][kpad]  and of  S = X^T X [kpad][kpad]  (K = rows)
+ *   vp3d_act_mask_s16     G as S16 rows [M][C] (rows_out) and / or as a transposed S16 operand [C][ld_t] (t_out) under
+ *                         the bound go_bound/(1-p), published in g_bound (32 floats, zeroed by the caller)
+ *   vp3d_wgrad_rows_s16 / vp3d_tconv_nt_s16   raw partials of  P = G^T X [C][kpad]  (from the rows when kpad == 128,
+ *                         else from the transposed copies) and of  S = X^T X [kpad][kpad]  (K = rows)
  *   vp3d_sum_slices       S as doubles (slice order)
  *   vp3d_expand_bwd_s16   dbeta = P[:, one_col], dgamma = invstd (<W, P> - mean dbeta), and
  *                         dW = A P + B sX + Cx (W S - mean sX)  (A = scale, B = -A dbeta/M, Cx = -A invstd dgamma/M,
  *                         sX = S[:, one_col]) un-packed to Conv1d.weight layout [C][c_in][taps]. */
-int vp3d_act_mask_t_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
-                        const uint8_t* act_bits, float p, float* g_bound, void* t_out, int64_t ld_t);
+int vp3d_act_mask_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
+                      const uint8_t* act_bits, float p, float* g_bound, void* rows_out, void* t_out, int64_t ld_t);
 int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out);
 int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
                         int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
@@ -273,7 +274,8 @@ int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t t
  *   partials[s][co][tap*c_in + ci] = sum over the rows m of K-slice s of  dy[m][co] * x[m*taps + tap][ci]
  * dy: [M][ld_dy] S16 (exponent of *dy_bound), x: [M*taps][ld_x] S16 (exponent of *x_bound; for a conv of stride == taps
  * these are simply the rows of its input), partials: splits * c_out * taps*c_in floats, summed and un-packed by
- * vp3d_wgrad_reduce(partials, taps*c_in, splits, c_out, c_in, taps, dw).  c_out, c_in % 256 == 0, operands < 2 GiB. */
+ * vp3d_wgrad_reduce(partials, taps*c_in, splits, c_out, c_in, taps, dw).  c_out % 256 == 0, c_in % 256 == 0 or
+ * c_in == 128 (one narrow column tile per tap: the expand conv's 128-wide im2row rows), operands < 2 GiB. */
 int vp3d_wgrad_rows_s16(vp3d_stream_t stream, int64_t M, const void* dy, int64_t ld_dy, int32_t c_out,
                         const float* dy_bound, const void* x, int64_t ld_x, int32_t taps, int32_t c_in,
                         const float* x_bound, int32_t splits, float* partials);

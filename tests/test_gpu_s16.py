@@ -361,7 +361,8 @@ def test_s16_backward_bucket_exchange_through_rccl_single_rank():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("b,t,c_out,c_in,taps", [(8, 9, 256, 256, 3), (5, 13, 512, 256, 1), (64, 27, 256, 512, 3)])
+@pytest.mark.parametrize("b,t,c_out,c_in,taps", [(8, 9, 256, 256, 3), (5, 13, 512, 256, 1), (64, 27, 256, 512, 3),
+                                                 (7, 37, 512, 128, 1), (64, 81, 256, 128, 1)])     # narrow B tile (k_tn_s16<1>)
 def test_wgrad_from_rows_vs_fp64(b, t, c_out, c_in, taps):
     """vp3d_wgrad_rows_s16 (weight gradient straight from the S16 rows of dy and of the conv input, transposing on the
     LDS read) against an fp64 reference on the decoded operands, for ragged row counts (K tail of the 32-row tiles),

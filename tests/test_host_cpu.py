@@ -202,7 +202,8 @@ def test_rows_form_wgrad_split_choice_is_launchable():
             assert s == 1 or nkt // s >= 6
     assert S._wgrad_rows_splits(27648, 1024, 3072) == 16        # 48 tiles x 16 slices = 3 rounds (measured best)
     assert S._wgrad_rows_splits(27648, 1024, 1024) == 16        # 16 tiles x 16 slices = 1 round
-    assert S.wgrad_rows_supported(1024, 1024) and not S.wgrad_rows_supported(1024, 128)
+    assert S.wgrad_rows_supported(1024, 1024) and S.wgrad_rows_supported(1024, 128) and not S.wgrad_rows_supported(1024, 96)
+    assert not S.wgrad_rows_supported(128, 128) and not S.expand_rows_form(1024, 96)
 
 
 def test_common_model_shadow_import_resolves_as_integration_md_says(tmp_path):

@@ -811,8 +811,18 @@ __global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-constexpr int TN_BM = 256, TN_BN = 256, TN_BK = 32, TN_NT = 512, TN_PITCH = 1040;
-constexpr int TN_OP_B = TN_BK * TN_PITCH, TN_STAGE_B = 2 * TN_OP_B, TN_SMEM_B = 2 * TN_STAGE_B;
+constexpr int TN_BM = 256, TN_BK = 32, TN_NT = 512, TN_PITCH = 1040;
+constexpr int TN_OP_B = TN_BK * TN_PITCH;                    // operand image of 32 rows x 256 channels
+// Narrow B operand (128 channels per row: the expand conv's im2row rows): a 1-KiB LDS-DMA piece holds TWO 512-byte
+// rows, so the image is 16 row PAIRS at a pitch of 1056 B (= 264 dwords: pairs {0,4} / {1,5} / {2,6} / {3,7} of a
+// transpose read fall on disjoint bank halves; the two rows of a pair share banks: 2-way on 1/5 of the reads)
+constexpr int TN_PAIR = 1056, TN_OPB128_B = 16 * TN_PAIR;
+template <int CB>
+struct TnGeo {
+  static constexpr int BN = CB * 128;                        // 256 (CB = 2) or 128 (CB = 1) columns of B per tile
+  static constexpr int STAGE_B = TN_OP_B + (CB == 2 ? TN_OP_B : TN_OPB128_B);
+  static constexpr int SMEM_B = 2 * STAGE_B;
+};
 
 struct TnArgs {
   const float* A;          // dy rows  [Mk][lda]   (S16, 4-byte units)
@@ -825,16 +835,19 @@ struct TnArgs {
   int m_tiles, n_tiles, pos, splits, kt_per_split;
 };
 
-__device__ __forceinline__ f16x8 tn_frag(const char* p) {   // 8 k values of one column: two transpose reads, 4 rows apart
+// 8 k values of one column: two transpose reads, `second` bytes (4 rows) apart
+__device__ __forceinline__ f16x8 tn_frag(const char* p, int second = 4 * TN_PITCH) {
   const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
-  const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p + 4 * TN_PITCH));
+  const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p + second));
   const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(f16x8, v);
 }
 
+template <int CB>
 __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
-  constexpr int RB = 4, CB = 2;
-  __shared__ __attribute__((aligned(16))) char smem[TN_SMEM_B];
+  constexpr int RB = 4;
+  using G = TnGeo<CB>;
+  __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / 4, wn = w % 4;
@@ -842,8 +855,8 @@ __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
   const int bid = blockIdx.x - split * p.pos;
   int tile_m, tile_n;
   if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos >> 3, tile_m, tile_n)) return;
-  const int na0 = tile_m * TN_BM, nb0 = tile_n * TN_BN;
-  const int tap = nb0 / p.c_in, ci0 = nb0 - tap * p.c_in;        // a column tile lies inside one tap (C_in % 256 == 0)
+  const int na0 = tile_m * TN_BM, nb0 = tile_n * G::BN;
+  const int tap = nb0 / p.c_in, ci0 = nb0 - tap * p.c_in;        // a column tile lies inside one tap (C_in % BN == 0)
   const int nkt_all = (p.Mk + TN_BK - 1) / TN_BK;
   const int kt_begin = split * p.kt_per_split;
   const int nkt = max(0, min(nkt_all, kt_begin + p.kt_per_split) - kt_begin);
@@ -859,33 +872,45 @@ __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
   // LDS-DMA: wave w owns rows 4w .. 4w+3 of both operands; rows >= Mk lie beyond num_records and arrive as zeros
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  int a_vo[4], b_vo[4];
+  constexpr int NPB = CB == 2 ? 4 : 2;                       // B pieces per wave: one per row, or one per row pair
+  int a_vo[4], b_vo[NPB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t r = (int64_t)kt_begin * TN_BK + w * 4 + i;
-    const int64_t ao = (r * p.lda + na0) * 4 + lane * 16, bo = ((r * p.taps + tap) * p.ldb + ci0) * 4 + lane * 16;
+    const int64_t ao = (r * p.lda + na0) * 4 + lane * 16;
     a_vo[i] = ao < (int64_t)p.a_bytes ? (int)ao : kOob;
+  }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int64_t r = (int64_t)kt_begin * TN_BK + w * 4 + (CB == 2 ? i : 2 * i + (lane >> 5));
+    const int64_t bo = ((r * p.taps + tap) * p.ldb + ci0) * 4 + (CB == 2 ? lane : (lane & 31)) * 16;
     b_vo[i] = bo < (int64_t)p.b_bytes ? (int)bo : kOob;
   }
   const int a_step = TN_BK * p.lda * 4, b_step = TN_BK * p.taps * p.ldb * 4;
   auto issue = [&](int stage) {
-    char* sA = smem + stage * TN_STAGE_B;
+    char* sA = smem + stage * G::STAGE_B;
 #pragma unroll
     for (int i = 0; i < 4; ++i) blds16(rsA, a_vo[i], sA + (w * 4 + i) * TN_PITCH);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) blds16(rsB, b_vo[i], sA + TN_OP_B + (w * 4 + i) * TN_PITCH);
+    for (int i = 0; i < NPB; ++i)
+      blds16(rsB, b_vo[i], sA + TN_OP_B + (CB == 2 ? (w * 4 + i) * TN_PITCH : (w * 2 + i) * TN_PAIR));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {          // (offsets past the end stay past the end: operands are < 2 GiB, kOob = 2^31)
+    for (int i = 0; i < 4; ++i)             // (offsets past the end stay past the end: operands are < 2 GiB, kOob = 2^31)
       a_vo[i] = (unsigned)a_vo[i] + (unsigned)a_step < 0x80000000u ? a_vo[i] + a_step : kOob;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
       b_vo[i] = (unsigned)b_vo[i] + (unsigned)b_step < 0x80000000u ? b_vo[i] + b_step : kOob;
-    }
   };
 
   const int g = lane >> 4, sl = lane & 15, h = g >> 1;
   const int rsel = ((sl >> 2) & 1) + 8 * ((sl >> 3) & 1) + 2 * h;          // {0,1,8,9}[sl >> 2] + 2h
-  const int off_lane = rsel * TN_PITCH + (g & 1) * 64 + ((sl & 3) >> 1) * 32 + ((sl & 3) & 1) * 8;
-  const int a_off = wm * (RB * 32) * 4 + off_lane;
-  const int b_off = TN_OP_B + wn * (CB * 32) * 4 + off_lane;
+  const int col_lane = (g & 1) * 64 + ((sl & 3) >> 1) * 32 + ((sl & 3) & 1) * 8;
+  const int a_off = wm * (RB * 32) * 4 + rsel * TN_PITCH + col_lane;
+  // row r of the narrow B image sits at (r >> 1) * TN_PAIR + (r & 1) * 512
+  const int b_off = TN_OP_B + (CB == 2 ? wn * (CB * 32) * 4 + rsel * TN_PITCH
+                                       : wn * 128 + (4 * ((sl >> 3) & 1) + h) * TN_PAIR + ((sl >> 2) & 1) * 512) + col_lane;
+  constexpr int B_SECOND = CB == 2 ? 4 * TN_PITCH : 2 * TN_PAIR;          // 4 rows further
+  constexpr int B_KSTEP = CB == 2 ? 16 * TN_PITCH : 8 * TN_PAIR;          // 16 rows further
 
   if (nkt > 0) {
     issue(0);
@@ -893,7 +918,7 @@ __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
     for (int it = 0; it < nkt; ++it) {
       wait_vmcnt<0>();
       __syncthreads();
-      const char* sS = smem + st * TN_STAGE_B;
+      const char* sS = smem + st * G::STAGE_B;
       // All fragment reads of the tile first, THEN the LDS-DMA of the next tile (other stage), then the MFMAs: hipcc
       // cannot prove that a transpose read does not alias an LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of
       // the first read that follows one -- issued ahead of the reads (as k_nt_s16 does) the DMA would be waited for
@@ -908,8 +933,8 @@ __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
-          bh[ks][j] = tn_frag(sS + b_off + j * 128 + ks * 16 * TN_PITCH);
-          bl[ks][j] = tn_frag(sS + b_off + j * 128 + ks * 16 * TN_PITCH + 16);
+          bh[ks][j] = tn_frag(sS + b_off + j * 128 + ks * B_KSTEP, B_SECOND);
+          bl[ks][j] = tn_frag(sS + b_off + j * 128 + ks * B_KSTEP + 16, B_SECOND);
         }
       }
       if (it + 1 < nkt) issue(st ^ 1);
@@ -1122,10 +1147,11 @@ int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld
                           const float* x, int64_t ld_x, int32_t taps, int32_t c_in, const float* x_bound, int32_t splits,
                           float* part) {
   const int64_t a_bytes = Mk * ld_dy * 4, b_bytes = Mk * taps * ld_x * 4;
+  const bool narrow = c_in == 128;                       // one 128-column tile per tap (the expand conv's im2row rows)
   VP3D_REQUIRE(Mk > 0 && dy && x && part && dy_bound && x_bound && taps >= 1 && c_out > 0 && c_in > 0 && c_out % 256 == 0 &&
-                   c_in % 256 == 0 && ld_dy >= c_out && ld_x >= c_in && ld_dy % 8 == 0 && ld_x % 8 == 0 && aligned16(dy) &&
-                   aligned16(x) && aligned16(part),
-               "wgrad_rows_s16: needs c_out, c_in %% 256 == 0 and 16-byte aligned S16 rows");
+                   (c_in % 256 == 0 || narrow) && ld_dy >= c_out && ld_x >= c_in && ld_dy % 8 == 0 && ld_x % 8 == 0 &&
+                   aligned16(dy) && aligned16(x) && aligned16(part),
+               "wgrad_rows_s16: needs c_out %% 256 == 0, c_in %% 256 == 0 (or == 128) and 16-byte aligned S16 rows");
   VP3D_REQUIRE(a_bytes < ((int64_t)1 << 31) && b_bytes < ((int64_t)1 << 31), "wgrad_rows_s16: operands must stay below 2 GiB");
   const int nkt = (int)((Mk + TN_BK - 1) / TN_BK);
   VP3D_REQUIRE(splits >= 1 && splits <= nkt, "wgrad_rows_s16: splits=%d for %d K-tiles", splits, nkt);
@@ -1133,11 +1159,12 @@ int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld
   a.A = dy; a.B = x; a.part = part; a.bound_a = dy_bound; a.bound_b = x_bound;
   a.Mk = (int)Mk; a.lda = (int)ld_dy; a.ldb = (int)ld_x; a.NA = c_out; a.NB = taps * c_in; a.taps = taps; a.c_in = c_in;
   a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
-  a.m_tiles = c_out / TN_BM; a.n_tiles = a.NB / TN_BN;
+  a.m_tiles = c_out / TN_BM; a.n_tiles = a.NB / (narrow ? 128 : 256);
   a.pos = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);
   a.splits = splits;
   a.kt_per_split = (nkt + splits - 1) / splits;
-  hipLaunchKernelGGL(k_tn_s16, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
+  if (narrow) hipLaunchKernelGGL(k_tn_s16<1>, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
+  else hipLaunchKernelGGL(k_tn_s16<2>, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
   return check_launch("wgrad_rows_s16");
 }
 

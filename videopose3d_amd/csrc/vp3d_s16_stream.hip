@@ -765,6 +765,7 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
   double P[4] = {0.0, 0.0, 0.0, 0.0};
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   if (live) {
+#pragma unroll 8
     for (int s = 0; s < splits; ++s) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(pws + ((int64_t)s * C + c) * kpad + j0);
 #pragma unroll
@@ -797,10 +798,15 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
   }
   const double B = -A * db * inv_m, Cx = -A * is * dg * inv_m;
   double T[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = 0; i < kv; ++i) {
+#pragma unroll 6
+  for (int i = 0; i < kv; ++i) {                       // (unrolled: the loads of several rows of S in flight, not one)
     const double wi = (double)w_s[cl][i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) T[e] += wi * S[(int64_t)i * kpad + j0 + e];
+    const double2 s01 = *reinterpret_cast<const double2*>(S + (int64_t)i * kpad + j0);
+    const double2 s23 = *reinterpret_cast<const double2*>(S + (int64_t)i * kpad + j0 + 2);
+    T[0] += wi * s01.x;
+    T[1] += wi * s01.y;
+    T[2] += wi * s23.x;
+    T[3] += wi * s23.y;
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -881,15 +887,15 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
   return check_launch("bn_bwd_apply_s16");
 }
 
-int vp3d_act_mask_t_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
-                        const uint8_t* act_bits, float p, float* g_bound, void* t_out, int64_t ld_t) {
-  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && go_bound && act_bits && g_bound && t_out &&
-                   p >= 0.f && p < 1.f && aligned16(go),
-               "act_mask_t_s16: bad argument (needs C %% 64 == 0, 16-byte aligned rows)");
-  int rc = check_t("act_mask_t_s16", t_out, ld_t, 1, M);
+int vp3d_act_mask_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* go_bound,
+                      const uint8_t* act_bits, float p, float* g_bound, void* rows_out, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && go && go_bound && act_bits && g_bound &&
+                   (rows_out || t_out) && p >= 0.f && p < 1.f && aligned16(go) && aligned16(rows_out),
+               "act_mask_s16: bad argument (needs C %% 64 == 0, 16-byte aligned rows)");
+  int rc = check_t("act_mask_s16", t_out, ld_t, 1, M);
   if (rc) return rc;
   TOut t{(float*)t_out, ld_t, 1};
-  const size_t lds = (size_t)64 * TPITCH * 4;
+  const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
   const int64_t ntiles = (M + 63) / 64, gx = C / 64;
   int64_t per_block = gx * ntiles / 2048;
   per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
@@ -899,8 +905,8 @@ int vp3d_act_mask_t_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   hipLaunchKernelGGL((k_bn_bwd_apply_s16<true, true>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, (int)M,
                      C, go, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, d, act_bits, 1.0f / (1.0f - p), (const float*)nullptr, (const float*)nullptr, go_bound,
-                     (float*)nullptr, t, g_bound);
-  return check_launch("act_mask_t_s16");
+                     (float*)rows_out, t, g_bound);
+  return check_launch("act_mask_s16");
 }
 
 int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out) {

@@ -209,6 +209,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
                                 x_rows=a if rows_form[idx] else None))
             if idx == 0 and one_col >= 0:
                 saved[0].one_col, saved[0].w_packed = one_col, w0_packed
+                if S.expand_rows_form(spec.c_out, kpad):
+                    saved[0].x_rows = a                  # P = G^T X reads the rows; the transposed copy only feeds X^T X
         if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:
@@ -367,15 +369,16 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         # expand layer without dy: G = dh * keep * [z > 0] (one pass over dh), P = G^T X, then dgamma / dbeta / dW from P,
         # X^T X and the weights (vp3d_expand_bwd_s16) -- no reduce / finalize / apply passes over (dh, y) for this layer
         spec0 = plan.convs[0]
-        g_t = S.act_mask_t(dh, bounds[0], L[0].bits, p if L[0].drop is not None else 0.0)
+        rows0 = L[0].x_rows is not None
+        g0 = S.act_mask(dh, bounds[0], L[0].bits, p if L[0].drop is not None else 0.0, transposed=not rows0)
         if gram_ev is not None:
             main.wait_event(gram_ev)
         o_w, o_g, o_bt = view(convs[0].weight), view(bns[0].weight), view(bns[0].bias)
         if o_g is None or o_bt is None:
             o_g = o_bt = None
         m0 = L[0].y.shape[0] * L[0].y.shape[1]
-        dw0, dg0, db0 = S.expand_bwd(g_t, L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in, spec0.taps, L[0].one_col,
-                                     out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt)
+        dw0, dg0, db0 = S.expand_bwd(g0, L[0].x_rows if rows0 else L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in,
+                                     spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt)
         grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)
     else:
         dy0, dy0_t = act_bwd(0, dh)

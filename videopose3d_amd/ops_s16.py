@@ -190,16 +190,18 @@ def nt_raw(a_t: S16, b_t: S16) -> Tuple[torch.Tensor, int]:
     return ws, splits
 
 
-def act_mask_t(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float) -> S16:
-    """G = go * keep * [bn(y) > 0] as a transposed S16 operand [C][roundup(M, 64)] (the expand layer's backward)."""
+def act_mask(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float, transposed: bool) -> S16:
+    """G = go * keep * [bn(y) > 0] (the expand layer's backward) as S16 rows [B,T,C], or as a transposed S16 operand
+    [C][roundup(M, 64)]."""
     ops._chk(go, "go")
     b, t, c = go.shape
     m = b * t
-    gt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=go.device)
+    out = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=go.device) if transposed else torch.empty_like(go)
     gb = new_bound(go.device)
-    check(_lib.lib().vp3d_act_mask_t_s16(ops._stream(), m, c, go.data_ptr(), go_bound.data_ptr(), act_bits.data_ptr(), float(p),
-                                         gb.data_ptr(), gt.data_ptr(), gt.shape[1]), "vp3d_act_mask_t_s16")
-    return S16(gt, gb)
+    check(_lib.lib().vp3d_act_mask_s16(ops._stream(), m, c, go.data_ptr(), go_bound.data_ptr(), act_bits.data_ptr(), float(p),
+                                       gb.data_ptr(), None if transposed else out.data_ptr(), out.data_ptr() if transposed else None,
+                                       out.shape[1] if transposed else 0), "vp3d_act_mask_s16")
+    return S16(out, gb)
 
 
 def gram(x_t: S16) -> torch.Tensor:
@@ -211,12 +213,30 @@ def gram(x_t: S16) -> torch.Tensor:
     return out
 
 
-def expand_bwd(g_t: S16, x_t: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
-               taps: int, one_col: int, out_dw=None, out_dgamma=None, out_dbeta=None):
-    """(dW [C][c_in][taps], dgamma, dbeta) of the expand layer from G^T X, X^T X and the packed weight (see include/vp3d.h)."""
-    c, kpad = g_t.data.shape[0], x_t.data.shape[0]
-    dev = g_t.data.device
-    ws, splits = nt_raw(g_t, x_t)
+def expand_rows_form(c_out: int, kpad: int) -> bool:
+    """P = G^T X straight from the S16 rows (k_tn_s16<1>, the narrow-B form of the rows-form weight gradient) instead of
+    from transposed copies.  Opt-in (VP3D_EXPAND_ROWS=1): measured SLOWER than the NT GEMM on transposed copies for this
+    shape (M 82,944 x 1024 x 128 stand-alone: 137 us vs 110 us, tools/expand_bwd_bench.py) -- with a 128-column B tile
+    the kernel issues 20 transpose reads per 12 MFMAs and is LDS-bound."""
+    return os.environ.get("VP3D_EXPAND_ROWS", "0") == "1" and kpad == 128 and c_out % 256 == 0
+
+
+def expand_bwd(g: S16, x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
+               taps: int, one_col: int, rows: bool, out_dw=None, out_dgamma=None, out_dbeta=None):
+    """(dW [C][c_in][taps], dgamma, dbeta) of the expand layer from G^T X, X^T X and the packed weight (see include/vp3d.h).
+    rows: g [.., C] and x [.., kpad] are S16 rows (vp3d_wgrad_rows_s16); else both are transposed operands [C or kpad][Mp]."""
+    dev = g.data.device
+    if rows:
+        c, kpad = g.data.shape[-1], x.data.shape[-1]
+        assert expand_rows_form(c, kpad) and g.data.numel() // c == m_rows and x.data.numel() // kpad == m_rows
+        splits = max(1, min(64, ((m_rows + 31) // 32) // 6, 512 // (c // 256)))
+        ws = torch.empty((splits, c, kpad), dtype=torch.float32, device=dev)
+        ops._timed_call("tconv_wgrad", 2.0 * m_rows * c * kpad, _lib.lib().vp3d_wgrad_rows_s16, ops._stream(), m_rows,
+                        g.data.data_ptr(), c, c, g.bound_ptr(), x.data.data_ptr(), kpad, 1, kpad, x.bound_ptr(), splits,
+                        ws.data_ptr(), nbytes=4.0 * (g.data.numel() + x.data.numel() + c * kpad))
+    else:
+        c, kpad = g.data.shape[0], x.data.shape[0]
+        ws, splits = nt_raw(g, x)
     dw = out_dw if out_dw is not None else torch.empty((c, c_in, taps), dtype=torch.float32, device=dev)
     if out_dgamma is not None and out_dbeta is not None:
         dgam, dbet = out_dgamma, out_dbeta
@@ -231,12 +251,12 @@ def expand_bwd(g_t: S16, x_t: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor
 
 
 def wgrad_rows_supported(c_out: int, c_in: int) -> bool:
-    return c_out % 256 == 0 and c_in % 256 == 0
+    return c_out % 256 == 0 and (c_in % 256 == 0 or c_in == 128)
 
 
 def _wgrad_rows_splits(m_rows: int, c_out: int, n_cols: int) -> int:
     """K-slices of the 256x256 rows-form wgrad GEMM: the S16 planner's 256x256 cost terms (plan_nt_s16)."""
-    tiles, nkt = (c_out // 256) * (n_cols // 256), (m_rows + 31) // 32
+    tiles, nkt = (c_out // 256) * max(1, n_cols // 256), (m_rows + 31) // 32
     best, best_s = None, 1
     for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
         if s > 1 and nkt // s < 6:
