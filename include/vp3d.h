@@ -251,6 +251,11 @@ int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const
                                const float* scale, const float* go_bound, float* partials, double* group_partials,
                                int32_t* tickets, float* dgamma, float* dbeta, float* dy_bound, int32_t* nparts,
                                int32_t* ngroups, int32_t* ntickets);
+/* Transposed operand of a conv's weight gradient from the S16 ROWS of the conv's input, for any (stride, dilation, taps):
+ *   t_out[(k*C + c)*ld_t + m] = x[b][t*t_stride + t_off + k*tap_step][c],  m = b*t_dst + t  (zero for rows out of range and
+ *   for m >= M up to the next multiple of 64).  The strided forward producers write this layout directly when the windows
+ *   tile the input; the dilated class / ragged windows build it in backward.  The values keep their exponent. */
+int vp3d_gather_t_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* x, int32_t C, void* t_out, int64_t ld_t);
 /* Backward of the expand layer without materialising dy (videopose3d_amd/engine_s16.py; replaces autograd's backward of
  * model.py:74,127 for expand_conv / expand_bn when no input gradient is wanted).  With X = the im2row rows of the layer
  * input incl. a bias column of ones (vp3d_im2row one_col) and G = go * keep * [bn(y) > 0]:

@@ -231,11 +231,13 @@ def test_unsupported_configurations_fall_back_to_fp32_kernels():
     from videopose3d_amd import engine_s16
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=48)        # channels % 64 != 0
     assert m.math == V.default_math() and not engine_s16.supported(m, 27, True)
-    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128)                   # dilated training -> fp32
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128)                   # the dilated class trains on S16 as well
+    assert engine_s16.supported(m, 27, True) and engine_s16.supported(m, 27, False)
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128, dense=True)       # ... unless its dense kernels are > 8 taps wide
     assert not engine_s16.supported(m, 27, True) and engine_s16.supported(m, 27, False)
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=128)
-    assert engine_s16.supported(m, 27, True) and not engine_s16.supported(m, 28, True)
-    assert not engine_s16.supported(m, 27, True, need_dx=True)
+    assert engine_s16.supported(m, 27, True) and engine_s16.supported(m, 28, True)
+    assert engine_s16.supported(m, 27, True, need_dx=True)
     # and calls too small to be compute-bound stay on the fp32 kernels (launch-latency regime)
     from videopose3d_amd import engine
     engine.S16_MIN_FORWARD_FLOPS.update({True: 60e9, False: 35e9})
@@ -401,3 +403,60 @@ def test_model_gradients_with_rows_form_wgrad(monkeypatch):
     torch.mean(torch.norm(y_b - tgt, dim=3)).backward()
     for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
         assert float((pa.grad - pb.grad).abs().max() / (pa.grad.abs().max() + 1e-30)) < 2e-5, k
+
+
+@pytest.mark.parametrize("kind,fw,causal,t_in,c", [("dilated", [3, 3, 3], False, 40, 128), ("dilated", [3, 3, 3], True, 33, 64),
+                                                   ("strided", [3, 3, 3], False, 29, 128), ("strided", [3, 5, 3], True, 47, 64),
+                                                   ("dilated", [3, 5, 3], False, 50, 256), ("strided", [3, 3, 3], False, 27, 256)])
+def test_general_training_configurations_and_input_gradient(kind, fw, causal, t_in, c):
+    """Everything run.py:171-184 can construct trains on the split-fp16 engine: the dilated class (gather-form data
+    gradient, weight-gradient operand gathered from the saved rows), strided windows that do not tile the input, 5-tap
+    filters, causal variants, and the gradient w.r.t. the input -- all parameter gradients, the input gradient, outputs
+    and running statistics against the fp32 engine on the same weights / dropout stream (which the golden tests pin)."""
+    import copy
+    from videopose3d_amd import engine
+    torch.manual_seed(7)
+    cls = V.TemporalModel if kind == "dilated" else V.TemporalModelOptimized1f
+    m32 = cls(17, 2, 17, fw, causal=causal, dropout=0.25, channels=c).to(DEV).train()
+    m32.math = "f32"
+    m16 = copy.deepcopy(m32)
+    m16.math = "f16x3"
+    for m in (m32, m16):
+        m._drop_seed, m._drop_calls = 123, 0
+    assert engine.use_s16(m16, t_in, True, True, batch=6)
+    x0 = (torch.randn(6, t_in, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+    outs, dxs = [], []
+    engine.ENGINE_CALLS.clear()
+    for m in (m32, m16):
+        x = x0.clone().requires_grad_(True)
+        yv = m(x)
+        tgt = torch.randn(yv.shape, generator=torch.Generator().manual_seed(3)).to(DEV) * 0.3
+        torch.mean(torch.norm(yv - tgt, dim=3)).backward()
+        outs.append(yv.detach())
+        dxs.append(x.grad.clone())
+    assert engine.ENGINE_CALLS["s16_train"] == 1 and engine.ENGINE_CALLS["f32_train"] == 1
+    assert float(torch.mean(torch.norm(outs[0] - outs[1], dim=3))) < 1e-5
+    assert float((dxs[0] - dxs[1]).abs().max() / (dxs[0].abs().max() + 1e-30)) < 1e-4
+    for (k, a), (_, q) in zip(m16.named_parameters(), m32.named_parameters()):
+        assert float((a.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)) < 1e-4, k
+    for (k, a), (_, q) in zip(m16.named_buffers(), m32.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, q, rtol=1e-5, atol=1e-6), k
+
+
+def test_gather_transposed_operand_vs_torch():
+    """vp3d_gather_t_s16: T[(k*C + c)][b*t_out + t] = x[b][t*stride + k*dil][c] for a dilated and a ragged strided conv."""
+    g = torch.Generator().manual_seed(5)
+    b, t_in, c = 3, 41, 128
+    x = torch.randn(b, t_in, c, generator=g).to(DEV)
+    xs = S.split(x)
+    xv = S.join(xs)
+    for spec in (ConvSpec(c, c, 3, 9, 1), ConvSpec(c, c, 3, 1, 3), ConvSpec(c, c, 5, 1, 5)):
+        t_out = spec.t_out(t_in)
+        got = S.join(S.gather_t(xs, spec, t_out))
+        m = b * t_out
+        assert got.shape == (spec.taps * c, S.t_pitch(m))
+        for k in range(spec.taps):
+            rows = xv[:, k * spec.dil: k * spec.dil + (t_out - 1) * spec.stride + 1: spec.stride]      # [b, t_out, c]
+            assert torch.equal(got[k * c:(k + 1) * c, :m], rows.reshape(m, c).t().contiguous()), (spec, k)
+        assert float(got[:, m:].abs().max()) == 0.0

@@ -147,14 +147,17 @@ def test_engine_selection_by_arithmetic_and_size():
     assert engine.use_s16(big, 243, True, batch=1024)
     assert engine.use_s16(big, 243, True, batch=128)                      # 45 GFLOP: already pays (tools/small_modes.py)
     assert not engine.use_s16(big, 243, True, batch=64)                   # launch-latency regime
-    assert not engine.use_s16(big, 243, True, need_dx=True, batch=1024)   # input gradients: fp32 engine
-    assert not engine.use_s16(big, 244, True, batch=1024)                 # windows that do not tile
+    assert engine.use_s16(big, 243, True, need_dx=True, batch=1024)       # input gradients (expand layer on the fp32 kernels)
+    assert engine.use_s16(big, 244, True, batch=1024)                     # windows that do not tile
     big.math = "f32"
     assert not engine.use_s16(big, 243, True, batch=1024)
     ev = V.TemporalModel(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
     ev.math = "f16x3"
     assert engine.use_s16(ev, 243, False, batch=1024) and not engine.use_s16(ev, 300, False, batch=2)
-    assert not engine.use_s16(ev, 243, True, batch=1024)                  # training of the dilated class
+    assert engine.use_s16(ev, 243, True, batch=1024)                      # training of the dilated class
+    dense = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=1024, dense=True)
+    dense.math = "f16x3"
+    assert engine.use_s16(dense, 243, False, batch=1024) and not engine.use_s16(dense, 243, True, batch=1024)   # 19-tap convs
     odd = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=48)
     odd.math = "f16x3"
     assert not engine.use_s16(odd, 100, False, batch=4096)                # channels % 64 != 0

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vp3d_bn_bwd_reduce_fin_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _P(_i32), _P(_i32), _P(_i32)]),
     "vp3d_act_mask_s16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64]),
+    "vp3d_gather_t_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _vp, _i64]),
     "vp3d_sum_slices": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "vp3d_expand_bwd_s16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp]),

@@ -731,6 +731,41 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_bwd_finalize_bound(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// S16 rows x[B][t_src][C] -> the transposed operand of a conv's weight gradient for ANY (stride, dilation, taps):
+//     T[(k*C + c)][m] = x[b][t*t_stride + t_off + k*tap_step][c],   m = b*t_dst + t      (zero beyond M, out of range)
+// i.e. the layout the forward producers write for strided convs whose windows tile the input, built on demand (in
+// backward, from the saved rows) for the dilated class, for windows that do not tile and for wider filters.
+// grid = (C/64, row tiles of 64, taps); values keep their exponent (decode hi + lo, re-split: value-preserving).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_t_s16(int M, int C, int t_dst, int t_src, int t_stride, int tap_step,
+                                                      int t_off, const float* __restrict__ x, TOut t) {
+  extern __shared__ float tile[];
+  const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
+  const int k = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * 64;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = rsub + it * 32;
+    const int64_t m = m0 + r;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const int b = (int)(m / t_dst);
+      const int tt = (int)(m - (int64_t)b * t_dst) * t_stride + t_off + k * tap_step;
+      if ((unsigned)tt < (unsigned)t_src) {
+        const f16x8* rp = reinterpret_cast<const f16x8*>(x + ((int64_t)b * t_src + tt) * C + c);
+        s16_join8(rp[0], rp[1], 1.f, v);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r * TPITCH + g8 * 8 + e] = v[e];
+  }
+  __syncthreads();
+  TOut tk{t.ptr + (int64_t)k * C * t.ld, t.ld, 1};
+  tile_store_t(tile, tk, C, c0, m0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Backward of the expand layer (conv -> BatchNorm -> ReLU -> dropout) WITHOUT materialising dy.  The layer has no data
 // gradient to produce and its conv is linear in a 128-column operand X (im2row rows with a bias column of ones), so with
 // G = go * keep * [z>0] (vp3d_act_mask_t_s16) everything follows from two small reductions over the rows,
@@ -907,6 +942,25 @@ int vp3d_act_mask_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* g
                      (const float*)nullptr, d, act_bits, 1.0f / (1.0f - p), (const float*)nullptr, (const float*)nullptr, go_bound,
                      (float*)rows_out, t, g_bound);
   return check_launch("act_mask_s16");
+}
+
+int vp3d_gather_t_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* x, int32_t C, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(map && x && t_out && C > 0 && C % 64 == 0 && map->batch > 0 && map->t_dst > 0 && map->t_src > 0 && map->taps >= 1 &&
+                   aligned16(x),
+               "gather_t_s16: bad argument (needs C %% 64 == 0, 16-byte aligned S16 rows)");
+  const int64_t M = (int64_t)map->batch * map->t_dst;
+  VP3D_REQUIRE(M < ((int64_t)1 << 31) && (M + 63) / 64 <= 65535 * (int64_t)64 && map->taps <= 65535,
+               "gather_t_s16: too many rows (M=%lld)", (long long)M);
+  int rc = check_t("gather_t_s16", t_out, ld_t, 1, M);
+  if (rc) return rc;
+  VP3D_REQUIRE((M + 63) / 64 <= 2147483647 / 1, "gather_t_s16: grid");
+  TOut t{(float*)t_out, ld_t, 1};
+  const int64_t tiles = (M + 63) / 64;
+  VP3D_REQUIRE(tiles <= 65535, "gather_t_s16: more than 65535 row tiles (M=%lld)", (long long)M);
+  hipLaunchKernelGGL(k_gather_t_s16, dim3(C / 64, (unsigned)tiles, map->taps), dim3(256), (size_t)64 * TPITCH * 4,
+                     (hipStream_t)stream, (int)M, C, map->t_dst, map->t_src, map->t_stride, map->tap_step, map->t_off,
+                     (const float*)x, t);
+  return check_launch("gather_t_s16");
 }
 
 int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out) {

@@ -350,7 +350,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     if use_s16(mod, x3.shape[1], True, need_dx, batch=x3.shape[0]):
         from . import engine_s16
         ENGINE_CALLS["s16_train"] += 1
-        out, saved = engine_s16.forward_train(mod, x3, save)
+        out, saved = engine_s16.forward_train(mod, x3, save, need_dx)
         if saved is not None:
             saved["s16"] = True
         return out, saved

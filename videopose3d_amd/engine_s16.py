@@ -31,21 +31,28 @@ from ._lib import RowMap
 from .plan import ConvSpec, StackPlan
 
 
+MAX_TRAIN_TAPS = 8      # widest conv the training path packs / gathers (dense=True models with pad >= 4 train on the fp32 kernels)
+
+
 def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
+    """What the split-fp16 engine implements: channel counts that are multiples of 64 and an expand conv of at most 128
+    input columns (taps * J_in * in_features; 17 x 2 x 3 = 102).  Training covers both classes (dilated / strided), causal
+    or not, any window length and filter widths up to 8 taps per conv -- a dense=True model with wider kernels (2*pad + 1
+    taps: its weight-gradient operand would be taps times the activation) trains on the fp32 kernels.  Input gradients are
+    produced by the fp32 kernels for the expand layer only."""
     plan: StackPlan = mod._plan
     c = plan.convs[0].c_out
     if c % 64 != 0 or plan.convs[0].c_in * plan.convs[0].taps > 128:
         return False
     if not training:
         return True
-    if need_dx or plan.kind != "strided" or max(plan.filter_widths) > 3:
-        return False
-    t = t_in
-    for spec in plan.convs:
-        if spec.taps > 1 and spec.taps * spec.t_out(t) != t:
-            return False
-        t = spec.t_out(t)
-    return True
+    return max(spec.taps for spec in plan.convs) <= MAX_TRAIN_TAPS
+
+
+def _tiles(spec: ConvSpec, t_in: int) -> bool:
+    """The conv's windows are disjoint and cover its input exactly (what run.py trains the strided class on): the conv is
+    a reshape GEMM, and the transposed weight-gradient operand is a plain re-layout the forward producer can write."""
+    return spec.dil == 1 and spec.stride == spec.taps and spec.taps * spec.t_out(t_in) == t_in
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -107,11 +114,13 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 # training (strided model)
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows", "one_col", "w_packed")
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows", "one_col", "w_packed", "wform", "xin_f32")
 
     def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits, x_rows=None):
         self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
         self.one_col, self.w_packed = -1, None   # expand layer: bias column of the im2row rows, fp32 weight pack (shortcut)
+        self.wform = "tcopy"      # weight-gradient form: "rows" (x_rows), "tcopy" (x_t from the producer), "gather" (x_rows ->
+        self.xin_f32 = None       # vp3d_gather_t_s16 in backward); expand layer with an input gradient: fp32 im2row rows
         self.x_rows = x_rows      # rows-form wgrad (wgrad_from_rows): the layer input as S16 rows instead of x_t
         self.bits = bits          # activation bits ([bn(y) > 0 and kept], 1 bit / element): what backward reads instead
                                   # of regenerating the Philox mask
@@ -135,7 +144,30 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
     return kv
 
 
-def forward_train(mod, x3: torch.Tensor, save: bool):
+def _packs(ws, specs, bounds, want_dgrad: bool):
+    """[(S16 forward pack, S16 dgrad pack or None)] for the C x C convs.  One launch for the stack when every conv is a
+    strided one of <= 3 taps (the benchmark configuration); else per layer, with the dgrad pack in the form the conv's
+    data gradient reads: [(k, ci)][co] for the reshape GEMM of a strided conv, [ci][k * C_out + co] for the gather form."""
+    if all(sp.stride == sp.taps and sp.dil == 1 and sp.taps <= 3 for sp in specs):
+        return S.pack_weights_multi(ws, bounds, want_dgrad=want_dgrad)
+    out = []
+    for i, (w, sp) in enumerate(zip(ws, specs)):
+        gather = sp.stride == 1
+        if sp.taps <= 3:
+            out.append(S.pack_weight(w, bounds[i], want_dgrad=want_dgrad, dilated_form=gather))
+            continue
+        # wider filters (rare: -arc 3,5,3 ...): re-layout with torch, split with the row kernel
+        c_out, c_in, taps = w.shape
+        wf = S.split(ops.pack_weight(w), bounds[i])
+        wd = None
+        if want_dgrad:
+            wd = S.split(w.permute(1, 2, 0).reshape(c_in, taps * c_out).contiguous() if gather
+                         else w.permute(2, 1, 0).reshape(taps * c_in, c_out).contiguous(), bounds[i])
+        out.append((wf, wd))
+    return out
+
+
+def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     plan: StackPlan = mod._plan
     plan.lengths(x3.shape[1])
     convs, bns = engine._convs(mod), engine._bns(mod)
@@ -153,7 +185,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
 
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
     use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
-    one_col = expand_shortcut_column(plan, sync) if use_bits else -1
+    one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
     xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
     assert kpad, "the S16 path stages the expand conv through im2row"
     m0 = xin.shape[0] * xin.shape[1]
@@ -161,22 +193,30 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
     x_rows, x_t = S.split_t(xin.view(m0, kpad), xb, want_rows=True, want_t=save)
     x_rows = S.S16(x_rows.data.view(xin.shape), xb)
     t_in0 = x3.shape[1]
+    xin_f32 = xin if (save and need_dx) else None     # the expand layer's input gradient runs on the fp32 kernels
     del xin
 
-    rows_form = [idx >= 1 and wgrad_from_rows(plan.convs[idx].c_out, plan.convs[idx].c_in) for idx in range(n_layers)]
+    # weight-gradient form of every C x C conv: from the S16 rows (k_tn_s16), from the transposed copy its producer
+    # writes (strided conv whose windows tile its input), or from a copy gathered in backward (everything else)
+    t_len = plan.lengths(t_in0)
+    t_in_of = [t_in0] + [t_len[(idx - 1) // 2] for idx in range(1, n_layers)]      # input length of conv idx
+    wform = ["tcopy"] * n_layers
+    for idx in range(1, n_layers):
+        sp = plan.convs[idx]
+        tiling = sp.taps == 1 or _tiles(sp, t_in_of[idx])
+        wform[idx] = ("rows" if wgrad_from_rows(sp.c_out, sp.c_in) else "tcopy") if tiling else "gather"
 
     def next_taps(idx):
-        """taps of the conv that consumes the activation of layer idx (its wgrad reduces over the transposed copy);
-        0: no consumer, or a consumer whose wgrad reads the rows themselves."""
-        return plan.convs[idx + 1].taps if idx + 1 < n_layers and not rows_form[idx + 1] else 0
+        """taps of the conv that consumes the activation of layer idx when its wgrad reduces over the producer-written
+        transposed copy; 0: no consumer, or one that reads the rows (directly, or gathered in backward)."""
+        return plan.convs[idx + 1].taps if idx + 1 < n_layers and wform[idx + 1] == "tcopy" else 0
 
     # per-step prologue for ALL layers, one launch each: weight maxima -> S16 weight packs; activation bounds
     ws = [c.weight.detach() for c in convs]
     S.amax_multi(ws, bounds[n_layers:])
     w0_packed = ops.pack_weight(ws[0], ld_out=kpad)
     packs = [(S.split(w0_packed, bounds[n_layers]), None)]
-    packs += S.pack_weights_multi(ws[1:], bounds[n_layers + 1:], want_dgrad=save)
-    t_len = plan.lengths(t_in0)
+    packs += _packs(ws[1:], plan.convs[1:], bounds[n_layers + 1:], save)
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
     S.act_bounds_multi(bns, m_all if sync is None else [sync.rows_total(m_) for m_ in m_all], res_from, p, bounds)
@@ -206,7 +246,10 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
                 bits = bits_all[bits_at:bits_at + m_rows * spec.c_out // 8]
                 bits_at += bits.numel()
             saved.append(_Saved(a_t, y, coef, drop, wd, t_in0 if idx == 0 else t_cur, kpad if idx == 0 else 0, bits,
-                                x_rows=a if rows_form[idx] else None))
+                                x_rows=a if wform[idx] != "tcopy" else None))
+            saved[-1].wform = wform[idx]
+            if idx == 0:
+                saved[0].xin_f32 = xin_f32
             if idx == 0 and one_col >= 0:
                 saved[0].one_col, saved[0].w_packed = one_col, w0_packed
                 if S.expand_rows_form(spec.c_out, kpad):
@@ -225,7 +268,6 @@ def forward_train(mod, x3: torch.Tensor, save: bool):
 
 
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
-    assert not need_dx
     plan: StackPlan = mod._plan
     L: List[_Saved] = saved["layers"]
     h_last = saved["h_last"]
@@ -303,8 +345,8 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
                                             out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0,   # expand: no dgrad
                                             sync=mod.__dict__.get("_vp3d_sync_bn"), act_bits=s.bits,
-                                            want_t=s.x_rows is None)
-        if s.x_rows is not None:
+                                            want_t=s.wform != "rows")
+        if s.wform == "rows":
             dy_t = dy                                # rows-form wgrad reads the rows
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
@@ -318,9 +360,12 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         m_rows = L[idx].y.shape[0] * L[idx].y.shape[1]
 
         def gemm():
-            if L[idx].x_rows is not None:
+            if L[idx].wform == "rows":
                 return S.wgrad_rows(dy_t, L[idx].x_rows, spec.c_out, spec.c_in, spec.taps, out=out)
-            return S.wgrad(dy_t, L[idx].x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
+            x_t = L[idx].x_t
+            if L[idx].wform == "gather":             # dilated / ragged windows / wide filters: build the operand now
+                x_t = S.gather_t(L[idx].x_rows, spec, L[idx].y.shape[1])
+            return S.wgrad(dy_t, x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
         if side is not None and on_side:
             # nothing inside backward consumes dW: it runs beside the next layer's HBM-bound BatchNorm-backward kernels
             ev = engine._fork_event(dev, idx)
@@ -336,13 +381,26 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         grads[3 * idx] = sunk(dw, out)
 
     def dgrad(idx, dy, residual, amax_out):
-        """dx of conv idx (strided: plain GEMM dy @ Wd into [B*T_out, taps*C_in] == [B, T_in, C_in])."""
+        """dx of conv idx.  Strided conv (stride == taps; also every 1x1 conv): windows do not overlap, dx viewed as
+        [B*T_out, taps*C_in] = dy @ Wd is a plain GEMM (rows of a ragged tail stay zero).  Stride-1 conv of several taps
+        (the dilated class): gather form dx[b,s] = sum_k dy[b, s - k*dil] @ W_k^T over the [ci][k*C_out + co] pack."""
         spec: ConvSpec = plan.convs[idx]
         bb, t_o, c_out = dy.data.shape
         taps, c_in = spec.taps, spec.c_in
         t_i = L[idx].t_in
-        assert taps * t_o == t_i
-        dx = torch.empty((bb, t_i, c_in), dtype=torch.float32, device=dev)
+        if spec.stride == 1 and taps > 1:
+            dx = torch.empty((bb, t_i, c_in), dtype=torch.float32, device=dev)
+            rm = RowMap(bb, t_i, t_o, 1, -spec.dil, 0, taps)
+            e = None
+            if residual is not None:
+                r, rs = residual                      # dx[b, s] += r[b, s - start]
+                assert rs.step == 1 and r.shape[0] == bb and r.shape[2] == c_in
+                e = ops._epi(residual=(r, 1, -rs.start, 0), n_cols=c_in)
+            S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, c_in, dx, t_i * c_in, c_in, epi=e, amax_out=amax_out,
+                        family="tconv_dgrad")
+            return dx
+        assert spec.stride == taps and spec.dil == 1 and taps * t_o <= t_i
+        dx = (torch.empty if taps * t_o == t_i else torch.zeros)((bb, t_i, c_in), dtype=torch.float32, device=dev)
         rm = RowMap(bb, t_o, t_o, 1, 0, 0, 1)
         e = None
         if residual is not None:
@@ -365,7 +423,20 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         wgrad(i1, dy1_t)
         group_done()
         del dy1, dy1_t
-    if L[0].one_col >= 0:
+    dx_in = None
+    if need_dx:
+        # input gradient (never asked for by run.py): the expand layer's backward on the fp32 kernels -- its conv reads
+        # 102 columns, so the cost is the two streaming passes either way
+        s0 = L[0]
+        o_g, o_bt, o_w = view(bns[0].weight), view(bns[0].bias), view(convs[0].weight)
+        if o_g is None or o_bt is None:
+            o_g = o_bt = None
+        dy0, dg0, db0 = ops.bn_act_bwd(dh, s0.y, s0.coef, s0.drop, out_dgamma=o_g, out_dbeta=o_bt,
+                                       sync=mod.__dict__.get("_vp3d_sync_bn"))
+        dw0 = ops.conv_wgrad(dy0, s0.xin_f32, plan.convs[0], rows_kpad=s0.kpad, out=o_w)
+        dx_in = ops.conv_dgrad(dy0, ops.pack_weight(convs[0].weight.detach()), plan.convs[0], s0.t_in)
+        grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)
+    elif L[0].one_col >= 0:
         # expand layer without dy: G = dh * keep * [z > 0] (one pass over dh), P = G^T X, then dgamma / dbeta / dW from P,
         # X^T X and the weights (vp3d_expand_bwd_s16) -- no reduce / finalize / apply passes over (dh, y) for this layer
         spec0 = plan.convs[0]
@@ -389,4 +460,4 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         main.wait_stream(side)
         keep.clear()
     group_done(on_side=False)
-    return grads + [d_sw, d_sb], None
+    return grads + [d_sw, d_sb], dx_in

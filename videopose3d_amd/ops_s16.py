@@ -173,6 +173,18 @@ def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, ou
     return out
 
 
+def gather_t(x: S16, spec: ConvSpec, t_out: int) -> S16:
+    """Transposed weight-gradient operand [taps*C][roundup(B*t_out, 64)] of conv `spec` gathered from the S16 rows of its
+    input x [B,T_in,C] (vp3d_gather_t_s16): any stride / dilation / taps."""
+    b, t_in, c = x.data.shape
+    m = b * t_out
+    out = torch.empty((spec.taps * c, t_pitch(m)), dtype=torch.float32, device=x.data.device)
+    rm = RowMap(b, t_out, t_in, spec.stride, spec.dil, 0, spec.taps)
+    check(_lib.lib().vp3d_gather_t_s16(ops._stream(), C.byref(rm), x.data.data_ptr(), c, out.data_ptr(), out.shape[1]),
+          "vp3d_gather_t_s16")
+    return S16(out, x.bound)
+
+
 def nt_raw(a_t: S16, b_t: S16) -> Tuple[torch.Tensor, int]:
     """Raw split-K partials [splits][NA][NB] of  a_t @ b_t^T  for two transposed S16 operands [NA][Mp], [NB][Mp] (rows
     along the reduction index): the weight-gradient GEMM without its un-pack.  Returns (partials, splits)."""
