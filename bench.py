@@ -44,6 +44,7 @@ MFMA_PER_MAC_F16X3 = 3                # the split scheme issues ah*bh + ah*bl + 
 SUSTAINED_F16_MFMA_TFLOPS = 1700.0    # what a bare v_mfma_f32_32x32x16_f16 loop sustains on RANDOM operands on this chip (DVFS /
                                       # power: tools/ubench/mfma_peak.hip measured 1,697-1,703 TFLOP/s with 1 and 2 workgroups per
                                       # CU, with and without a barrier every 24 MFMAs) -- the practical ceiling of the matrix pipes
+ACHIEVABLE_HBM_GBPS = 6300.0           # MI355X_MICROARCH.md: what a streaming kernel sustains of the 8 TB/s HBM3E peak
 FLOP_TRAIN_PER_FRAME = 1023866880     # fwd 352,569,344 + bwd 671,297,536 (conv MACs x 2)
 FLOP_EVAL_PER_FRAME = 5217830912      # TemporalModel forward on a 243-frame window
 
@@ -273,17 +274,44 @@ def instrumented(step, ops, n_prof, math):
         step()
     torch.cuda.synchronize()
     ops.set_profiler(None)
-    fam = {}
-    for name, flops, e0, e1, nbytes in recs:
+    fam, shapes, streams = {}, {}, {}
+    for name, flops, e0, e1, nbytes, shape in recs:
+        ms = e0.elapsed_time(e1)
+        if name.startswith("stream_"):                 # HBM-bound producers: bytes / time, not part of the GEMM families
+            f = streams.setdefault((name, shape), dict(bytes=0.0, ms=0.0, calls=0))
+            f["bytes"] += nbytes
+            f["ms"] += ms
+            f["calls"] += 1
+            continue
         f = fam.setdefault(name, dict(flops=0.0, ms=0.0, calls=0, bytes=0.0))
         f["flops"] += flops
         f["bytes"] += nbytes
-        f["ms"] += e0.elapsed_time(e1)
+        f["ms"] += ms
         f["calls"] += 1
+        g = shapes.setdefault((name, shape), dict(flops=0.0, ms=0.0, calls=0, bytes=0.0))
+        g["flops"] += flops
+        g["bytes"] += nbytes
+        g["ms"] += ms
+        g["calls"] += 1
     kernels = {k: dict(calls_per_step=v["calls"] // n_prof, ms_per_step=v["ms"] / n_prof,
                        avg_launch_ms=v["ms"] / v["calls"], tflops=v["flops"] / v["ms"] / 1e9,
                        algorithmic_bytes_per_launch=v["bytes"] / v["calls"])
                for k, v in fam.items()}
+    peak_alg = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3 if math == "f16x3" else PEAK_F32_MFMA_TFLOPS
+    per_launch = []
+    for (name, shape), v in shapes.items():
+        row = {"family": name, "calls_per_step": v["calls"] / n_prof, "us": v["ms"] / v["calls"] * 1e3,
+               "tflops": v["flops"] / v["ms"] / 1e9, "frac_of_peak": v["flops"] / v["ms"] / 1e9 / peak_alg,
+               "algorithmic_MB": v["bytes"] / v["calls"] / 1e6}
+        if shape is not None:
+            row.update(M=shape[0], N=shape[1], K=shape[2], cfg=shape[3], k_slices=shape[4], gemm_kernels=shape[5])
+        per_launch.append(row)
+    per_launch.sort(key=lambda r: -r["us"] * r["calls_per_step"])
+    streaming = [{"kernel": name, "rows": shape[0] if shape else None, "channels": shape[1] if shape else None,
+                  "us": v["ms"] / v["calls"] * 1e3, "algorithmic_MB": v["bytes"] / v["calls"] / 1e6,
+                  "GBps": v["bytes"] / v["ms"] / 1e6, "frac_of_achievable_hbm": v["bytes"] / v["ms"] / 1e6 / ACHIEVABLE_HBM_GBPS}
+                 for (name, shape), v in streams.items()]
+    streaming.sort(key=lambda r: -r["us"])
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     alg = kernels[dom]["tflops"]
     traffic, traffic_note = pmc_traffic(dom, math)
@@ -311,6 +339,8 @@ def instrumented(step, ops, n_prof, math):
             "algorithmic_bytes": kernels[dom]["algorithmic_bytes_per_launch"], "kernel": kname,
             "launches_per_step": kernels[dom]["calls_per_step"], "avg_launch_ms": kernels[dom]["avg_launch_ms"]}
     roof.update(extra)
+    roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r02_step_table.txt shows
+    roof["streaming"] = streaming[:6]        # from rocprofv3); the two big HBM-bound producers against the achievable HBM rate
     return roof, kernels
 
 
@@ -464,6 +494,8 @@ def main():
                    "grad_allreduce_bytes": sync.numel * 4 if world > 1 else 0},
         "step_tflops": FLOP_TRAIN_PER_FRAME * value / 1e12,
         "step_frac_of_fp32_mfma_peak": FLOP_TRAIN_PER_FRAME * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+        "step_frac_of_roofline": FLOP_TRAIN_PER_FRAME * value / 1e12 / world /
+        (PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3 if math == "f16x3" else PEAK_F32_MFMA_TFLOPS),
     }
 
     # ---- the same step replayed as ONE hipGraph (graph.GraphedTrainStep: forward + fused mpjpe + backward captured once;
@@ -568,7 +600,7 @@ def main():
                 ev(x)
                 torch.cuda.synchronize()
                 ops.set_profiler(None)
-            big = [(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b in recs if f > 1e11]
+            big = [(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b, _s in recs if f > 1e11]
             tf = FLOP_EVAL_PER_FRAME * B / dte / 1e12
             return y, {"workload": "TemporalModel eval forward (BN folded), arc 3,3,3,3,3 C=1024 B=1024 T=243", "math": mth,
                        "ms": dte * 1e3, "frames_per_s": B / dte, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,

@@ -196,6 +196,19 @@ typedef struct vp3d_s16 {
   const float* l1;
   const float* res_amax;
   float* out_wbound;
+  /* Fused conv + BatchNorm + ReLU + dropout for a conv whose GEMM is cheap to run twice (the expand conv: K = 128; replaces
+   * model.py:74 / :127 expand_conv -> expand_bn -> relu -> drop without storing the conv output):
+   *   no_output            : pass 1 -- only the epilogue's BatchNorm slab statistics are written (y may be NULL)
+   *   act_scale, act_shift : pass 2 -- y receives the S16 rows of dropout(relu(acc*act_scale[n] + act_shift[n])) under the
+   *                          exponent of *act_bound (mask: act_drop, element index m*c_out + n; NULL = no dropout) and
+   *                          act_bits (may be NULL) the [z > 0 and kept] bits, bit for bit what vp3d_bn_act_fwd_s16 produces
+   *                          from a stored conv output.  y must be contiguous [M][c_out], c_out % 64 == 0; no other epilogue. */
+  int32_t no_output;
+  const float* act_scale;
+  const float* act_shift;
+  const vp3d_dropout* act_drop;
+  const float* act_bound;
+  uint8_t* act_bits;
 } vp3d_s16;
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
 /* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form

@@ -460,3 +460,34 @@ def test_gather_transposed_operand_vs_torch():
             rows = xv[:, k * spec.dil: k * spec.dil + (t_out - 1) * spec.stride + 1: spec.stride]      # [b, t_out, c]
             assert torch.equal(got[k * c:(k + 1) * c, :m], rows.reshape(m, c).t().contiguous()), (spec, k)
         assert float(got[:, m:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1)])
+def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg):
+    """The expand layer's fused forward: pass 1 (no_output) writes only the BatchNorm slab statistics, pass 2 applies
+    BatchNorm + ReLU + dropout in the GEMM epilogue and writes S16 rows + activation bits -- bit for bit what
+    vp3d_bn_act_fwd_s16 makes of the stored conv output."""
+    g = torch.Generator().manual_seed(17)
+    b, t, k, c = 37, 27, 128, 256                       # M = 999: ragged last tile
+    spec = ConvSpec(k, c, 1)
+    x = (torch.randn(b, t, k, generator=g)).clamp(-1, 1).to(DEV)
+    w = (torch.randn(c, k, 1, generator=g) * 0.1).to(DEV)
+    xs, ws_ = S.split(x), S.split(ops.pack_weight(w))
+    m = b * t
+    st_a, st_b = ops.stat_buffers(m, c, DEV), ops.stat_buffers(m, c, DEV)
+    y = S.conv_nt(xs, ws_, spec, stats=st_a, cfg=cfg if cfg > 0 else -1)
+    assert S.conv_nt(xs, ws_, spec, stats=st_b, no_output=True, cfg=cfg if cfg > 0 else -1) is None
+    assert torch.equal(st_a[0], st_b[0]) and torch.equal(st_a[1], st_b[1])
+    coef = ops.bn_finalize(torch.nn.BatchNorm1d(c).to(DEV), m, st_a)
+    drop = ops.make_dropout(p_drop, 99, 3, 0)
+    bound = S.new_bound(DEV)
+    bound[0] = 40.0
+    bits_ref, bits_f = S.new_act_bits(m, c, DEV), S.new_act_bits(m, c, DEV)
+    bits_ref.zero_()
+    bits_f.zero_()
+    a_ref, _ = S.bn_act_fwd(y, coef, drop, None, bound, act_bits=bits_ref)
+    a_f = S.conv_nt(xs, ws_, spec, act=(coef, drop, bound, bits_f), cfg=cfg if cfg > 0 else -1)
+    assert torch.equal(a_f.data.view(torch.int32), a_ref.data.view(torch.int32))
+    assert torch.equal(bits_f, bits_ref)
+    if p_drop > 0:
+        assert 0.6 < float((S.join(a_f) != 0).float().mean() / (S.join(S.bn_act_fwd(y, coef, None, None, bound)[0]) != 0).float().mean()) < 0.9

@@ -87,3 +87,11 @@ def s16_or_skip(mode, model, t_in, training, need_dx=False):
     from videopose3d_amd import engine
     if mode == "f16x3" and not engine.use_s16(model, t_in, training, need_dx):
         pytest.skip("engine_s16.supported() rejects this configuration: covered under the f32 id")
+
+
+def unpack_act_bits(bits, m_rows, c):
+    """Activation bits of an [m_rows, c] activation (videopose3d_amd: byte of (row m, channels c0..c0+7) at
+    ((c0 // 64) * M + m) * 8 + (c0 % 64) // 8, bit e = channel c0 + e) -> bool array [m_rows, c]."""
+    b = np.asarray(bits.detach().cpu().numpy() if hasattr(bits, "detach") else bits, np.uint8).reshape(c // 64, m_rows, 8)
+    u = np.unpackbits(b[..., None], axis=-1, bitorder="little")            # [tile][m][byte][bit]
+    return u.transpose(1, 0, 2, 3).reshape(m_rows, c).astype(bool)

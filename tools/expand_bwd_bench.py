@@ -7,6 +7,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["VP3D_EXPAND_ROWS"] = "1"            # (so that the rows-form P GEMM can be timed next to the default)
 import torch  # noqa: E402
 
 from videopose3d_amd import ops, ops_s16 as S  # noqa: E402
@@ -59,3 +60,23 @@ dyb = S.new_bound(dev)
 drop = ops.make_dropout(0.25, 1, 0, 0)
 print("old: reduce+finalize+apply(T only) %7.1f us" % timeit(
     lambda: S.bn_act_bwd(go, gb, y, coef, drop, 0.25, S.new_bound(dev), want_rows=False, act_bits=bits)))
+
+# ---- forward: unfused (GEMM + statistics -> y, vp3d_bn_act_fwd_s16) vs fused (statistics-only pass, fused-activation pass)
+from videopose3d_amd.plan import ConvSpec  # noqa: E402
+spec = ConvSpec(kpad, c, 1)
+xs3 = S.S16(x_rows.data.view(1024, 81, kpad), xb)
+ws_ = S.split(wp)
+bn = torch.nn.BatchNorm1d(c).to(dev)
+st = ops.stat_buffers(m, c, dev)
+bound = S.new_bound(dev)
+bound[0] = 64.0
+bits_f = S.new_act_bits(m, c, dev)
+for cfg in (20, 22, -1):
+    yy = S.conv_nt(xs3, ws_, spec, stats=st, cfg=cfg)
+    cf = ops.bn_finalize(bn, m, st)
+    print("forward cfg %3d: GEMM+stats -> y %6.1f us | act kernel %6.1f us | stats-only pass %6.1f us | fused-act pass p=0.25 %6.1f us, p=0 %6.1f us" % (
+        cfg, timeit(lambda: S.conv_nt(xs3, ws_, spec, stats=st, cfg=cfg)),
+        timeit(lambda: S.bn_act_fwd(yy, cf, drop, None, bound, act_bits=bits_f)),
+        timeit(lambda: S.conv_nt(xs3, ws_, spec, stats=st, no_output=True, cfg=cfg)),
+        timeit(lambda: S.conv_nt(xs3, ws_, spec, act=(cf, drop, bound, bits_f), cfg=cfg)),
+        timeit(lambda: S.conv_nt(xs3, ws_, spec, act=(cf, None, bound, bits_f), cfg=cfg))))

@@ -43,7 +43,9 @@ class S16Opts(C.Structure):
     _fields_ = [("x_bound", C.c_void_p), ("w_bound", C.c_void_p), ("amax_out", C.c_void_p), ("cfg", C.c_int32),
                 ("splits", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("raw_partials", C.c_int32),
                 ("res_s16", C.c_int32), ("res_bound", C.c_void_p), ("out_s16", C.c_int32), ("in_amax", C.c_void_p),
-                ("l1", C.c_void_p), ("res_amax", C.c_void_p), ("out_wbound", C.c_void_p)]
+                ("l1", C.c_void_p), ("res_amax", C.c_void_p), ("out_wbound", C.c_void_p), ("no_output", C.c_int32),
+                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("act_drop", C.POINTER(Dropout)),
+                ("act_bound", C.c_void_p), ("act_bits", C.c_void_p)]
 
 
 class Gather(C.Structure):

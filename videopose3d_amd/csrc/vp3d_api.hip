@@ -45,6 +45,9 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->r_s16 = e->c_s16 = 0;
   e->r_bound = e->in_amax = e->l1 = e->res_amax = nullptr;
   e->out_wbound = nullptr;
+  e->no_out = 0;
+  e->act_scale = e->act_shift = e->act_bound = nullptr;
+  e->act_bits = nullptr;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -185,7 +188,7 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
   int rc = check_map(map, "tconv_nt_s16");
   if (rc) return rc;
   VP3D_REQUIRE(x && wt && zeros && o, "tconv_nt_s16: null pointer");
-  VP3D_REQUIRE(y || (o->raw_partials && o->ws), "tconv_nt_s16: no output buffer");
+  VP3D_REQUIRE(y || (o->raw_partials && o->ws) || (o->no_output && epi && epi->stat_sum), "tconv_nt_s16: no output buffer");
   VP3D_REQUIRE(c_in > 0 && c_out > 0 && ldx >= 1 && ldw >= map->taps * c_in && (o->raw_partials || ldy >= c_out),
                "tconv_nt_s16: bad sizes (c_in=%d c_out=%d ldx=%d ldw=%d ldy=%d)", c_in, c_out, ldx, ldw, ldy);
   RowsGemmArgs a;
@@ -237,8 +240,27 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
     a.epi.res_amax = o->res_amax;
     a.epi.out_wbound = o->out_wbound;
   }
+  if (o->no_output) {
+    VP3D_REQUIRE(!o->raw_partials && !o->out_s16 && a.epi.stat_sum != nullptr && o->act_scale == nullptr,
+                 "tconv_nt_s16: a statistics-only launch needs the statistics epilogue and nothing else");
+    a.epi.no_out = 1;
+  }
+  if (o->act_scale != nullptr) {
+    VP3D_REQUIRE(!o->raw_partials && !o->out_s16 && o->act_shift && o->act_bound && y && c_out % 64 == 0 && ldy == c_out &&
+                     y_bpitch == (int64_t)map->t_dst * c_out && aligned16(y) && a.epi.R == nullptr && a.epi.bias == nullptr &&
+                     a.epi.stat_sum == nullptr && !a.epi.relu,
+                 "tconv_nt_s16: the fused activation writes contiguous S16 rows [M][c_out] (c_out %% 64 == 0) and takes no "
+                 "other epilogue");
+    if (o->act_drop) VP3D_REQUIRE(o->act_drop->p >= 0.f && o->act_drop->p < 1.f, "tconv_nt_s16: dropout p=%f", o->act_drop->p);
+    a.epi.act_scale = o->act_scale;
+    a.epi.act_shift = o->act_shift;
+    a.epi.act_bound = o->act_bound;
+    a.epi.act_bits = o->act_bits;
+    a.epi.ab_drop = make_drop(o->act_drop);
+  }
   set_splits(&a, nullptr, 0);
-  return launch_nt_s16((hipStream_t)stream, a, o->cfg, (o->out_s16 || o->res_s16) ? 1 : o->splits, o->ws, o->ws_floats,
+  const bool single = o->out_s16 || o->res_s16 || o->no_output || o->act_scale != nullptr;
+  return launch_nt_s16((hipStream_t)stream, a, o->cfg, single ? 1 : o->splits, o->ws, o->ws_floats,
                        o->raw_partials != 0);   // the finishing pass of a split launch knows neither S16 residuals nor S16 output
 }
 

@@ -205,7 +205,9 @@ __device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int p
   return true;
 }
 
-template <class C>
+// ACT: the instance that carries the fused BatchNorm + ReLU + dropout epilogue (Epi::act_scale) -- kept out of the
+// general instances so that its Philox temporaries do not enter their register allocation.
+template <class C, bool ACT = false>
 __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const RowsGemmArgs p) {
   constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE, PA = C::PA, PB = C::PB;
   constexpr int BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP, CPR = ROWB / 16;   // chunks per row
@@ -467,6 +469,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
   }
 
+  if (!partial && e.no_out) return;                  // statistics-only launch (workgroup-uniform)
   __syncthreads();                                   // every wave is done reading the operand ring
   // Each wave stages one 32-row block of its sub-tile at a time through its own [32][CB*32] fp32 LDS region and
   // writes it out with 16-B stores (a row of the region = CB*128 B contiguous in C).
@@ -478,6 +481,70 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const bool vec = partial ? (p.N % 4 == 0) : (e.vec != 0);
   float amax = 0.f;
   const float rscale = (!partial && e.r_s16) ? s16_pow2(s16_exp_of(e.r_bound)) : 1.f;
+  if (ACT) {
+    // ---- fused BatchNorm + ReLU + dropout -> S16 rows + activation bits: lane = 8 consecutive columns of a row -----
+    DropP d = e.ab_drop;
+    drop_resolve(d);
+    const float inv = s16_pow2(-s16_exp_of(e.act_bound));
+    constexpr int LPR8 = WCOLS / 8, ERPP8 = 64 / LPR8;
+    const int rr8 = lane / LPR8, c8 = (lane % LPR8) * 8;
+    const int n8 = n0 + wn * WCOLS + c8;
+    float sc8[8], sh8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      sc8[c] = n8 < Nlim ? e.act_scale[n8 + c] : 0.f;
+      sh8[c] = n8 < Nlim ? e.act_shift[n8 + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
+        }
+      epi_stage_sync();
+#pragma unroll 2
+      for (int ps = 0; ps < 32 / ERPP8; ++ps) {
+        const int r = ps * ERPP8 + rr8;
+        const int lr = (wm * RB + i) * 32 + r;
+        const int m = m0 + lr;
+        if (m >= p.m_end || n8 >= Nlim) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c8 + 4);
+        const float y8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t e0 = (int64_t)m * p.N + n8;      // element index in the [M][N] activation (the mask's counter)
+        float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (d.on) {
+          float ma[4], mb[4];
+          drop4(d, (uint64_t)(e0 >> 2), ma);
+          drop4(d, (uint64_t)(e0 >> 2) + 1, mb);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            mk[c] = ma[c];
+            mk[4 + c] = mb[c];
+          }
+        }
+        float v[8];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float z = fmaf(y8[c], sc8[c], sh8[c]);
+          v[c] = (z > 0.f ? z * mk[c] : (z != z ? z : 0.f)) * inv;
+          bits |= (z > 0.f && mk[c] != 0.f) ? (1u << c) : 0u;
+        }
+        if (e.act_bits != nullptr) e.act_bits[act_bits_index(n8, m, p.M)] = (uint8_t)bits;
+        f16x8 hi, lo;
+        s16_split8(v, 1.f, hi, lo);
+        f16x8* o = reinterpret_cast<f16x8*>(e.C + (int64_t)m * p.N + n8);
+        o[0] = hi;
+        o[1] = lo;
+      }
+      epi_stage_sync();
+    }
+    return;
+  }
   if (!partial && e.c_s16) {
     // ---- S16 output (eval chaining): lane = 8 consecutive columns = one S16 group --------------------------
     const float wb = e.l1[0] * s16_load_bound(e.in_amax) + e.l1[1] + (e.res_amax != nullptr ? s16_load_bound(e.res_amax) : 0.f);
@@ -988,6 +1055,15 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   a.tail_pos = 0;
   a.splits = splits;
   a.kt_per_split = (nkt + splits - 1) / splits;
+  if (a.epi.act_scale != nullptr) {
+    if constexpr (C::BUF && !C::PIPE && C::BKE == 32) {          // (instantiated for the planner's configurations only)
+      hipLaunchKernelGGL((k_nt_s16<C, true>), dim3(positions * splits), dim3(C::NT), 0, s, a);
+      return check_launch("nt_s16(act)");
+    } else {
+      set_error("nt_s16: the fused activation epilogue exists for tile configurations 20 / 22 / 30 only");
+      return VP3D_E_INVALID;
+    }
+  }
   hipLaunchKernelGGL((k_nt_s16<C>), dim3(positions * splits), dim3(C::NT), 0, s, a);
   return check_launch("nt_s16");
 }

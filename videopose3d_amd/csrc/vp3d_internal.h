@@ -63,6 +63,15 @@ struct Epi {
   const float* l1;
   const float* res_amax;
   float* out_wbound;
+  // statistics-only launch (no_out != 0): nothing but the BatchNorm slab statistics is written (C may be NULL)
+  int32_t no_out;
+  // fused activation (act_scale != nullptr): C receives the S16 rows of dropout(relu(acc * act_scale[n] + act_shift[n]))
+  // (mask: ab_drop, element index m * N + n) under the exponent of *act_bound, act_bits the [z > 0 and kept] bits --
+  // exactly what vp3d_bn_act_fwd_s16 writes from a stored conv output
+  const float* act_scale;
+  const float* act_shift;
+  const float* act_bound;
+  uint8_t* act_bits;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";

@@ -60,4 +60,13 @@ __device__ __forceinline__ void s16_join8(const f16x8& hi, const f16x8& lo, floa
 
 __device__ __forceinline__ float s16_pow2(int e) { return ldexpf(1.0f, e); }
 
+// "activation bits": one byte per (row, 8 consecutive channels), bit e = [bn(y) > 0 and the element was kept by the
+// dropout]: written by the forward producers (vp3d_bn_act_fwd_s16, or the fused-activation epilogue of the GEMM), read
+// by the backward passes instead of regenerating the Philox mask (10 integer multiplies per element and pass).  Stored
+// per 64-channel tile so that a block's bytes are contiguous: byte of (row m, channels c..c+7) at
+// ((c / 64) * M + m) * 8 + (c % 64) / 8.
+__device__ __forceinline__ int64_t act_bits_index(int c, int64_t m, int M) {
+  return ((int64_t)(c >> 6) * M + m) * 8 + ((c & 63) >> 3);
+}
+
 }  // namespace vp3d

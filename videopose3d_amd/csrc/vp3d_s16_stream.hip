@@ -58,14 +58,6 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, float (&o)[8]
   }
 }
 
-// "activation bits": one byte per (row, 8 consecutive channels), bit e = [bn(y) > 0 and the element was kept by the
-// dropout]: written by the forward producer, read by the two backward passes instead of regenerating the Philox mask
-// (10 integer multiplies per element and pass).  Stored per 64-channel tile so that a block's bytes are contiguous:
-// byte of (row m, channels c..c+7) at ((c / 64) * M + m) * 8 + (c % 64) / 8.
-__device__ __forceinline__ int64_t act_bits_index(int c, int64_t m, int M) {
-  return ((int64_t)(c >> 6) * M + m) * 8 + ((c & 63) >> 3);
-}
-
 struct ResS16 {
   const float* res;           // S16 rows
   const float* bound;
@@ -387,8 +379,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
   const bool owner = rsub == 0 && c < C;
   if (owner) {
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int r = row0; r < row0 + nrows; ++r) {
+#pragma unroll 8
+    for (int r = row0; r < row0 + nrows; ++r) {          // (unrolled: the loads of 8 rows in flight, the tail is pure latency)
       const f32x4 v = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 0) * C + c);
       const f32x4 w = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 1) * C + c);
 #pragma unroll
@@ -397,11 +389,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
         b[e] += (double)w[e];
       }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      fin.gpart[((int64_t)grp * 2 + 0) * C + c + e] = a[e];
-      fin.gpart[((int64_t)grp * 2 + 1) * C + c + e] = b[e];
-    }
+    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 0) * C + c) = double2{a[0], a[1]};
+    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 0) * C + c + 2) = double2{a[2], a[3]};
+    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 1) * C + c) = double2{b[0], b[1]};
+    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 1) * C + c + 2) = double2{b[2], b[3]};
   }
   // ---- stage 2 (groups) + finalize -----------------------------------------------------------------------------
   if (!last_arriver(cnt + ngroups, ngroups, flag)) return;
@@ -409,12 +400,14 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
   const float gmax = s16_load_bound(fin.go_bound) * fin.inv_keep;      // (whole waves take part in the bound's shuffle)
   if (owner) {
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 6
     for (int g = 0; g < ngroups; ++g) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] += fin.gpart[((int64_t)g * 2 + 0) * C + c + e];
-        b[e] += fin.gpart[((int64_t)g * 2 + 1) * C + c + e];
-      }
+      const double2 a01 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 0) * C + c);
+      const double2 a23 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 0) * C + c + 2);
+      const double2 b01 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 1) * C + c);
+      const double2 b23 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 1) * C + c + 2);
+      a[0] += a01.x; a[1] += a01.y; a[2] += a23.x; a[3] += a23.y;
+      b[0] += b01.x; b[1] += b01.y; b[2] += b23.x; b[3] += b23.y;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -133,6 +133,17 @@ def wgrad_from_rows(c_out: int, c_in: int) -> bool:
     return os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in)
 
 
+def next_is_not_tcopy(plan: StackPlan, t_in: int) -> bool:
+    """The conv after the expand layer takes its weight-gradient operand from the rows (directly or gathered), i.e. the
+    expand layer's producer has no transposed copy to write (the fused GEMM epilogue writes rows only)."""
+    if len(plan.convs) < 2:
+        return True
+    sp = plan.convs[1]
+    t1 = plan.convs[0].t_out(t_in)
+    tiling = sp.taps == 1 or _tiles(sp, t1)
+    return (not tiling) or wgrad_from_rows(sp.c_out, sp.c_in)
+
+
 def expand_shortcut_column(plan: StackPlan, sync) -> int:
     """Padding column of the expand conv's im2row rows that carries the constant 1 of the no-dy backward of the expand
     layer (expand_bwd below), or -1 when that backward is not used: no spare padding column, synchronised BatchNorm
@@ -186,6 +197,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
     use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
+    fuse_expand = (os.environ.get("VP3D_EXPAND_FUSED", "1") != "0" and sync is None and not need_dx and
+                   (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1]))
     xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
     assert kpad, "the S16 path stages the expand conv through im2row"
     m0 = xin.shape[0] * xin.shape[1]
@@ -234,7 +247,11 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         m_rows = b * spec.t_out(t_cur)
         assert m_rows == m_all[idx]
         stats = ops.stat_buffers(m_rows, spec.c_out, dev)
-        y = S.conv_nt(a, wf, spec, stats=stats)
+        # expand layer, fused: its GEMM (K = 128) is cheap enough to run twice -- pass 1 only produces the BatchNorm
+        # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
+        # the conv output never goes to HBM (its backward, expand_bwd, needs no y either)
+        fused0 = idx == 0 and fuse_expand and n_layers > 1
+        y = S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
         coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
@@ -254,7 +271,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
                 saved[0].one_col, saved[0].w_packed = one_col, w0_packed
                 if S.expand_rows_form(spec.c_out, kpad):
                     saved[0].x_rows = a                  # P = G^T X reads the rows; the transposed copy only feeds X^T X
-        if idx == n_layers - 1:              # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
+        if fused0:
+            a, a_t = S.conv_nt(a, wf, spec, act=(coef, drop, bounds[idx], bits)), None
+        elif idx == n_layers - 1:            # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:
             a, a_t = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=next_taps(idx) if save else 0,
@@ -447,7 +466,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         o_w, o_g, o_bt = view(convs[0].weight), view(bns[0].weight), view(bns[0].bias)
         if o_g is None or o_bt is None:
             o_g = o_bt = None
-        m0 = L[0].y.shape[0] * L[0].y.shape[1]
+        m0 = dh.shape[0] * dh.shape[1]
         dw0, dg0, db0 = S.expand_bwd(g0, L[0].x_rows if rows0 else L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in,
                                      spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt)
         grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)

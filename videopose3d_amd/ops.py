@@ -27,8 +27,8 @@ def set_profiler(records):
 
 
 class _Timed:
-    def __init__(self, family, flops, nbytes=0.0):
-        self.family, self.flops, self.nbytes = family, flops, nbytes
+    def __init__(self, family, flops, nbytes=0.0, shape=None):
+        self.family, self.flops, self.nbytes, self.shape = family, flops, nbytes, shape
 
     def __enter__(self):
         if _prof is not None:
@@ -40,7 +40,7 @@ class _Timed:
     def __exit__(self, *exc):
         if _prof is not None:
             self.e1.record()
-            _prof.append((self.family, self.flops, self.e0, self.e1, self.nbytes))
+            _prof.append((self.family, self.flops, self.e0, self.e1, self.nbytes, self.shape))
         return False
 
 
@@ -113,9 +113,15 @@ def stat_buffers(m_rows: int, c: int, device) -> Tuple[torch.Tensor, torch.Tenso
 # --------------------------------------------------------------------------------------------------------
 # convolutions
 # --------------------------------------------------------------------------------------------------------
-def _timed_call(family, flops, fn, *args, nbytes=0.0):
-    """nbytes: algorithmic HBM bytes of the launch (every operand read once, the result written once)."""
-    with _Timed(family, flops, nbytes):
+launch_log = None        # tools/step_table.py: a list that receives (family, flops, nbytes, shape) of every GEMM call, in issue order
+
+
+def _timed_call(family, flops, fn, *args, nbytes=0.0, shape=None):
+    """nbytes: algorithmic HBM bytes of the launch (every operand read once, the result written once); shape: what the
+    per-launch evidence tables print -- (M, N, K, tile configuration, K-slices, GEMM kernels launched)."""
+    if launch_log is not None:
+        launch_log.append((family, flops, nbytes, shape))
+    with _Timed(family, flops, nbytes, shape):
         check(fn(*args), fn.__name__)
 
 

@@ -89,18 +89,27 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
 
 
 def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=None, stats=None, amax_out=None,
-            cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None, s16_out=None):
+            cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None, s16_out=None, no_output: bool = False,
+            act=None):
     """y = conv(x) with the fused epilogue of ops.conv_fwd; x [B,T_in,C_in] and wt [C_out, taps*C_in] in S16.
 
     residual = (tensor, ResSpec): fp32 tensor or S16 (decoded with its own bound).
     s16_out = None: y is fp32 (returned).  s16_out = (in_amax, l1, res_amax or None): y is written as S16 whose bound
-    l1[0]*max(in_amax) + l1[1] + max(res_amax) is evaluated on the device; returns S16(y, that bound)."""
+    l1[0]*max(in_amax) + l1[1] + max(res_amax) is evaluated on the device; returns S16(y, that bound).
+    no_output: only the BatchNorm slab statistics (`stats`) are produced (returns None).
+    act = (coef, drop, out_bound, act_bits or None): fused BatchNorm + ReLU + dropout epilogue -- returns the S16 rows of
+    dropout(relu(y*coef[0] + coef[1])) under out_bound (and fills act_bits) without ever storing y."""
     xd, wd = x.data, wt.data
     b, t_in, c_in = xd.shape
     assert c_in == spec.c_in and wd.shape == (spec.c_out, spec.taps * spec.c_in), (xd.shape, wd.shape, spec)
     t_out = spec.t_out(t_in)
-    if out is None:
+    if no_output:
+        assert stats is not None and act is None and s16_out is None and residual is None and bias is None and not relu
+        out = None
+    elif out is None:
         out = torch.empty((b, t_out, spec.c_out), dtype=torch.float32, device=xd.device)
+    if act is not None:
+        assert stats is None and s16_out is None and residual is None and bias is None and not relu
     if spec.dil == 1:
         rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
         c_src = spec.taps * c_in
@@ -117,9 +126,19 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
         res = (r, rs.step, rs.start, 0)
     e = ops._epi(bias, relu, res, stats, spec.c_out)
     m, k = b * t_out, spec.taps * c_in
-    if s16_out is not None or res_s16 is not None:
+    if s16_out is not None or res_s16 is not None or no_output or act is not None:
         splits = 1
     o, ws = _opts(x, wt, m, spec.c_out, k, xd.device, amax_out, cfg, splits)
+    keep = None
+    if no_output:
+        o.no_output = 1
+    if act is not None:
+        coef, drop, out_bound, act_bits = act
+        o.act_scale, o.act_shift, o.act_bound = coef[0].data_ptr(), coef[1].data_ptr(), out_bound.data_ptr()
+        o.act_bits = None if act_bits is None else act_bits.data_ptr()
+        if drop is not None:
+            keep = drop
+            o.act_drop = C.pointer(drop)
     if res_s16 is not None:
         o.res_s16, o.res_bound = 1, res_s16.bound.data_ptr()
     wbound = None
@@ -131,9 +150,16 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
         o.out_wbound = wbound.data_ptr()
     ops._timed_call("tconv_fwd", 2.0 * m * spec.c_out * k, _lib.lib().vp3d_tconv_nt_s16,
                     ops._stream(), C.byref(rm), xd.data_ptr(), c_in, c_src, wd.data_ptr(), wd.shape[1], spec.c_out,
-                    out.data_ptr(), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
+                    ops._p(out), t_out * spec.c_out, spec.c_out, C.byref(e) if e is not None else None,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
-                    nbytes=4.0 * (xd.numel() + wd.numel() + out.numel() + (out.numel() if residual is not None else 0)))
+                    nbytes=4.0 * (xd.numel() + wd.numel() + (0 if out is None else out.numel()) +
+                                  (out.numel() if residual is not None else 0)),
+                    shape=(m, spec.c_out, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
+    del keep
+    if no_output:
+        return None
+    if act is not None:
+        return S16(out, act[2])
     return out if s16_out is None else S16(out, wbound)
 
 
@@ -147,7 +173,7 @@ def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: t
                     ops._stream(), C.byref(rm), xd.data_ptr(), xd.shape[-1], c_src, wd.data_ptr(), wd.shape[-1], n,
                     out.data_ptr(), y_bpitch, ldy, C.byref(epi) if epi is not None else None,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
-                    nbytes=4.0 * (xd.numel() + wd.numel() + m * n))
+                    nbytes=4.0 * (xd.numel() + wd.numel() + m * n), shape=(m, n, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
     return out
 
 
@@ -165,7 +191,7 @@ def wgrad(dy_t: S16, x_t: S16, c_out: int, c_in: int, taps: int, n_cols: int, ou
     ops._timed_call("tconv_wgrad", 2.0 * (flops_rows or mp) * c_out * taps * c_in, _lib.lib().vp3d_tconv_nt_s16,
                     ops._stream(), C.byref(rm), dy_t.data.data_ptr(), mp, mp, x_t.data.data_ptr(), mp, n_cols,
                     None, 0, n_cols, None, ops.zeros_page(dev).data_ptr(), C.byref(o),
-                    nbytes=4.0 * (dy_t.data.numel() + x_t.data.numel() + c_out * n_cols))
+                    nbytes=4.0 * (dy_t.data.numel() + x_t.data.numel() + c_out * n_cols), shape=(c_out, n_cols, mp, cfg, splits, 1))
     if out is None:
         out = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dev)
     check(_lib.lib().vp3d_wgrad_reduce(ops._stream(), ws.data_ptr(), n_cols, splits, c_out, c_in, taps, out.data_ptr()),
@@ -198,7 +224,7 @@ def nt_raw(a_t: S16, b_t: S16) -> Tuple[torch.Tensor, int]:
     ops._timed_call("tconv_wgrad", 2.0 * mp * na * nb, _lib.lib().vp3d_tconv_nt_s16,
                     ops._stream(), C.byref(rm), a_t.data.data_ptr(), mp, mp, b_t.data.data_ptr(), mp, nb,
                     None, 0, nb, None, ops.zeros_page(dev).data_ptr(), C.byref(o),
-                    nbytes=4.0 * (a_t.data.numel() + b_t.data.numel() + na * nb))
+                    nbytes=4.0 * (a_t.data.numel() + b_t.data.numel() + na * nb), shape=(na, nb, mp, cfg, splits, 1))
     return ws, splits
 
 
@@ -245,7 +271,7 @@ def expand_bwd(g: S16, x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, co
         ws = torch.empty((splits, c, kpad), dtype=torch.float32, device=dev)
         ops._timed_call("tconv_wgrad", 2.0 * m_rows * c * kpad, _lib.lib().vp3d_wgrad_rows_s16, ops._stream(), m_rows,
                         g.data.data_ptr(), c, c, g.bound_ptr(), x.data.data_ptr(), kpad, 1, kpad, x.bound_ptr(), splits,
-                        ws.data_ptr(), nbytes=4.0 * (g.data.numel() + x.data.numel() + c * kpad))
+                        ws.data_ptr(), nbytes=4.0 * (g.data.numel() + x.data.numel() + c * kpad), shape=(c, kpad, m_rows, "tn", splits, 1))
     else:
         c, kpad = g.data.shape[0], x.data.shape[0]
         ws, splits = nt_raw(g, x)
@@ -295,7 +321,7 @@ def wgrad_rows(dy: S16, x: S16, c_out: int, c_in: int, taps: int, out: Optional[
     ws = torch.empty((splits, c_out, n_cols), dtype=torch.float32, device=dev)
     ops._timed_call("tconv_wgrad", 2.0 * m * c_out * n_cols, _lib.lib().vp3d_wgrad_rows_s16, ops._stream(), m, dd.data_ptr(),
                     c_out, c_out, dy.bound_ptr(), xd.data_ptr(), c_in, taps, c_in, x.bound_ptr(), splits, ws.data_ptr(),
-                    nbytes=4.0 * (dd.numel() + xd.numel() + c_out * n_cols))
+                    nbytes=4.0 * (dd.numel() + xd.numel() + c_out * n_cols), shape=(c_out, n_cols, m, "tn", splits, 1))
     if out is None:
         out = torch.empty((c_out, c_in, taps), dtype=torch.float32, device=dev)
     check(_lib.lib().vp3d_wgrad_reduce(ops._stream(), ws.data_ptr(), n_cols, splits, c_out, c_in, taps, out.data_ptr()),
@@ -359,10 +385,13 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
     else:
         rargs = (None, None, t, 0, 0, 0, c)
     f32 = torch.empty_like(y) if want_f32 else None
-    check(_lib.lib().vp3d_bn_act_fwd_s16(ops._stream(), m, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                                         C.byref(drop) if drop is not None else None, *rargs, out_bound.data_ptr(),
-                                         out.data_ptr(), ops._p(f32), ops._p(tt), tt.shape[1] if tt is not None else 0,
-                                         max(t_taps, 1), ops._p(act_bits)), "vp3d_bn_act_fwd_s16")
+    nb = y.numel() * (8.0 + (4.0 if residual is not None else 0.0) + (4.0 if tt is not None else 0.0) +
+                      (4.0 if want_f32 else 0.0) + (0.125 if act_bits is not None else 0.0))
+    with ops._Timed("stream_bn_act_fwd", 0.0, nb, (m, c)):
+        check(_lib.lib().vp3d_bn_act_fwd_s16(ops._stream(), m, c, y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                             C.byref(drop) if drop is not None else None, *rargs, out_bound.data_ptr(),
+                                             out.data_ptr(), ops._p(f32), ops._p(tt), tt.shape[1] if tt is not None else 0,
+                                             max(t_taps, 1), ops._p(act_bits)), "vp3d_bn_act_fwd_s16")
     if want_f32:
         return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None), f32
     return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
@@ -452,10 +481,13 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     assert want_rows or want_t
     dy = torch.empty_like(y) if want_rows else None
     dyt = torch.empty((c, t_pitch(m)), dtype=torch.float32, device=y.device) if want_t else None   # (wgrad_rows needs none)
-    check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, ops._p(act_bits),
-                                  a_g.data_ptr(), a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), ops._p(dyt),
-                                  dyt.shape[1] if dyt is not None else 0),
-          "vp3d_bn_bwd_apply_s16")
+    nb = y.numel() * (8.0 + (4.0 if dy is not None else 0.0) + (4.0 if dyt is not None else 0.0) +
+                      (0.125 if act_bits is not None else 0.0))
+    with ops._Timed("stream_bn_bwd_apply", 0.0, nb, (m, c)):
+        check(L.vp3d_bn_bwd_apply_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, ops._p(act_bits),
+                                      a_g.data_ptr(), a_b.data_ptr(), dy_bound.data_ptr(), ops._p(dy), ops._p(dyt),
+                                      dyt.shape[1] if dyt is not None else 0),
+              "vp3d_bn_bwd_apply_s16")
     return (S16(dy, dy_bound) if dy is not None else None), (S16(dyt, dy_bound) if dyt is not None else None), dgam, dbet
 
 
