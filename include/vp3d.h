@@ -254,11 +254,12 @@ int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const fl
                             const float* mean, const float* invstd, const uint8_t* act_bits, float keep_scale,
                             float* partials, int32_t* nparts);
 /* vp3d_bn_bwd_reduce_bits + vp3d_bn_bwd_finalize_s16 in ONE launch (replaces the reduction half of autograd's
- * batch_norm backward, model.py:127,134 backward): the partial rows are summed by the last-arriving blocks (tickets, fp64,
- * fixed order => deterministic), which also write dgamma / dbeta and max the bound of dy into dy_bound (zeroed by the
- * caller).  Workspaces: partials [*nparts][2][C] floats, group_partials [*ngroups][2][C] doubles, tickets [*ntickets]
- * int32 that must be ZERO on entry and are zero again on exit (keep one buffer per stream).  Call with partials == NULL
- * to query the three sizes.  keep scale = 1/(1-p). */
+ * batch_norm backward, model.py:127,134 backward).  Strip-owned: a block walks a row range of one 64-channel strip and
+ * writes one partial row; the LAST block of a strip to finish (one ticket per strip) sums the strip's *nparts (<= 32) partial
+ * rows (fp64, row order => deterministic), writes dgamma / dbeta of its channels and maxes the bound of dy into dy_bound
+ * (zeroed by the caller).  Workspaces: partials [C/64][*nparts][2][64] floats (= *nparts * 2 * C), tickets [*ntickets] int32
+ * that must be ZERO on entry and are zero again on exit (keep one buffer per stream); group_partials is no longer used
+ * (*ngroups = 0, may be NULL).  Call with partials == NULL to query the sizes.  keep scale = 1/(1-p). */
 int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,
                                const float* mean, const float* invstd, const uint8_t* act_bits, float p,
                                const float* scale, const float* go_bound, float* partials, double* group_partials,

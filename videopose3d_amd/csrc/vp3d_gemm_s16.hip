@@ -1120,7 +1120,11 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
   }
   // Hybrid 30: the 256x256 configuration on whole rounds of 256 tiles and the 128x128 one on the rows of the fractional
   // last round (4x finer tiles on 2x the slots instead of 256 - f idle CUs for a whole tile time).
-  if (best_cfg == 22 && best_s == 1) {
+  // (Re-measured with the round-2 kernel, tools/dgrad_epi_bench.py + tools/env_ab.py: the plain 256x256 launch is now
+  // faster on every shape of the step -- 518 vs 568 us on M 27,648 x N 3072 x K 1024, -0.7 % step time -- because the
+  // two launches serialise; the hybrid stays available as the explicit configuration 30.)
+  constexpr bool kPlanHybrid = false;
+  if (kPlanHybrid && best_cfg == 22 && best_s == 1) {
     const int m_split = hybrid_split_rows(M, N);
     if (m_split > 0 && m_split < M) {
       const int n256 = (N + 255) / 256, n128 = (N + 127) / 128;

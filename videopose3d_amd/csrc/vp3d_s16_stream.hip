@@ -273,22 +273,15 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
 // the block folds its row sub-groups through LDS (fixed order) and writes ONE partial row:
 // partials[(blockIdx.y*2 + {0,1})*C + c].
 // ---------------------------------------------------------------------------------------------------------
-// Optional finalize fused into the reduction (fin.cnt != nullptr): the partial rows are folded by "last arrivers" -- the
-// last block of every group of fin.per_group blocks sums its group's rows (fp64, row order) into gpart[group], the last
-// group to finish sums the group rows (group order), writes dgamma / dbeta and max-es the bound of dy.  Fixed summation
-// tree => deterministic; no block ever waits (tickets, not spinning), so co-residency is not required.  This replaces
-// the separate [C]-sized finalize launch, whose few blocks waited 80-140 us for a CU slot behind the weight-gradient
-// GEMM that runs on the second stream (profiles/r01_s16_step_timeline.txt).
+// Finalize fused into the reduction (k_bn_bwd_reduce_strips below): what the strip's last block needs.
 struct BwdFin {
-  double* gpart;               // [groups][2][C]
-  int* cnt;                    // [gridDim.x][groups + 1] tickets, zero on entry, zero again on exit
+  int* cnt;                    // [strips] tickets, zero on entry, zero again on exit
   float* dgamma;
   float* dbeta;
   const float* scale;
   const float* go_bound;
   float* dy_bound;
   float inv_keep, inv_m, sqrt_m1;
-  int per_group;
 };
 
 // Ticket of a block that has finished writing its contribution: true for the block that arrives last.  Publish / consume
@@ -314,7 +307,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
                                                             const float* __restrict__ invstd,
                                                             const uint8_t* __restrict__ act_bits, float keep_scale,
                                                             float* __restrict__ partials, int lanes_per_row,
-                                                            int rows_per_block, BwdFin fin) {
+                                                            int rows_per_block) {
   __shared__ float red[256 * 8];
   const int lr = threadIdx.x % lanes_per_row, rsub = threadIdx.x / lanes_per_row;
   const int c = (blockIdx.x * lanes_per_row + lr) * 4;
@@ -365,66 +358,94 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const 
     *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 0) * C + c) = f32x4{sg[0], sg[1], sg[2], sg[3]};
     *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.y * 2 + 1) * C + c) = f32x4{sgx[0], sgx[1], sgx[2], sgx[3]};
   }
-  if (fin.cnt == nullptr) return;
+}
 
-  // ---- fused finalize: stage 1 (group of rows) ---------------------------------------------------------------
-  const int per = fin.per_group;
-  const int ngroups = ((int)gridDim.y + per - 1) / per;
-  const int grp = (int)blockIdx.y / per;
-  const int row0 = grp * per, nrows = min(per, (int)gridDim.y - row0);
-  int* cnt = fin.cnt + (int64_t)blockIdx.x * (ngroups + 1);
-  int* flag = reinterpret_cast<int*>(red);
-  if (rows_per_block > 1) __syncthreads();             // (red[] was read above)
-  if (!last_arriver(cnt + grp, nrows, flag)) return;
-  const bool owner = rsub == 0 && c < C;
-  if (owner) {
-    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-    for (int r = row0; r < row0 + nrows; ++r) {          // (unrolled: the loads of 8 rows in flight, the tail is pure latency)
-      const f32x4 v = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 0) * C + c);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(partials + ((int64_t)r * 2 + 1) * C + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] += (double)v[e];
-        b[e] += (double)w[e];
-      }
-    }
-    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 0) * C + c) = double2{a[0], a[1]};
-    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 0) * C + c + 2) = double2{a[2], a[3]};
-    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 1) * C + c) = double2{b[0], b[1]};
-    *reinterpret_cast<double2*>(fin.gpart + ((int64_t)grp * 2 + 1) * C + c + 2) = double2{b[2], b[3]};
-  }
-  // ---- stage 2 (groups) + finalize -----------------------------------------------------------------------------
-  if (!last_arriver(cnt + ngroups, ngroups, flag)) return;
-  float bmax = 0.f;
-  const float gmax = s16_load_bound(fin.go_bound) * fin.inv_keep;      // (whole waves take part in the bound's shuffle)
-  if (owner) {
-    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 6
-    for (int g = 0; g < ngroups; ++g) {
-      const double2 a01 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 0) * C + c);
-      const double2 a23 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 0) * C + c + 2);
-      const double2 b01 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 1) * C + c);
-      const double2 b23 = *reinterpret_cast<const double2*>(fin.gpart + ((int64_t)g * 2 + 1) * C + c + 2);
-      a[0] += a01.x; a[1] += a01.y; a[2] += a23.x; a[3] += a23.y;
-      b[0] += b01.x; b[1] += b01.y; b[2] += b23.x; b[3] += b23.y;
-    }
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm-backward column sums + finalize in ONE launch, strip-owned (vp3d_bn_bwd_reduce_fin_s16):
+//   block (strip s of 64 channels, row block rb of R): thread (rsub = tid / 16, q = tid % 16) walks the rows
+//   rb*rows_per + rsub + 16 i of its 4 channels (a wave reads four 256-byte runs per array and step), the block folds its
+//   16 row lanes through LDS in lane order and writes ONE partial row of 128 floats: partials[(s*R + rb)*128 + {0,1}*64 + ch].
+//   The LAST block of a strip to finish (one ticket per strip) loads the strip's R partial rows in a single batch (R <= 32:
+//   <= 16 floats per thread), sums them in fp64 in row order (deterministic) and writes dgamma / dbeta of its 64 channels and
+//   the strip's contribution to the bound of dy.  One fence / ticket / load round trip after the main loop: the two-stage
+//   full-row version this replaces spent 18-30 us in its tail (4-6 dependent round trips; tools/reduce_bench.py), the
+//   separate [C]-sized finalize launch before it waited 80-140 us for a CU slot behind the second stream's GEMM.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RED_MAX_R = 32;
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_strips(int M, int C, int rows_per, const float* __restrict__ go,
+                                                              const float* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const uint8_t* __restrict__ act_bits,
+                                                              float* __restrict__ partials, BwdFin fin) {
+  __shared__ float red[RED_MAX_R * 128];               // [16 row lanes][128] for the block fold, [R][128] for the strip fold
+  __shared__ int flag;
+  const int q = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  const int s = blockIdx.x, rb = blockIdx.y, R = gridDim.y;
+  const int c = s * 64 + q * 4;
+  float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    float mu[4], is[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float db = (float)a[e], dg = (float)b[e];
-      fin.dbeta[c + e] = db;
-      fin.dgamma[c + e] = dg;
-      bmax = fmaxf(bmax, fabsf(fin.scale[c + e]) * (gmax + fabsf(db) * fin.inv_m + fin.sqrt_m1 * fabsf(dg) * fin.inv_m));
+      mu[e] = mean[c + e];
+      is[e] = invstd[c + e];
+    }
+    const uint8_t* bp = act_bits + act_bits_index(c, 0, M);
+    const int sh = c & 4;
+    const int m_end = min(M, (rb + 1) * rows_per);
+#pragma unroll 8
+    for (int m = rb * rows_per + rsub; m < m_end; m += 16) {
+      const int64_t e0 = (int64_t)m * C + c;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(go + e0);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e0);
+      const uint32_t bits = (uint32_t)bp[(int64_t)m * 8] >> sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = ((bits >> e) & 1u) ? gv[e] * fin.inv_keep : 0.f;
+        sg[e] += g;
+        sgx[e] = fmaf(g, (yv[e] - mu[e]) * is[e], sgx[e]);
+      }
     }
   }
+  // block fold over the 16 row lanes (lane order)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
-  __syncthreads();                                     // flag (red[0]) has been read by everyone
-  if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = bmax;
+  for (int e = 0; e < 4; ++e) {
+    red[rsub * 128 + q * 4 + e] = sg[e];
+    red[rsub * 128 + 64 + q * 4 + e] = sgx[e];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    s16_atomic_bound(fin.dy_bound, fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])));
-    for (int i = 0; i <= ngroups; ++i) cnt[i] = 0;     // every block of this column strip has drawn its tickets
+  float* prow = partials + ((int64_t)s * R + rb) * 128;
+  if (threadIdx.x < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r * 128 + threadIdx.x];
+    prow[threadIdx.x] = t;
+  }
+  if (!last_arriver(fin.cnt + s, R, &flag)) return;   // (its barriers also fence red[])
+  // ---- strip fold + finalize by the strip's last block ------------------------------------------------------------
+  const float* srows = partials + (int64_t)s * R * 128;
+  for (int i = threadIdx.x; i < R * 32; i += 256)
+    *reinterpret_cast<f32x4*>(red + i * 4) = *reinterpret_cast<const f32x4*>(srows + i * 4);
+  __syncthreads();
+  float bmax = 0.f;
+  const float gmax = s16_load_bound(fin.go_bound) * fin.inv_keep;      // (whole waves take part in the bound's shuffle)
+  if (threadIdx.x < 64) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < R; ++r) {
+      a += (double)red[r * 128 + threadIdx.x];
+      b += (double)red[r * 128 + 64 + threadIdx.x];
+    }
+    const float db = (float)a, dg = (float)b;
+    const int cc = s * 64 + threadIdx.x;
+    fin.dbeta[cc] = db;
+    fin.dgamma[cc] = dg;
+    bmax = fabsf(fin.scale[cc]) * (gmax + fabsf(db) * fin.inv_m + fin.sqrt_m1 * fabsf(dg) * fin.inv_m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+    if (threadIdx.x == 0) {
+      s16_atomic_bound(fin.dy_bound, bmax);
+      fin.cnt[s] = 0;                                  // every block of this strip has drawn its ticket
+    }
   }
 }
 
@@ -992,7 +1013,7 @@ int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const fl
   VP3D_REQUIRE(go && y && mean && invstd && act_bits && aligned16(go) && aligned16(y) && aligned16(partials),
                "bn_bwd_reduce_bits: null or unaligned pointer");
   hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
-                     invstd, act_bits, keep_scale, partials, lpr, rpb, BwdFin{});
+                     invstd, act_bits, keep_scale, partials, lpr, rpb);
   return check_launch("bn_bwd_reduce_bits");
 }
 
@@ -1003,24 +1024,23 @@ int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const
                                int32_t* ngroups, int32_t* ntickets) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && C > 0 && C % 64 == 0 && nparts && ngroups && ntickets && p >= 0.f && p < 1.f,
                "bn_bwd_reduce_fin_s16: bad argument (needs C %% 64 == 0)");
-  const int c4 = C / 4;
-  const int lpr = c4 < 256 ? c4 : 256;
-  const int rpb = 256 / lpr;
-  const int gx = (c4 + lpr - 1) / lpr;
-  int64_t gy = (M + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);     // the geometry of vp3d_bn_bwd_reduce_bits
-  const int64_t cap = 512 / gx > 0 ? 512 / gx : 1;
-  gy = gy > cap ? cap : gy;
-  int per = 1;                                         // ~sqrt(rows) rows per group: both last-arriver stages stay short
-  while (per * per < gy) ++per;
-  *nparts = (int32_t)gy;
-  *ngroups = (int32_t)((gy + per - 1) / per);
-  *ntickets = gx * (*ngroups + 1);
+  (void)group_partials;                                // (single-stage fold: no second workspace any more)
+  const int strips = C / 64;
+  // row blocks: >= 4 steps of 16 rows per block, ~512 blocks at most (2 per CU), <= RED_MAX_R partial rows per strip
+  int64_t R = (M + 63) / 64;
+  const int64_t cap = 512 / strips > 0 ? 512 / strips : 1;
+  R = R > cap ? cap : R;
+  R = R > RED_MAX_R ? RED_MAX_R : R;
+  const int rows_per = (int)((M + R - 1) / R);
+  R = (M + rows_per - 1) / rows_per;
+  *nparts = (int32_t)R;
+  *ngroups = 0;
+  *ntickets = strips;
   if (partials == nullptr) return VP3D_OK;             // size query
-  VP3D_REQUIRE(go && y && mean && invstd && act_bits && scale && go_bound && group_partials && tickets && dgamma && dbeta &&
-                   dy_bound && aligned16(go) && aligned16(y) && aligned16(partials) && aligned16(group_partials),
+  VP3D_REQUIRE(go && y && mean && invstd && act_bits && scale && go_bound && tickets && dgamma && dbeta && dy_bound &&
+                   aligned16(go) && aligned16(y) && aligned16(partials),
                "bn_bwd_reduce_fin_s16: null or unaligned pointer");
   BwdFin fin;
-  fin.gpart = group_partials;
   fin.cnt = tickets;
   fin.dgamma = dgamma;
   fin.dbeta = dbeta;
@@ -1030,9 +1050,8 @@ int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const
   fin.inv_keep = 1.0f / (1.0f - p);
   fin.inv_m = 1.0f / (float)M;
   fin.sqrt_m1 = sqrtf((float)(M > 1 ? M - 1 : 1));
-  fin.per_group = per;
-  hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
-                     invstd, act_bits, fin.inv_keep, partials, lpr, rpb, fin);
+  hipLaunchKernelGGL(k_bn_bwd_reduce_strips, dim3(strips, (unsigned)R), dim3(256), 0, (hipStream_t)stream, (int)M, C, rows_per,
+                     go, y, mean, invstd, act_bits, partials, fin);
   return check_launch("bn_bwd_reduce_fin_s16");
 }
 
