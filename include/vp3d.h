@@ -209,8 +209,16 @@ typedef struct vp3d_s16 {
   const vp3d_dropout* act_drop;
   const float* act_bound;
   uint8_t* act_bits;
+  /* Stream-K configurations (cfg 120 / 122 = the tilings 20 / 22 with the K-tiles of the last, partly filled round of tiles
+   * shared equally by a full round of workgroups; the last contributor of a tile sums the partial accumulators in a fixed
+   * order and runs the epilogue -- one launch, no finishing pass, bit-reproducible): ws / ws_floats is their workspace and
+   * tickets the zeroed int32 counters (zero again on exit; keep one buffer per stream), sizes from vp3d_nt_s16_workspace. */
+  int32_t* tickets;
 } vp3d_s16;
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
+/* Workspace of a vp3d_tconv_nt_s16 launch in configuration (cfg, splits): floats (0: none) and int32 tickets (0: none). */
+int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
+                          int32_t* tickets);
 /* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form
  * (c_in % 32 == 0, 16-byte aligned rows, ldx / ldw in 4-byte units).  Every GEMM of the model runs through it:
  *   forward : wt = S16 of the packed rows Wt[co][k*c_in+ci]

@@ -491,3 +491,41 @@ def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg):
     assert torch.equal(bits_f, bits_ref)
     if p_drop > 0:
         assert 0.6 < float((S.join(a_f) != 0).float().mean() / (S.join(S.bn_act_fwd(y, coef, None, None, bound)[0]) != 0).float().mean()) < 0.9
+
+
+@pytest.mark.parametrize("cfg", [120, 122])
+@pytest.mark.parametrize("shape", [(37, 27, 256, 256, 3), (64, 48, 128, 512, 1), (300, 27, 256, 768, 3)])
+def test_stream_k_equals_plain_launch(cfg, shape):
+    """Stream-K configurations (shared K-tiles of the last round + in-kernel fix-up by the last contributor): same result as
+    the plain launch of the same tiling up to the summation order of the K ranges (fp32 accumulators: ~1e-6 of sum|a||b|),
+    fused epilogue included (bias, ReLU, residual, BatchNorm slab statistics, amax) -- and bit-identical run to run."""
+    b, t, c_in, c_out, taps = shape
+    g = torch.Generator().manual_seed(cfg + b)
+    spec = ConvSpec(c_in, c_out, taps, 1, taps) if taps > 1 else ConvSpec(c_in, c_out, 1)
+    x = torch.randn(b, t, c_in, generator=g).to(DEV)
+    w = (torch.randn(c_out, c_in, taps, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(c_out, generator=g).to(DEV)
+    xs, ws_ = S.split(x), S.split(ops.pack_weight(w))
+    t_out = spec.t_out(t)
+    m = b * t_out
+    res = torch.randn(b, t_out, c_out, generator=g).to(DEV)
+    from videopose3d_amd.plan import ResSpec
+
+    def run(c):
+        st = ops.stat_buffers(m, c_out, DEV)
+        am = S.new_bound(DEV)
+        y = S.conv_nt(xs, ws_, spec, bias=bias, relu=True, residual=(res, ResSpec(0, 1)), stats=st, amax_out=am, cfg=c, splits=1)
+        return y, st, am
+
+    y0, st0, am0 = run(cfg - 100)
+    y1, st1, am1 = run(cfg)
+    y2, st2, am2 = run(cfg)
+    den = torch.nn.functional.conv1d(x.abs().permute(0, 2, 1), w.abs(), stride=spec.stride).permute(0, 2, 1)
+    assert float(((y1 - y0).abs() / den).max()) < 2e-6
+    assert float((st1[0] - st0[0]).abs().max() / st0[0].abs().max()) < 1e-5
+    assert float((st1[1] - st0[1]).abs().max() / st0[1].abs().max()) < 1e-5
+    assert abs(float(am1.max()) - float(am0.max())) <= 1e-5 * float(am0.max())
+    assert torch.equal(y1, y2) and torch.equal(st1[0], st2[0]) and torch.equal(st1[1], st2[1])
+    ref = torch.relu(torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double(), bias.double(),
+                                                stride=spec.stride).permute(0, 2, 1)) + res.double()
+    assert float(((y1.double() - ref).abs() / (den.double() + 1.0)).max()) < 2e-6

@@ -261,7 +261,15 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
   set_splits(&a, nullptr, 0);
   const bool single = o->out_s16 || o->res_s16 || o->no_output || o->act_scale != nullptr;
   return launch_nt_s16((hipStream_t)stream, a, o->cfg, single ? 1 : o->splits, o->ws, o->ws_floats,
-                       o->raw_partials != 0);   // the finishing pass of a split launch knows neither S16 residuals nor S16 output
+                       o->raw_partials != 0,    // the finishing pass of a split launch knows neither S16 residuals nor S16 output
+                       o->tickets);
+}
+
+int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
+                          int32_t* tickets) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && ws_floats && tickets, "nt_s16_workspace: bad argument");
+  nt_s16_workspace((int)M, N, K, cfg, splits, raw_partials, ws_floats, tickets);
+  return VP3D_OK;
 }
 
 int vp3d_split_rows(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, void* dst,

@@ -24,7 +24,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int SK_AUX = 16;  // cache policy of the stream-K partial-tile traffic (16 = sc1: past the L2)
 constexpr int KQ = 32;   // K and channels-per-tap are multiples of this many elements (launcher check)
 
 // BKE: elements per K-tile (16 or 32 -> 64- or 128-byte rows in the LDS image, 1 or 2 MFMA k-steps per tile).
@@ -186,10 +188,7 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
 // form compact patches: column blocks of up to 8 tiles, inside a block m-tile by m-tile (the ~32-64 tiles an XCD runs at
 // a time are a 4..8 x 8 patch: ~12 operand panels for 32 tiles).  Equal shares matter: handing out whole m-tiles per XCD
 // (the fp32 kernel's order) leaves e.g. 108 m-tiles as 14/14/14/14/13/13/13/13 -- a sixth round on four XCDs.
-__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int per_xcd, int& tile_m, int& tile_n) {
-  const int xcd = bid & 7, q = bid >> 3;
-  const int L = xcd * per_xcd + q;
-  if (q >= per_xcd || L >= m_tiles * n_tiles) return false;
+__device__ __forceinline__ void tile_from_linear(int L, int m_tiles, int n_tiles, int& tile_m, int& tile_n) {
   const int gn = min(n_tiles, 8);
   const int full = (n_tiles / gn) * gn;              // columns in full blocks
   const int in_full = m_tiles * full;
@@ -202,12 +201,32 @@ __device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int p
     tile_m = r / gl;
     tile_n = full + (r - tile_m * gl);
   }
+}
+__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int per_xcd, int& tile_m, int& tile_n) {
+  const int xcd = bid & 7, q = bid >> 3;
+  const int L = xcd * per_xcd + q;
+  if (q >= per_xcd || L >= m_tiles * n_tiles) return false;
+  tile_from_linear(L, m_tiles, n_tiles, tile_m, tile_n);
   return true;
+}
+
+// ---- stream-K (SK instances) -------------------------------------------------------------------------------------------
+// A launch of T tiles on P resident workgroups leaves the last ceil(T/P)-th round partly empty (432 tiles of 256x256 on
+// 256 CUs: 1.69 rounds cost 2).  The SK instances run the first sk_dp_blocks tiles of the linear order whole, one per
+// workgroup as always, and hand the K-tiles ("units") of the remaining sk_tiles tiles to sk_blocks further workgroups in
+// EQUAL contiguous shares: workgroup rank r owns units [r U / G, (r + 1) U / G) of the U = sk_tiles * K/BK units, i.e. the
+// tail of one tile, possibly whole tiles, and the head of another.  A workgroup that holds only part of a tile's K range
+// stores its scaled accumulators in the tile's workspace slot of its segment and draws the tile's ticket; the LAST
+// contributor to arrive sums all segments in segment order (deterministic) and runs the normal epilogue.  Nobody waits:
+// no co-residency requirement.  Partials cross XCDs (separate L2s), so they are stored and loaded with sc1 (past the L2)
+// instead of fencing -- an agent-scope acquire would invalidate the L2 that holds everybody's operand panels.
+__device__ __forceinline__ int sk_rank_of(int64_t x, int64_t U, int G) {       // largest r with floor(r U / G) <= x
+  return (int)(((x + 1) * G + U - 1) / U) - 1;
 }
 
 // ACT: the instance that carries the fused BatchNorm + ReLU + dropout epilogue (Epi::act_scale) -- kept out of the
 // general instances so that its Philox temporaries do not enter their register allocation.
-template <class C, bool ACT = false>
+template <class C, bool ACT = false, bool SK = false>
 __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const RowsGemmArgs p) {
   constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE, PA = C::PA, PB = C::PB;
   constexpr int BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP, CPR = ROWB / 16;   // chunks per row
@@ -220,12 +239,18 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const int wm = w / C::WN, wn = w % C::WN;
   const int h = lane >> 5, cl = lane & 31;
 
+  const int nkt_all = p.K / BK;
+  // ---- work of this workgroup: one (tile, K range) segment, or (stream-K workgroups) a run of them ------------------------
   // uniform split-K: blockIdx = split * positions + position (the tiles of one K range are dispatched together and
   // share operand panels in L2); every split writes its raw, scaled partial matrix [M][N] at part + split*part_stride
-  const int split = blockIdx.x / p.pos_full;
+  const int split = SK ? 0 : blockIdx.x / p.pos_full;
   const int bid = blockIdx.x - split * p.pos_full;
-  int tile_m, tile_n;
-  if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos_full >> 3, tile_m, tile_n)) return;
+  const int sk_T_dp = p.m_tiles * p.n_tiles - p.sk_tiles;           // stream-K: tiles [0, sk_T_dp) run whole
+  const int64_t sk_U = (int64_t)p.sk_tiles * nkt_all;
+  int sk_rank = 0;
+  __shared__ int sk_flag;
+  // One (tile, K range) segment: main loop, then the tile's epilogue -- or, for part of a shared tile, the fix-up.
+  auto run_segment = [&](const int tile_m, const int tile_n, const int kt_begin, const int kt_end, const int sk_ts) {
   const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;      // this launch covers rows [m_begin, m_end)
 
   for (int r = tid; r < BM; r += C::NT) {
@@ -244,9 +269,6 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt_all = p.K / BK;
-  const int kt_begin = split * p.kt_per_split;
-  const int kt_end = min(nkt_all, kt_begin + p.kt_per_split);
   const int nkt = max(0, kt_end - kt_begin);
 
   // ---- LDS-DMA staging: running pointers, one 64-bit add per piece per K-tile (as the fp32 kernel) ----
@@ -427,6 +449,59 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
         for (int j = 0; j < CB; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] *= scale;
+    }
+  }
+  if (SK && (kt_begin != 0 || kt_end != nkt_all)) {
+    // ---- stream-K fix-up: this workgroup holds part of the tile's K range ------------------------------------------------
+    const int r_first = sk_rank_of((int64_t)sk_ts * nkt_all, sk_U, p.sk_blocks);
+    const int r_last = sk_rank_of((int64_t)sk_ts * nkt_all + nkt_all - 1, sk_U, p.sk_blocks);
+    const int nseg = r_last - r_first + 1, my_seg = sk_rank - r_first;
+    constexpr int NV = RB * CB * 4;                    // 16-byte vectors of accumulators per lane
+    float* tile_ws = p.sk_ws + (int64_t)sk_ts * p.sk_max_seg * (BM * BN);
+    {
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_ws + (int64_t)my_seg * (BM * BN)), 0,
+                                                                    BM * BN * 4, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const f32x16& a16 = acc[v / (CB * 4)][(v / 4) % CB];
+        const int q4 = (v & 3) * 4;
+        u32x4 d;
+        d[0] = __float_as_uint(a16[q4 + 0]);
+        d[1] = __float_as_uint(a16[q4 + 1]);
+        d[2] = __float_as_uint(a16[q4 + 2]);
+        d[3] = __float_as_uint(a16[q4 + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (v * C::NT + tid) * 16, 0, SK_AUX);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores have reached memory ...
+    __syncthreads();                                   // ... and so have everybody's
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(p.sk_cnt + sk_ts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == nseg - 1;
+      if (last) __hip_atomic_store(p.sk_cnt + sk_ts, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+      sk_flag = last;
+    }
+    __syncthreads();
+    if (!sk_flag) return;                              // (workgroup-uniform) somebody else finishes this tile
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sg = 0; sg < nseg; ++sg) {                // segment order: the sum does not depend on who arrived last
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_ws + (int64_t)sg * (BM * BN)), 0,
+                                                                    BM * BN * 4, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (v * C::NT + tid) * 16, 0, SK_AUX);
+        f32x16& a16 = acc[v / (CB * 4)][(v / 4) % CB];
+        const int q4 = (v & 3) * 4;
+        a16[q4 + 0] += __uint_as_float(d[0]);
+        a16[q4 + 1] += __uint_as_float(d[1]);
+        a16[q4 + 2] += __uint_as_float(d[2]);
+        a16[q4 + 3] += __uint_as_float(d[3]);
+      }
     }
   }
   if (!partial) {
@@ -685,6 +760,55 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       float m = red[0];
       for (int i = 1; i < C::NW; ++i) m = fmaxf(m, red[i]);
       s16_atomic_bound(e.amax_out, m);
+    }
+  }
+  };   // run_segment
+
+  if constexpr (!SK) {
+    int tile_m, tile_n;
+    if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos_full >> 3, tile_m, tile_n)) return;
+    const int kt_begin = split * p.kt_per_split;
+    run_segment(tile_m, tile_n, kt_begin, min(nkt_all, kt_begin + p.kt_per_split), 0);
+  } else {
+    // units in the linear tile order: unit = tile * (K-tiles per tile) + K-tile.  A whole-tile workgroup owns one tile's
+    // units, a stream-K workgroup its equal share of the shared tiles' units
+    int64_t u, u_end;
+    if ((int)blockIdx.x < p.sk_dp_blocks) {
+      u = (int64_t)((bid & 7) * (sk_T_dp >> 3) + (bid >> 3)) * nkt_all;
+      u_end = u + nkt_all;
+    } else {
+      const int g = (int)blockIdx.x - p.sk_dp_blocks;               // runs on XCD g % 8 (sk_dp_blocks % 8 == 0): the workgroups
+      sk_rank = (g & 7) * (p.sk_blocks >> 3) + (g >> 3);            // of one XCD share contiguous tiles
+      u = (int64_t)sk_T_dp * nkt_all + (int64_t)sk_rank * sk_U / p.sk_blocks;
+      u_end = (int64_t)sk_T_dp * nkt_all + (int64_t)(sk_rank + 1) * sk_U / p.sk_blocks;
+    }
+    // Order of a stream-K workgroup's segments: the (partial) TAIL of its first tile is run LAST.  All shares are equal, so
+    // every workgroup then walks K-tile position t (heads / whole tiles) or t + K/BK - share (tails) at step t: the
+    // workgroups stay in lockstep along K and keep sharing operand panels in L2, as the whole-tile rounds do (in unit
+    // order every workgroup starts at a different K offset: measured 1.6x slower than the plain launch).
+    int64_t tail_u = -1, tail_end = 0;
+    if (u % nkt_all != 0) {
+      tail_u = u;
+      tail_end = min(u_end, (u / nkt_all + 1) * nkt_all);
+      u = tail_end;
+    }
+    bool first = true;
+    for (;;) {
+      if (u >= u_end) {
+        if (tail_u < 0) break;
+        u = tail_u;
+        u_end = tail_end;
+        tail_u = -1;
+      }
+      const int L = (int)(u / nkt_all);
+      const int kb = (int)(u - (int64_t)L * nkt_all);
+      const int ke = (int)min((int64_t)nkt_all, kb + (u_end - u));
+      u += ke - kb;
+      int tile_m, tile_n;
+      tile_from_linear(L, p.m_tiles, p.n_tiles, tile_m, tile_n);
+      if (!first) __syncthreads();                   // the previous segment's epilogue is done with the row table / staging
+      first = false;
+      run_segment(tile_m, tile_n, kb, ke, L - sk_T_dp);
     }
   }
 }
@@ -1068,7 +1192,74 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   return check_launch("nt_s16");
 }
 
+// ---- stream-K geometry (host): which tiles are shared, by how many workgroups, workspace ------------------------------------
+struct SkGeom {
+  int t_dp, t_sk, blocks, max_seg;
+  int64_t ws_floats;
+};
+constexpr int kSkMinUnits = 8;          // K-tiles per stream-K workgroup at least (below that the fix-up dominates)
+template <class C>
+bool sk_geometry(int M, int N, int K, SkGeom* g) {
+  const int64_t T = (int64_t)((M + C::BM - 1) / C::BM) * ((N + C::BN - 1) / C::BN);
+  const int P = 256 * C::OCC, nkt = K / C::BKE;
+  if (T <= 0 || T >= (1 << 30) || nkt < kSkMinUnits) return false;
+  const int rem = (int)(T % P);
+  if (rem == 0) return false;                          // whole rounds: nothing to balance
+  int t_sk = rem;
+  if (T >= P && rem < P / 2) t_sk += P;                // at least half a tile of work per workgroup
+  const int64_t U = (int64_t)t_sk * nkt;
+  int G = P;
+  while (G > 8 && U < (int64_t)G * kSkMinUnits) G >>= 1;
+  if (U < (int64_t)G * kSkMinUnits) return false;
+  const int per = (int)(U / G);
+  g->t_dp = (int)T - t_sk;
+  g->t_sk = t_sk;
+  g->blocks = G;
+  g->max_seg = (nkt + per - 1) / per + 1;
+  g->ws_floats = (int64_t)t_sk * g->max_seg * C::BM * C::BN;
+  return true;
+}
+
+template <class C>
+int launch_cfg_sk(hipStream_t s, RowsGemmArgs a, float* ws, int64_t ws_floats, int32_t* tickets) {
+  SkGeom g;
+  if (!sk_geometry<C>(a.M, a.N, a.K, &g)) return launch_cfg<C>(s, a, 1);     // whole rounds (or too little K): plain launch
+  VP3D_REQUIRE(ws != nullptr && aligned16(ws) && ws_floats >= g.ws_floats && tickets != nullptr,
+               "nt_s16: the stream-K configuration needs its workspace (%lld floats) and %d zeroed tickets (vp3d_nt_s16_workspace)",
+               (long long)g.ws_floats, g.t_sk);
+  a.m_begin = 0;
+  a.m_end = a.M;
+  a.m_tiles = (a.M + C::BM - 1) / C::BM;
+  a.n_tiles = (a.N + C::BN - 1) / C::BN;
+  a.pos_full = g.t_dp + g.blocks;
+  a.tail_pos = 0;
+  a.splits = 1;
+  a.kt_per_split = a.K / C::BKE;
+  a.sk_dp_blocks = g.t_dp;
+  a.sk_tiles = g.t_sk;
+  a.sk_blocks = g.blocks;
+  a.sk_max_seg = g.max_seg;
+  a.sk_ws = ws;
+  a.sk_cnt = tickets;
+  hipLaunchKernelGGL((k_nt_s16<C, false, true>), dim3(g.t_dp + g.blocks), dim3(C::NT), 0, s, a);
+  return check_launch("nt_s16(stream-K)");
+}
+
 }  // namespace
+
+// Workspace of a launch in configuration cfg: floats (0 = none) and zeroed int32 tickets (0 = none).
+void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets) {
+  *ws_floats = (splits > 1 || raw) ? (int64_t)(splits > 1 ? splits : 1) * M * N : 0;
+  *tickets = 0;
+  SkGeom g;
+  bool sk = false;
+  if (cfg == 120) sk = sk_geometry<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(M, N, K, &g);
+  if (cfg == 122) sk = sk_geometry<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(M, N, K, &g);
+  if (sk) {
+    *ws_floats = g.ws_floats;
+    *tickets = g.t_sk;
+  }
+}
 
 // Tile configuration and split-K factor of an [M,N,K] S16 GEMM: cost model in microseconds, least-squares fit (10 % rms)
 // to the tools/s16_tune.py sweep on MI355X (22 shapes of the training step x 2 tilings x up to 10 split factors; its
@@ -1143,8 +1334,11 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
 // cfg < 0: planned.  splits > 1 needs `ws` (splits*M*N floats): forward/dgrad launches then run k_s16_finish for the fused
 // epilogue; with raw_partials the partial matrices ARE the result (wgrad: vp3d_wgrad_reduce sums them).
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, float* ws, int64_t ws_floats,
-                  bool raw_partials) {
+                  bool raw_partials, int32_t* tickets) {
   RowsGemmArgs a = a_in;
+  a.sk_dp_blocks = a.sk_tiles = a.sk_blocks = a.sk_max_seg = 0;
+  a.sk_ws = nullptr;
+  a.sk_cnt = nullptr;
   VP3D_REQUIRE(a.K % KQ == 0 && a.c_src % KQ == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && aligned16(a.A) && aligned16(a.B) &&
                    aligned16(a.zeros),
                "nt_s16: the split-fp16 GEMM needs channel counts %% 32 == 0 and 16-byte aligned S16 rows");
@@ -1171,6 +1365,16 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   const int64_t a_bytes = ((a_rows - 1) * a.lda + a.c_src) * 4, b_bytes = ((int64_t)(a.N - 1) * a.ldb + a.K) * 4;
   a.a_bytes = (uint32_t)a_bytes;
   a.b_bytes = (uint32_t)b_bytes;
+  if (cfg == 120 || cfg == 122) {                // stream-K instances of 20 / 22 (whole-launch configurations: no split-K)
+    const bool flat = a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31);
+    if (flat || raw_partials || a.epi.no_out || a.epi.act_scale != nullptr) {
+      cfg -= 100;
+      splits = 1;
+    } else {
+      return cfg == 120 ? launch_cfg_sk<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, ws, ws_floats, tickets)
+                        : launch_cfg_sk<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, ws, ws_floats, tickets);
+    }
+  }
   if (cfg >= 20 && cfg <= 23 && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31))) {
     static const int flat_of[4] = {0, 10, 4, 13};
     cfg = flat_of[cfg - 20];

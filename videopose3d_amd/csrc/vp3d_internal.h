@@ -92,6 +92,12 @@ struct RowsGemmArgs {
   int64_t part_floats;
   uint32_t a_bytes, b_bytes;   // S16 kernel, buffer-descriptor DMA: byte extents of the two operands (set by the launcher)
   int32_t m_begin, m_end;      // S16 kernel: the rows this launch covers (set by the launcher; [0, M) normally)
+  // S16 kernel, stream-K instances (set by the launcher): blocks [0, sk_dp_blocks) run the first tiles of the linear order
+  // whole, the sk_blocks behind share the K-tiles of the last sk_tiles tiles; workspace sk_ws: sk_max_seg slots of one tile
+  // of floats per shared tile, sk_cnt: one ticket per shared tile (zero on entry, zero again on exit)
+  int32_t sk_dp_blocks, sk_tiles, sk_blocks, sk_max_seg;
+  float* sk_ws;
+  int32_t* sk_cnt;
   Epi epi;
 };
 
@@ -122,7 +128,8 @@ int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
 // split-fp16 NT GEMM (vp3d_gemm_s16.hip); cfg selects the tile configuration
 void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out);
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, float* ws, int64_t ws_floats,
-                  bool raw_partials);
+                  bool raw_partials, int32_t* tickets = nullptr);
+void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets);
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
                       const float* bound);
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound);

@@ -81,7 +81,14 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
         splits = ps if splits <= 0 else splits
     o.cfg, o.splits = cfg, splits
     ws = None
-    if splits > 1 or raw:
+    if cfg >= 100:                                    # stream-K configuration: partial-tile slots + one ticket per shared tile
+        nf, nt = C.c_int64(0), C.c_int32(0)
+        check(_lib.lib().vp3d_nt_s16_workspace(m, n, k, cfg, 1, 0, C.byref(nf), C.byref(nt)), "vp3d_nt_s16_workspace")
+        if nf.value:
+            ws = torch.empty(nf.value, dtype=torch.float32, device=device)
+            o.ws, o.ws_floats = ws.data_ptr(), ws.numel()
+            o.tickets = _tickets(device, nt.value).data_ptr()
+    elif splits > 1 or raw:
         ws = torch.empty((splits, m, n), dtype=torch.float32, device=device)
         o.ws, o.ws_floats = ws.data_ptr(), ws.numel()
     o.raw_partials = 1 if raw else 0
