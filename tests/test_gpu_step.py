@@ -421,6 +421,68 @@ def test_graphed_train_step_equals_eager_steps(p_drop):
     assert torch.allclose(m_e.expand_bn.running_var, m_g.expand_bn.running_var, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_graphed_generic_step_equals_eager_semi_supervised_step(p_drop):
+    """graph.GraphedStep (hipGraph capture of an arbitrary autograd step) on run.py's semi-supervised step (run.py:322-394:
+    pose + trajectory model, mpjpe + weighted mpjpe + project_to_2d back-projection + bone-length term) against the same
+    steps run eagerly: losses, every gradient of both models, running statistics; masks advance on every replay."""
+    import copy
+    import videopose3d_amd as V
+    from videopose3d_amd import loss as vloss
+    from videopose3d_amd.camera import project_to_2d
+    from videopose3d_amd.graph import GraphedStep
+    torch.manual_seed(11)
+    fw, bsz = [3, 3, 3], 8
+    pos_e = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=p_drop, channels=64).to(DEV).train()
+    traj_e = V.TemporalModelOptimized1f(17, 2, 1, fw, dropout=p_drop, channels=64).to(DEV).train()
+    pos_g, traj_g = copy.deepcopy(pos_e), copy.deepcopy(traj_e)
+    for i, (a, b) in enumerate(((pos_e, pos_g), (traj_e, traj_g))):
+        a._drop_seed = b._drop_seed = 777 + i
+        a._drop_calls, b._drop_calls = 1, 0            # replay k draws offset 0 + k; the eager models start at 1
+    parents = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]
+    par = torch.tensor(parents[1:], device=DEV)       # (a Python-list index would be a host-to-device copy inside the capture)
+
+    def make_fn(pos, traj):
+        def fn(cat, y3, cam):
+            y_traj = y3[:, :, :1]
+            y_pos = y3.clone()
+            y_pos[:, :, 0] = 0
+            p_cat, t_cat = pos(cat), traj(cat)
+            loss = vloss.mpjpe(p_cat[:bsz], y_pos) + vloss.weighted_mpjpe(t_cat[:bsz], y_traj, 1 / y_traj[:, :, :, 2])
+            recon = project_to_2d(p_cat[bsz:] + t_cat[bsz:], cam)
+            loss = loss + vloss.mpjpe(recon, cat[bsz:, 13:-13, :, :2].contiguous())
+            dists = p_cat[:, :, 1:] - p_cat.index_select(2, par)
+            bone = torch.mean(torch.norm(dists, dim=3), dim=1)
+            loss = loss + torch.mean(torch.abs(torch.mean(bone[:bsz], dim=0) - torch.mean(bone[bsz:], dim=0)))
+            loss.backward()
+            return loss.detach()
+        return fn
+
+    eager, step = make_fn(pos_e, traj_e), GraphedStep(make_fn(pos_g, traj_g), models=(pos_g, traj_g))
+    gen = torch.Generator().manual_seed(9)
+    losses = []
+    for k in range(3):
+        cat = (torch.randn(2 * bsz, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(DEV)
+        y3 = (torch.randn(bsz, 1, 17, 3, generator=gen) * 0.3).to(DEV)
+        y3[:, :, 0, 2] = y3[:, :, 0, 2].abs() + 3.0
+        cam = torch.tensor([1.15, 1.15, 0.0, 0.0, -0.2, 0.25, 0.0, 0.0, 0.0]).repeat(bsz, 1).to(DEV)
+        pos_e.zero_grad(set_to_none=True)
+        traj_e.zero_grad(set_to_none=True)
+        le = float(eager(cat, y3, cam))
+        lg = float(step(cat, y3, cam))
+        losses.append(lg)
+        assert abs(le - lg) < 1e-6 * max(1.0, abs(le)), (k, le, lg)
+        for me, mg in ((pos_e, pos_g), (traj_e, traj_g)):
+            for (name, pe), (_, pg) in zip(me.named_parameters(), mg.named_parameters()):
+                assert torch.allclose(pe.grad, pg.grad, rtol=1e-5, atol=1e-8), (k, name)
+    for me, mg in ((pos_e, pos_g), (traj_e, traj_g)):
+        for (name, be), (_, bg) in zip(me.named_buffers(), mg.named_buffers()):
+            assert torch.allclose(be.float(), bg.float(), rtol=1e-6, atol=1e-7), name
+    assert int(pos_g.expand_bn.num_batches_tracked) == 3 and len(step._cache) == 1
+    if p_drop > 0:
+        assert len({round(v, 9) for v in losses}) == 3
+
+
 def test_batched_sequence_evaluation_equals_one_by_one():
     """generators.predict_sequences (several ragged-length videos per forward call, TTA pair folded) against the reference
     evaluation loop: one sequence + its mirrored copy per call (run.py:652-680)."""

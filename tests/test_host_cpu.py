@@ -276,3 +276,17 @@ def test_direct_gradient_sink_refuses_a_second_backward_pass():
         sync.group_done(0)
     sync.zero_grad()
     sync.group_done(0)
+
+
+def test_dropout_seed_is_reproducible_across_processes():
+    """The dropout stream of a model is a function of torch's seed, the rank and the model's construction ORDINAL -- not of
+    id(self): two runs of the same script (or two debug reruns of a DP rank) draw the same masks."""
+    import subprocess
+    import sys
+    code = ("import torch, videopose3d_amd as V\n"
+            "torch.manual_seed(7)\n"
+            "a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3], channels=32)\n"
+            "b = V.TemporalModelOptimized1f(17, 2, 1, [3, 3], channels=32)\n"
+            "print(a._next_dropout_state()[0], b._next_dropout_state()[0])\n")
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT).stdout.split() for _ in range(2)]
+    assert len(outs[0]) == 2 and outs[0] == outs[1] and outs[0][0] != outs[0][1]

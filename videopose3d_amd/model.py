@@ -40,6 +40,7 @@ class TemporalModelBase(nn.Module):
     """Do not instantiate this class (mirrors reference model.py:10-77)."""
 
     _kind = None
+    _n_models = 0
 
     def __init__(self, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels):
         super().__init__()
@@ -58,6 +59,8 @@ class TemporalModelBase(nn.Module):
         self._stats_epoch = 0
         self._drop_calls = 0
         self._drop_seed = None
+        TemporalModelBase._n_models += 1
+        self._ordinal = TemporalModelBase._n_models      # construction order in this process: separates the models' mask streams
         self._drop_counter = None       # optional device uint64 step counter added to the dropout offset (graph.py)
         # GEMM arithmetic (not part of the reference API / state_dict): "f16x3" = split-fp16 operands on
         # v_mfma_f32_32x32x16_f16 (fp32-class results: 22+ operand bits, exact products, fp32 accumulation; ~3x the
@@ -114,7 +117,8 @@ class TemporalModelBase(nn.Module):
     def _next_dropout_state(self):
         if self._drop_seed is None:
             rank = int(os.environ.get("RANK", "0"))
-            self._drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + id(self) % 65521) \
+            # (model ordinal, not id(self): the same script gives the same masks in every process / on every rerun)
+            self._drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + self._ordinal) \
                 & 0xFFFFFFFFFFFFFFFF
         off = self._drop_calls
         self._drop_calls += 1
