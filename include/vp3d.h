@@ -216,6 +216,19 @@ typedef struct vp3d_s16 {
   int32_t* tickets;
 } vp3d_s16;
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
+/* The expand layer's forward, dedicated kernel (replaces model.py:74 / :127 / :176
+ *   x = self.drop(self.relu(self.expand_bn(self.expand_conv(x))))
+ * in training mode without ever storing the conv output): x = S16 im2row rows [M][kpad] (kpad = 32..128, e.g. 3 taps x 34
+ * channels = 102 -> 128), w = S16 weight rows [N][kpad], both with their bounds.  Two launches around vp3d_bn_finalize:
+ *   statistics pass (stat_sum, stat_m2 != NULL, out == NULL): the 64-row-slab BatchNorm statistics of X W^T, the layout
+ *       vp3d_tconv_nt_s16's statistics epilogue writes ([M/64 slabs][N]);
+ *   activation pass (out != NULL): out = S16 rows [M][N] of dropout(relu(X W^T * scale[n] + shift[n])) under the exponent of
+ *       *out_bound, act_bits (may be NULL) the [z > 0 and kept] bits -- bit for bit what vp3d_tconv_nt_s16 +
+ *       vp3d_bn_act_fwd_s16 produce.
+ * A workgroup keeps the W fragments of its 256 columns in registers and streams 64-row tiles of X through LDS. */
+int vp3d_expand_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t N, int32_t kpad, const void* x, const float* x_bound,
+                        const void* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
+                        const float* shift, const vp3d_dropout* drop, const float* out_bound, void* out, uint8_t* act_bits);
 /* Workspace of a vp3d_tconv_nt_s16 launch in configuration (cfg, splits): floats (0: none) and int32 tickets (0: none). */
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
                           int32_t* tickets);

@@ -462,13 +462,15 @@ def test_gather_transposed_operand_vs_torch():
         assert float(got[:, m:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kc", [(128, 256), (96, 64), (64, 1024)])
 @pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1)])
-def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg):
+def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg, kc):
     """The expand layer's fused forward: pass 1 (no_output) writes only the BatchNorm slab statistics, pass 2 applies
     BatchNorm + ReLU + dropout in the GEMM epilogue and writes S16 rows + activation bits -- bit for bit what
     vp3d_bn_act_fwd_s16 makes of the stored conv output."""
     g = torch.Generator().manual_seed(17)
-    b, t, k, c = 37, 27, 128, 256                       # M = 999: ragged last tile
+    b, t = 37, 27                                       # M = 999: ragged last tile
+    k, c = kc
     spec = ConvSpec(k, c, 1)
     x = (torch.randn(b, t, k, generator=g)).clamp(-1, 1).to(DEV)
     w = (torch.randn(c, k, 1, generator=g) * 0.1).to(DEV)
@@ -489,6 +491,15 @@ def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg):
     a_f = S.conv_nt(xs, ws_, spec, act=(coef, drop, bound, bits_f), cfg=cfg if cfg > 0 else -1)
     assert torch.equal(a_f.data.view(torch.int32), a_ref.data.view(torch.int32))
     assert torch.equal(bits_f, bits_ref)
+    # the dedicated expand-layer kernel (W fragments in registers, X streamed through LDS): the same bits again
+    st_c = ops.stat_buffers(m, c, DEV)
+    assert S.expand_fwd(xs, ws_, stats=st_c) is None
+    assert torch.equal(st_a[0], st_c[0]) and torch.equal(st_a[1], st_c[1])
+    bits_d = S.new_act_bits(m, c, DEV)
+    bits_d.zero_()
+    a_d = S.expand_fwd(xs, ws_, act=(coef, drop, bound, bits_d))
+    assert torch.equal(a_d.data.view(torch.int32), a_ref.data.view(torch.int32))
+    assert torch.equal(bits_d, bits_ref)
     if p_drop > 0:
         assert 0.6 < float((S.join(a_f) != 0).float().mean() / (S.join(S.bn_act_fwd(y, coef, None, None, bound)[0]) != 0).float().mean()) < 0.9
 

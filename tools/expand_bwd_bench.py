@@ -80,3 +80,11 @@ for cfg in (20, 22, -1):
         timeit(lambda: S.conv_nt(xs3, ws_, spec, stats=st, no_output=True, cfg=cfg)),
         timeit(lambda: S.conv_nt(xs3, ws_, spec, act=(cf, drop, bound, bits_f), cfg=cfg)),
         timeit(lambda: S.conv_nt(xs3, ws_, spec, act=(cf, None, bound, bits_f), cfg=cfg))))
+
+# ---- the dedicated expand-layer kernel (vp3d_expand_fwd_s16) ---------------------------------------------------------------
+yy = S.conv_nt(xs3, ws_, spec, stats=st)
+cf = ops.bn_finalize(bn, m, st)
+print("dedicated kernel: statistics pass %6.1f us | activation pass p=0.25 %6.1f us, p=0 %6.1f us" % (
+    timeit(lambda: S.expand_fwd(xs3, ws_, stats=st)),
+    timeit(lambda: S.expand_fwd(xs3, ws_, act=(cf, drop, bound, bits_f))),
+    timeit(lambda: S.expand_fwd(xs3, ws_, act=(cf, None, bound, bits_f)))))

@@ -265,6 +265,23 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
                        o->tickets);
 }
 
+int vp3d_expand_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t N, int32_t kpad, const void* x, const float* x_bound,
+                        const void* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
+                        const float* shift, const vp3d_dropout* drop, const float* out_bound, void* out, uint8_t* act_bits) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && N % 8 == 0 && kpad >= 32 && kpad <= 128 && kpad % 32 == 0 && x && w &&
+                   x_bound && w_bound && aligned16(x) && aligned16(w) && M * kpad * 4 < ((int64_t)1 << 31),
+               "expand_fwd_s16: bad argument (16-byte aligned S16 rows of 32..128 columns, N %% 8 == 0, X below 2 GiB)");
+  const bool stats = stat_sum != nullptr, act = out != nullptr;
+  VP3D_REQUIRE(stats != act, "expand_fwd_s16: exactly one of the statistics pass (stat_sum, stat_m2) and the activation pass (out)");
+  if (stats) VP3D_REQUIRE(stat_m2 != nullptr, "expand_fwd_s16: stat_m2 is NULL");
+  if (act) {
+    VP3D_REQUIRE(scale && shift && out_bound && aligned16(out), "expand_fwd_s16: the activation pass needs scale, shift, out_bound");
+    if (drop) VP3D_REQUIRE(drop->p >= 0.f && drop->p < 1.f, "expand_fwd_s16: dropout p=%f", drop->p);
+  }
+  return launch_expand_fwd_s16((hipStream_t)stream, M, N, kpad, (const float*)x, x_bound, (const float*)w, w_bound, stat_sum,
+                               stat_m2, scale, shift, make_drop(act ? drop : nullptr), out_bound, (float*)out, act_bits);
+}
+
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
                           int32_t* tickets) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && ws_floats && tickets, "nt_s16_workspace: bad argument");

@@ -1,0 +1,319 @@
+// The expand layer of the temporal model in split-fp16 arithmetic (gfx950 / CDNA4), forward:
+//     a0 = dropout(relu(BatchNorm(X W^T)))          reference model.py:74 (TemporalModelBase._forward_blocks callers :127/:176)
+// X = the im2row rows of the 2-D keypoints [M][kpad] (kpad <= 128: 3 taps x 34 channels = 102 -> 128), W [N][kpad].
+//
+// The generic NT GEMM (vp3d_gemm_s16.hip) is built around a deep K loop; with K = 128 a 256x256 tile is four K-tiles of main
+// loop and then an epilogue that writes 256 KB with the matrix pipe idle -- the layer took 105 us (statistics pass) + 247 us
+// (BatchNorm + ReLU + dropout pass) for 4 % of the step's FLOPs.  Here the shape is used instead of fought:
+//   * W is tiny: a wave keeps the fragments of ITS 32 output columns in registers for the whole launch (64 VGPRs for
+//     K = 128) -- no B operand traffic, no B tiles in LDS;
+//   * a workgroup = 8 compute waves (256 columns) + 1 loader wave walks the 64-row tiles of its row group: the loader
+//     streams the X rows HBM -> LDS (LDS-DMA through a buffer descriptor, 3-deep ring of 32-KiB tiles, rows XOR-swizzled
+//     against ds_read_b128 bank conflicts); only the loader has loads in flight, so its counted vmcnt waits stay exact
+//     while the compute waves issue stores (mixed loads and stores retire out of order with respect to each other);
+//   * a 64-row tile IS one BatchNorm statistics slab: pass 1 reduces the accumulators in registers (wave shuffles) and
+//     writes the slab's (sum, M2) per column -- nothing else; pass 2 recomputes the tile (48 MFMAs per wave), applies
+//     BatchNorm + ReLU + dropout and writes S16 rows + activation bits.  The conv output never exists in memory.
+// Both passes are bit-identical to the generic path (same k-step order, same epilogue arithmetic): tests/test_gpu_s16.py.
+#include "vp3d_internal.h"
+#include "vp3d_s16.h"
+
+namespace vp3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EX_CW = 8;                        // compute waves (32 output columns each)
+constexpr int EX_NT = (EX_CW + 1) * 64;         // + the loader wave
+constexpr int EX_ROWS = 64;                     // rows per tile = one statistics slab
+constexpr int EX_ROWB = 512;                    // bytes per staged row (kpad <= 128 S16 elements)
+constexpr int EX_STAGES = 3;
+constexpr int EX_STAGE_B = EX_ROWS * EX_ROWB;   // 32 KiB
+constexpr int EX_PIECES = EX_STAGE_B / 1024;    // 1-KiB LDS-DMA pieces per tile (2 rows each)
+constexpr int EX_EPI_PITCH = 36;                // floats per row of a wave's [32][32] transposition region
+constexpr int EX_EPI_B = 32 * EX_EPI_PITCH * 4;
+constexpr int EX_SMEM = EX_STAGES * EX_STAGE_B + EX_CW * EX_EPI_B;
+constexpr int EX_KS = 8;                        // 16-element k-steps (zero fragments beyond kpad)
+constexpr int kOobOff = (int)0x80000000u;
+
+struct ExpandArgs {
+  const float* X;              // S16 rows [M][kpad]
+  const float* W;              // S16 rows [N][kpad]
+  const float* x_bound;
+  const float* w_bound;
+  int32_t M, N, kpad;
+  uint32_t x_bytes;
+  int32_t n_slices, row_groups;   // grid = n_slices * row_groups workgroups
+  float* stat_sum;             // pass 1
+  float* stat_m2;
+  const float* scale;          // pass 2
+  const float* shift;
+  const float* out_bound;
+  float* out;
+  uint8_t* bits;
+  DropP drop;
+};
+
+template <int N>
+__device__ __forceinline__ void ex_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void ex_stage_sync() {           // a wave's own LDS writes -> its own LDS reads
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool ACT>
+__global__ void __launch_bounds__(EX_NT, 3) k_expand_fwd_s16(const ExpandArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[EX_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup b runs on XCD b % 8: the n_slices workgroups that read the same rows sit on the same XCD (one L2 fetch)
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int group = (b & 7) + 8 * (b / (8 * p.n_slices));
+  const int n_tiles = (p.M + EX_ROWS - 1) / EX_ROWS;
+  const int row_pitch_b = p.kpad * 4;
+
+  if (w == EX_CW) {
+    // ---- loader wave: tile it of this row group -> stage it % 3, two tiles ahead of the compute waves -----------------
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+    const int chunks = p.kpad / 4;                    // 16-byte chunks per row
+    auto issue = [&](int tile, int stage) {
+      char* sA = smem + stage * EX_STAGE_B;
+#pragma unroll 8
+      for (int pc = 0; pc < EX_PIECES; ++pc) {
+        const int r = 2 * pc + (lane >> 5), cp = lane & 31;          // LDS row / chunk position of this lane's 16 bytes
+        const int c = cp ^ (r & 15);                                 // source chunk (swizzle on the source side)
+        const int64_t row = (int64_t)tile * EX_ROWS + r;
+        const int off = (c < chunks && row < p.M) ? (int)(row * row_pitch_b + c * 16) : kOobOff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sA + pc * 1024), 16, off, 0, 0, 0);
+      }
+    };
+    int t = group;
+    if (t < n_tiles) issue(t, 0);
+    if (t + p.row_groups < n_tiles) issue(t + p.row_groups, 1);
+    int it = 0;
+    for (; t < n_tiles; t += p.row_groups, ++it) {
+      // tile `it` has landed when at most the pieces of tile it+1 are outstanding (loads retire in order)
+      if (t + p.row_groups < n_tiles) ex_wait_vmcnt<EX_PIECES>();
+      else ex_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                   // B_it: tile `it` visible; everybody is done with tile it-1
+      const int t2 = t + 2 * p.row_groups;
+      if (t2 < n_tiles) issue(t2, (it + 2) % EX_STAGES);
+    }
+    return;
+  }
+
+  // ---- compute waves ---------------------------------------------------------------------------------------------------
+  const int h = lane >> 5, cl = lane & 31;
+  const int n_col = slice * (EX_CW * 32) + w * 32 + cl;          // this lane's output column (B fragment / accumulator column)
+  // W fragments of the wave's 32 columns: k-step s, lane half h -> elements 16 s + 8 h .. + 7 (hi chunk 4 s + 2 h, lo the next)
+  f16x8 bh[EX_KS], bl[EX_KS];
+  {
+    const bool nok = n_col < p.N;
+    const char* wrow = reinterpret_cast<const char*>(p.W) + (int64_t)(nok ? n_col : 0) * row_pitch_b;
+#pragma unroll
+    for (int s = 0; s < EX_KS; ++s) {
+      const int c = 4 * s + 2 * h;
+      const bool ok = nok && c * 4 < p.kpad;
+      f16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+      bh[s] = ok ? *reinterpret_cast<const f16x8*>(wrow + c * 16) : z;
+      bl[s] = ok ? *reinterpret_cast<const f16x8*>(wrow + c * 16 + 16) : z;
+    }
+  }
+  const float acc_scale = s16_pow2(s16_exp_of(p.x_bound) + s16_exp_of(p.w_bound));
+  // fragment addressing in a staged tile: row (blk*32 + cl) * 512 B, chunk (4 s + 2 h) ^ (row & 15)
+  const int a_row = cl * EX_ROWB, swz = cl & 15;
+  float* wreg = reinterpret_cast<float*>(smem + EX_STAGES * EX_STAGE_B + w * EX_EPI_B);
+
+  // pass-2 constants: lane = 8 consecutive columns of a row of the wave's 32-column strip
+  const int q4 = lane & 3, rsub = lane >> 2;                     // column group, row within a 16-row pass
+  const int n8 = slice * (EX_CW * 32) + w * 32 + q4 * 8;
+  float sc8[8], sh8[8];
+  DropP d = p.drop;
+  float inv_out = 1.f;
+  if (ACT) {
+    drop_resolve(d);
+    inv_out = s16_pow2(-s16_exp_of(p.out_bound));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      sc8[c] = n8 + c < p.N ? p.scale[n8 + c] : 0.f;
+      sh8[c] = n8 + c < p.N ? p.shift[n8 + c] : 0.f;
+    }
+  }
+
+  int it = 0;
+  for (int t = group; t < n_tiles; t += p.row_groups, ++it) {
+    __builtin_amdgcn_s_barrier();                     // B_it (see the loader)
+    const char* sA = smem + (it % EX_STAGES) * EX_STAGE_B;
+    // NB 32-row blocks per compute phase: both for the statistics pass (a slab's M2 needs the slab mean first), one at a time
+    // for the activation pass (its epilogue constants and Philox temporaries need the registers)
+    constexpr int NB = ACT ? 1 : 2;
+    f32x16 acc[NB];
+    auto compute = [&](int blk0) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+      // fragments of k-step s+1 are read while the MFMAs of k-step s run (register double buffer; pinned below: hipcc's own
+      // schedule is read -> wait -> 1-2 MFMAs -> read ..., every LDS latency exposed)
+      f16x8 fa[2][NB][2];                              // [buffer][block][hi / lo]
+      auto load_frags = [&](int s_, int buf) {
+        const int co = ((4 * s_ + 2 * h) ^ swz) * 16;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          fa[buf][blk][0] = *reinterpret_cast<const f16x8*>(sA + (blk0 + blk) * 32 * EX_ROWB + a_row + co);
+          fa[buf][blk][1] = *reinterpret_cast<const f16x8*>(sA + (blk0 + blk) * 32 * EX_ROWB + a_row + (co ^ 16));
+        }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int s = 0; s < EX_KS; ++s) {
+        if (s + 1 < EX_KS) load_frags(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][blk][1], bh[s], acc[blk], 0, 0, 0);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][blk][0], bl[s], acc[blk], 0, 0, 0);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][blk][0], bh[s], acc[blk], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);        // masks: 0x100 DS read, 0x008 MFMA
+#pragma unroll
+      for (int s = 0; s + 1 < EX_KS; ++s) {
+#pragma unroll
+        for (int q = 0; q < 2 * NB; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB, 0);
+      if (acc_scale != 1.f) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[blk][r] *= acc_scale;
+      }
+    };
+    const int row0 = t * EX_ROWS;
+    const int cnt = min(EX_ROWS, p.M - row0);         // rows of this slab (wave-uniform)
+    if constexpr (!ACT) {
+      // ---- BatchNorm slab statistics (sum, M2 around the slab mean): accumulator row = (reg&3) + 8 (reg>>2) + 4 h ------
+      compute(0);
+      float s = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = blk * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          s += (r < cnt) ? acc[blk][reg] : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      const float mean = s / (float)cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = blk * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const float dlt = acc[blk][reg] - mean;
+          q += (r < cnt) ? dlt * dlt : 0.f;
+        }
+      q += __shfl_xor(q, 32);
+      if (h == 0 && n_col < p.N) {
+        p.stat_sum[(int64_t)t * p.N + n_col] = s;
+        p.stat_m2[(int64_t)t * p.N + n_col] = q;
+      }
+    } else {
+      // ---- BatchNorm + ReLU + dropout -> S16 rows + activation bits, one 32-row block at a time through the wave's region --
+#pragma unroll 1
+      for (int blk = 0; blk < 2; ++blk) {
+        compute(blk);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          wreg[r * EX_EPI_PITCH + cl] = acc[0][reg];
+        }
+        ex_stage_sync();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int r = ps * 16 + rsub;
+          const int m = row0 + blk * 32 + r;
+          if (m >= p.M || n8 >= p.N) continue;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(wreg + r * EX_EPI_PITCH + q4 * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(wreg + r * EX_EPI_PITCH + q4 * 8 + 4);
+          const float y8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const int64_t e0 = (int64_t)m * p.N + n8;   // element index in the [M][N] activation (the mask's counter)
+          float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+          if (d.on) {
+            float ma[4], mb[4];
+            drop4(d, (uint64_t)(e0 >> 2), ma);
+            drop4(d, (uint64_t)(e0 >> 2) + 1, mb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mk[c] = ma[c];
+              mk[4 + c] = mb[c];
+            }
+          }
+          float v[8];
+          uint32_t bits = 0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float z = fmaf(y8[c], sc8[c], sh8[c]);
+            v[c] = (z > 0.f ? z * mk[c] : (z != z ? z : 0.f)) * inv_out;
+            bits |= (z > 0.f && mk[c] != 0.f) ? (1u << c) : 0u;
+          }
+          if (p.bits != nullptr) p.bits[act_bits_index(n8, m, p.M)] = (uint8_t)bits;
+          f16x8 hi, lo;
+          s16_split8(v, 1.f, hi, lo);
+          f16x8* o = reinterpret_cast<f16x8*>(p.out + e0);
+          o[0] = hi;
+          o[1] = lo;
+        }
+        ex_stage_sync();
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
+                          const float* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
+                          const float* shift, const DropP& drop, const float* out_bound, float* out, uint8_t* bits) {
+  ExpandArgs a;
+  a.X = x;
+  a.W = w;
+  a.x_bound = x_bound;
+  a.w_bound = w_bound;
+  a.M = (int32_t)M;
+  a.N = N;
+  a.kpad = kpad;
+  a.x_bytes = (uint32_t)(M * kpad * 4);
+  a.n_slices = (N + EX_CW * 32 - 1) / (EX_CW * 32);
+  const int n_tiles = (int)((M + EX_ROWS - 1) / EX_ROWS);
+  // one workgroup per CU (132 KiB of LDS); every row group at least ~4 tiles; multiples of 8 groups
+  int groups = 256 / a.n_slices;
+  while (groups > 8 && groups * 4 > n_tiles) groups >>= 1;
+  groups = groups < 8 ? 8 : (groups / 8) * 8;
+  a.row_groups = groups;
+  a.stat_sum = stat_sum;
+  a.stat_m2 = stat_m2;
+  a.scale = scale;
+  a.shift = shift;
+  a.out_bound = out_bound;
+  a.out = out;
+  a.bits = bits;
+  a.drop = drop;
+  const dim3 grid(a.n_slices * a.row_groups), block(EX_NT);
+  if (out != nullptr) hipLaunchKernelGGL(k_expand_fwd_s16<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_expand_fwd_s16<false>, grid, block, 0, s, a);
+  return check_launch("expand_fwd_s16");
+}
+
+}  // namespace vp3d

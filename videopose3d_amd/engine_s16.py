@@ -251,7 +251,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
         # the conv output never goes to HBM (its backward, expand_bwd, needs no y either)
         fused0 = idx == 0 and fuse_expand and n_layers > 1
-        y = S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
+        dedicated0 = fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"      # vp3d_expand_fwd_s16
+        y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
         coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
@@ -272,7 +273,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
                 if S.expand_rows_form(spec.c_out, kpad):
                     saved[0].x_rows = a                  # P = G^T X reads the rows; the transposed copy only feeds X^T X
         if fused0:
-            a, a_t = S.conv_nt(a, wf, spec, act=(coef, drop, bounds[idx], bits)), None
+            act0 = (coef, drop, bounds[idx], bits)
+            a, a_t = (S.expand_fwd(a, wf, act=act0) if dedicated0 else S.conv_nt(a, wf, spec, act=act0)), None
         elif idx == n_layers - 1:            # the stack output also in fp32: the 3*J-column shrink conv runs on the fp32 path
             a, a_t, h_last = S.bn_act_fwd(y, coef, drop, residual, bounds[idx], t_taps=0, want_f32=True, act_bits=bits)
         else:

@@ -170,6 +170,31 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
     return out if s16_out is None else S16(out, wbound)
 
 
+def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
+    """The expand layer's dedicated forward kernel (vp3d_expand_fwd_s16): x S16 im2row rows [B, T, kpad], wt S16 [N, kpad].
+    stats = (sum, m2): statistics pass (returns None).  act = (coef, drop, out_bound, act_bits or None): activation pass,
+    returns the S16 rows [B, T, N] of dropout(relu(x wt^T * coef[0] + coef[1])) -- bit for bit what conv_nt + bn_act_fwd make."""
+    xd, wd = x.data, wt.data
+    b, t, kpad = xd.shape
+    n = wd.shape[0]
+    assert wd.shape[1] == kpad and (stats is None) != (act is None)
+    m = b * t
+    L = _lib.lib()
+    if stats is not None:
+        with ops._Timed("tconv_fwd", 2.0 * m * n * kpad, 4.0 * (xd.numel() + wd.numel()), (m, n, kpad, "ex", 1, 1)):
+            check(L.vp3d_expand_fwd_s16(ops._stream(), m, n, kpad, xd.data_ptr(), x.bound_ptr(), wd.data_ptr(), wt.bound_ptr(),
+                                        stats[0].data_ptr(), stats[1].data_ptr(), None, None, None, None, None, None),
+                  "vp3d_expand_fwd_s16(statistics)")
+        return None
+    coef, drop, out_bound, act_bits = act
+    out = torch.empty((b, t, n), dtype=torch.float32, device=xd.device)
+    with ops._Timed("tconv_fwd", 2.0 * m * n * kpad, 4.0 * (xd.numel() + wd.numel() + out.numel()), (m, n, kpad, "ex", 1, 1)):
+        check(L.vp3d_expand_fwd_s16(ops._stream(), m, n, kpad, xd.data_ptr(), x.bound_ptr(), wd.data_ptr(), wt.bound_ptr(), None,
+                                    None, coef[0].data_ptr(), coef[1].data_ptr(), C.byref(drop) if drop is not None else None,
+                                    out_bound.data_ptr(), out.data_ptr(), ops._p(act_bits)), "vp3d_expand_fwd_s16(activation)")
+    return S16(out, out_bound)
+
+
 def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: torch.Tensor, y_bpitch: int, ldy: int,
               *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0):
     """Raw form of conv_nt: out[b*y_bpitch + t*ldy + n] = sum_k x[gather] * wt[n][k] (+ epilogue)."""
