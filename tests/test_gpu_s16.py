@@ -8,6 +8,7 @@ import torch
 import videopose3d_amd as V
 from videopose3d_amd import ops, ops_s16 as S
 from videopose3d_amd.plan import ConvSpec, ResSpec
+from tests.util import unpack_act_bits
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -540,3 +541,29 @@ def test_stream_k_equals_plain_launch(cfg, shape):
     ref = torch.relu(torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double(), bias.double(),
                                                 stride=spec.stride).permute(0, 2, 1)) + res.double()
     assert float(((y1.double() - ref).abs() / (den.double() + 1.0)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(37, 27, 128, 256, 0.25), (64, 81, 128, 1024, 0.25), (5, 27, 64, 64, 0.0)])
+def test_expand_backward_p_from_go_equals_masked_gemm(shape):
+    """vp3d_expand_bwd_p_s16 (P = G^T X with G = go * keep * bits formed in registers, go read once) against an fp64 product
+    of the explicitly masked gradient, and against the two-kernel path it replaces (vp3d_act_mask_s16 + split-K GEMM)."""
+    b, t, kpad, c, p = shape
+    g = torch.Generator().manual_seed(b + c)
+    m = b * t
+    go = (torch.randn(b, t, c, generator=g) * 1e-3).to(DEV)
+    x = torch.randn(m, kpad, generator=g).clamp(-1, 1).to(DEV)
+    bits = torch.randint(0, 256, (m * c // 8,), generator=g, dtype=torch.uint8).to(DEV)
+    gb = S.amax(go)
+    xb = S.amax(x)
+    _, x_t = S.split_t(x, xb, want_rows=False, want_t=True)
+    ws, n = S.expand_p_from_go(go, gb, bits, p, x_t)
+    got = ws.double().sum(0)
+    keep = torch.from_numpy(unpack_act_bits(bits, m, c)).to(DEV)
+    G = go.view(m, c).double() * keep / (1.0 - p)
+    ref = G.t() @ x.double()
+    den = G.abs().t() @ x.double().abs()
+    assert float(((got - ref).abs() / (den + 1e-30)).max()) < 2e-6
+    g_t = S.act_mask(go, gb, bits, p, transposed=True)
+    ws2, n2 = S.nt_raw(g_t, x_t)
+    old = ws2.double().sum(0)
+    assert float(((got - old).abs() / (den + 1e-30)).max()) < 2e-6

@@ -88,3 +88,8 @@ print("dedicated kernel: statistics pass %6.1f us | activation pass p=0.25 %6.1f
     timeit(lambda: S.expand_fwd(xs3, ws_, stats=st)),
     timeit(lambda: S.expand_fwd(xs3, ws_, act=(cf, drop, bound, bits_f))),
     timeit(lambda: S.expand_fwd(xs3, ws_, act=(cf, None, bound, bits_f)))))
+
+# ---- backward: P = G^T X from go + bits (vp3d_expand_bwd_p_s16) vs act_mask + GEMM ------------------------------------------
+print("P from go + bits (fused kernel)   %7.1f us | + post %7.1f us" % (
+    timeit(lambda: S.expand_p_from_go(go, gb, bits, 0.25, x_t)),
+    timeit(lambda: S.expand_bwd(None, x_t, gram, wp, coef, m, 34, 3, 102, False, partials=S.expand_p_from_go(go, gb, bits, 0.25, x_t)))))

@@ -281,6 +281,155 @@ __global__ void __launch_bounds__(EX_NT, 3) k_expand_fwd_s16(const ExpandArgs p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the expand layer: P = G^T X  [C][kpad],  G = go * keep * [bn(y) > 0]  (include/vp3d.h, "Backward of the expand
+// layer without materialising dy"), straight from the incoming gradient go (fp32 rows) and the forward's activation bits.
+// Before: vp3d_act_mask_s16 wrote G as S16 (340 MB in, 340 MB out at the benchmark size) and a split-K GEMM read it again
+// (136 + 118 us).  Here a wave owns 32 channels: it loads ITS column of go for 16 rows at a time (8 rows per lane half: exactly
+// the MFMA A fragment, 128-byte runs per load), masks, scales and splits in registers, and multiplies with the B fragments
+// of X^T (the transposed S16 copy the forward already keeps for X^T X; 64-column slabs through a 2-deep LDS ring).  go is
+// read once; the kernel is bound by that read.  Register ring of 4 k-steps of loads in flight per wave (all VMEM operations
+// of a wave are loads, so the counted vmcnt waits are exact).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int EB_NW = 8, EB_NT = EB_NW * 64;
+constexpr int EB_SLAB = 64;                     // rows (reduction index) per LDS stage = 4 k-steps
+constexpr int EB_ROWB = EB_SLAB * 4;            // bytes per staged X^T row
+constexpr int EB_STAGE_B = 128 * EB_ROWB;       // kpad <= 128 rows
+constexpr int EB_SMEM = 2 * EB_STAGE_B;
+
+struct ExpandBwdArgs {
+  const float* go;             // [M][C] fp32
+  const float* go_bound;
+  const uint8_t* bits;
+  const float* xt;             // S16 transposed X: [kpad][ld_t]
+  const float* x_bound;
+  float* part;                 // [groups][C][kpad]
+  int32_t M, C, kpad, ld_t;
+  uint32_t go_bytes, bits_bytes, xt_bytes;
+  int32_t n_slices, groups, rows_per;     // rows_per % 64 == 0
+  float inv_keep;
+};
+
+__global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[EB_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, cl = lane & 31;
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;               // the slices of one row group share an XCD (X^T slabs: one L2 fetch)
+  const int group = (b & 7) + 8 * (b / (8 * p.n_slices));
+  const int c0w = slice * (EB_NW * 32) + w * 32;         // first channel of this wave
+  const int row_begin = group * p.rows_per, row_end = min(p.M, row_begin + p.rows_per);
+  const int n_stage = (max(0, row_end - row_begin) + EB_SLAB - 1) / EB_SLAB;
+  const int nj = p.kpad / 32;
+
+  __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)p.go, 0, p.go_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bits, 0, p.bits_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.xt, 0, p.xt_bytes, 0x00020000);
+
+  // ---- register ring: k-step q -> slot q % 4: 8 rows of go for this lane's channel + their activation-bit words ----------
+  float gv[4][8];
+  uint32_t bw[4][8];
+  const bool c_ok = c0w + cl < p.C;
+  const int g_col = (c0w + cl) * 4;
+  const int64_t bits_base = (int64_t)(c0w >> 6) * p.M * 8 + ((c0w & 63) >> 3);
+  auto issue_loads = [&](int q, int slot) {              // rows row_begin + 16 q + 8 h + i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = row_begin + q * 16 + 8 * h + i;
+      const bool ok = m < row_end && c_ok;
+      gv[slot][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, ok ? (int)((int64_t)m * p.C * 4 + g_col) : kOobOff, 0, 0));
+      bw[slot][i] = __builtin_amdgcn_raw_buffer_load_b32(rsB, ok ? (int)(bits_base + (int64_t)m * 8) : kOobOff, 0, 0);
+    }
+  };
+  // X^T slab S -> buffer S & 1: piece pc = 4 rows x 256 B; lane's 16 bytes: row 4 pc + (lane >> 4), chunk position lane & 15
+  auto issue_slab = [&](int S) {
+    char* sB = smem + (S & 1) * EB_STAGE_B;
+    const int m0 = row_begin + S * EB_SLAB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = w * 4 + i;
+      const int r = 4 * pc + (lane >> 4), cp = lane & 15;
+      const int c = cp ^ (r & 15);
+      const int off = r < p.kpad ? (int)(((int64_t)r * p.ld_t + m0) * 4 + c * 16) : kOobOff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sB + pc * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const float g_bound = s16_load_bound(p.go_bound) * p.inv_keep;
+  const int e_g = s16_exp_for_bound(g_bound);
+  const float g_scale = p.inv_keep * s16_pow2(-e_g);
+  const int b_row = cl * EB_ROWB, swz = cl & 15;
+
+  auto k_step = [&](int slot, int ks, const char* sB) {
+    // A fragment: G[rows 8 h + i][channel cl] = go * keep-scale * bit, split into hi + lo halves
+    f16x8 ah, al;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float g = ((bw[slot][i] >> cl) & 1u) ? gv[slot][i] * g_scale : 0.f;
+      const _Float16 hh = (_Float16)g;
+      ah[i] = hh;
+      al[i] = (_Float16)(g - (float)hh);
+    }
+    const int co = ((4 * ks + 2 * h) ^ swz) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nj) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + co);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + (co ^ 16));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+  };
+
+  if (n_stage > 0) {
+    issue_slab(0);
+    issue_loads(0, 0);
+    issue_loads(1, 1);
+    issue_loads(2, 2);
+    for (int S = 0; S < n_stage; ++S) {
+      // oldest outstanding first: [slab S+... issued after the previous barrier], loads q+1, q+2: the loads of k-step 4 S (and
+      // the slab S, older) have landed when at most 32 newer loads are outstanding
+      ex_wait_vmcnt<32>();
+      __builtin_amdgcn_s_barrier();                  // slab S visible; everybody is done with slab S-1
+      if (S + 1 < n_stage) issue_slab(S + 1);
+      const char* sB = smem + (S & 1) * EB_STAGE_B;
+      const int q = 4 * S;
+      issue_loads(q + 3, 3);                         // (hipcc tracks these register loads itself: its counted waits before the
+      k_step(0, 0, sB);                              //  uses below leave the newer k-steps -- and the next slab -- in flight)
+      issue_loads(q + 4, 0);
+      k_step(1, 1, sB);
+      issue_loads(q + 5, 1);
+      k_step(2, 2, sB);
+      issue_loads(q + 6, 2);
+      k_step(3, 3, sB);
+    }
+  }
+  ex_wait_vmcnt<0>();
+
+  // ---- partial P of this row group: part[group][c][j], scaled ------------------------------------------------------------
+  const float scale = s16_pow2(e_g + s16_exp_of(p.x_bound));
+  float* out = p.part + (int64_t)group * p.C * p.kpad;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < nj) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int c = c0w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (c < p.C) out[(int64_t)c * p.kpad + j * 32 + cl] = acc[j][reg] * scale;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
@@ -316,4 +465,41 @@ int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, con
   return check_launch("expand_fwd_s16");
 }
 
+}  // namespace vp3d
+
+namespace vp3d {
+int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
+                            const uint8_t* bits, float p, const float* xt, int64_t ld_t, const float* x_bound, int32_t groups,
+                            float* part) {
+  ExpandBwdArgs a;
+  a.go = go;
+  a.go_bound = go_bound;
+  a.bits = bits;
+  a.xt = xt;
+  a.x_bound = x_bound;
+  a.part = part;
+  a.M = (int32_t)M;
+  a.C = C;
+  a.kpad = kpad;
+  a.ld_t = (int32_t)ld_t;
+  a.go_bytes = (uint32_t)(M * C * 4);
+  a.bits_bytes = (uint32_t)(M * C / 8);
+  a.xt_bytes = (uint32_t)((int64_t)kpad * ld_t * 4);
+  a.n_slices = (C + EB_NW * 32 - 1) / (EB_NW * 32);
+  a.groups = groups;
+  const int64_t slabs = (M + EB_SLAB - 1) / EB_SLAB;
+  a.rows_per = (int32_t)((slabs + groups - 1) / groups) * EB_SLAB;
+  a.inv_keep = 1.0f / (1.0f - p);
+  hipLaunchKernelGGL(k_expand_bwd_p_s16, dim3(a.n_slices * groups), dim3(EB_NT), 0, s, a);
+  return check_launch("expand_bwd_p_s16");
+}
+
+// row groups of vp3d_expand_bwd_p_s16: one workgroup per CU over all column slices, >= 4 slabs per group, a multiple of 8
+int expand_bwd_groups(int64_t M, int32_t C) {
+  const int n_slices = (C + EB_NW * 32 - 1) / (EB_NW * 32);
+  const int64_t slabs = (M + EB_SLAB - 1) / EB_SLAB;
+  int groups = 256 / n_slices;
+  while (groups > 8 && (int64_t)groups * 4 > slabs) groups >>= 1;
+  return groups < 8 ? 8 : (groups / 8) * 8;
+}
 }  // namespace vp3d

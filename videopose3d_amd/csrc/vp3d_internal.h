@@ -134,6 +134,11 @@ void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t
 int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
                           const float* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
                           const float* shift, const DropP& drop, const float* out_bound, float* out, uint8_t* bits);
+// expand layer, backward: partial P = G^T X per row group from go + activation bits (vp3d_expand_s16.hip)
+int expand_bwd_groups(int64_t M, int32_t C);
+int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
+                            const uint8_t* bits, float p, const float* xt, int64_t ld_t, const float* x_bound, int32_t groups,
+                            float* part);
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
                       const float* bound);
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound);

@@ -462,7 +462,10 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         # X^T X and the weights (vp3d_expand_bwd_s16) -- no reduce / finalize / apply passes over (dh, y) for this layer
         spec0 = plan.convs[0]
         rows0 = L[0].x_rows is not None
-        g0 = S.act_mask(dh, bounds[0], L[0].bits, p if L[0].drop is not None else 0.0, transposed=not rows0)
+        p0 = p if L[0].drop is not None else 0.0
+        fused_p = (not rows0) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"     # vp3d_expand_bwd_p_s16: G never stored
+        g0 = None if fused_p else S.act_mask(dh, bounds[0], L[0].bits, p0, transposed=not rows0)
+        part0 = S.expand_p_from_go(dh, bounds[0], L[0].bits, p0, L[0].x_t) if fused_p else None
         if gram_ev is not None:
             main.wait_event(gram_ev)
         o_w, o_g, o_bt = view(convs[0].weight), view(bns[0].weight), view(bns[0].bias)
@@ -470,7 +473,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             o_g = o_bt = None
         m0 = dh.shape[0] * dh.shape[1]
         dw0, dg0, db0 = S.expand_bwd(g0, L[0].x_rows if rows0 else L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in,
-                                     spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt)
+                                     spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt, partials=part0)
         grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)
     else:
         dy0, dy0_t = act_bwd(0, dh)

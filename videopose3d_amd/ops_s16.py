@@ -291,12 +291,34 @@ def expand_rows_form(c_out: int, kpad: int) -> bool:
     return os.environ.get("VP3D_EXPAND_ROWS", "0") == "1" and kpad == 128 and c_out % 256 == 0
 
 
-def expand_bwd(g: S16, x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
-               taps: int, one_col: int, rows: bool, out_dw=None, out_dgamma=None, out_dbeta=None):
+def expand_p_from_go(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float, x_t: S16) -> Tuple[torch.Tensor, int]:
+    """Raw partials [n][C][kpad] of P = G^T X straight from the incoming gradient go [B, T, C] and the activation bits
+    (vp3d_expand_bwd_p_s16: G = go * keep * [bn(y) > 0] is formed in registers, go is read once).  x_t: transposed S16 X."""
+    ops._chk(go, "go")
+    b, t, c = go.shape
+    m = b * t
+    kpad, ld_t = x_t.data.shape
+    n = C.c_int32(0)
+    L = _lib.lib()
+    check(L.vp3d_expand_bwd_p_s16(ops._stream(), m, c, kpad, None, None, None, float(p), None, ld_t, None, None, C.byref(n)),
+          "vp3d_expand_bwd_p_s16(query)")
+    ws = torch.empty((n.value, c, kpad), dtype=torch.float32, device=go.device)
+    ops._timed_call("tconv_wgrad", 2.0 * m * c * kpad, L.vp3d_expand_bwd_p_s16, ops._stream(), m, c, kpad, go.data_ptr(),
+                    go_bound.data_ptr(), act_bits.data_ptr(), float(p), x_t.data.data_ptr(), ld_t, x_t.bound_ptr(), ws.data_ptr(),
+                    C.byref(n), nbytes=4.0 * (go.numel() + x_t.data.numel() + c * kpad) + act_bits.numel(),
+                    shape=(c, kpad, m, "exb", n.value, 1))
+    return ws, n.value
+
+
+def expand_bwd(g: Optional[S16], x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
+               taps: int, one_col: int, rows: bool, out_dw=None, out_dgamma=None, out_dbeta=None, partials=None):
     """(dW [C][c_in][taps], dgamma, dbeta) of the expand layer from G^T X, X^T X and the packed weight (see include/vp3d.h).
     rows: g [.., C] and x [.., kpad] are S16 rows (vp3d_wgrad_rows_s16); else both are transposed operands [C or kpad][Mp]."""
-    dev = g.data.device
-    if rows:
+    dev = x.data.device
+    if partials is not None:                          # (ws, splits) from expand_p_from_go
+        ws, splits = partials
+        c, kpad = ws.shape[1], ws.shape[2]
+    elif rows:
         c, kpad = g.data.shape[-1], x.data.shape[-1]
         assert expand_rows_form(c, kpad) and g.data.numel() // c == m_rows and x.data.numel() // kpad == m_rows
         splits = max(1, min(64, ((m_rows + 31) // 32) // 6, 512 // (c // 256)))
