@@ -308,10 +308,12 @@ int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float
 /* P = G^T X without G: the raw partials [*nparts][C][kpad] of P straight from the incoming gradient go (fp32 rows [M][C]), the
  * forward's activation bits and the transposed S16 copy x_t [kpad][ld_t] of X (zero for columns >= M).  Replaces
  * vp3d_act_mask_s16 + the split-K GEMM over G (go is read once, G never exists); vp3d_expand_bwd_s16 takes the partials
- * (splits = *nparts).  Call with partials == NULL to query *nparts. */
+ * (splits = *nparts).  gram_partials != NULL: the workgroups of the first column slice also accumulate the raw partials
+ * [*nparts][kpad][kpad] of S = X^T X (the X^T fragments they hold are both of its operands: no extra loads; vp3d_sum_slices
+ * folds them) -- the separate split-K GEMM for S is not needed then.  Call with partials == NULL to query *nparts. */
 int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
                           const uint8_t* act_bits, float p, const void* x_t, int64_t ld_t, const float* x_bound, float* partials,
-                          int32_t* nparts);
+                          float* gram_partials, int32_t* nparts);
 int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
                         int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
                         const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw);

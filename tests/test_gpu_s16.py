@@ -556,8 +556,11 @@ def test_expand_backward_p_from_go_equals_masked_gemm(shape):
     gb = S.amax(go)
     xb = S.amax(x)
     _, x_t = S.split_t(x, xb, want_rows=False, want_t=True)
-    ws, n = S.expand_p_from_go(go, gb, bits, p, x_t)
+    ws, n, gram = S.expand_p_from_go(go, gb, bits, p, x_t, want_gram=True)
     got = ws.double().sum(0)
+    xx = x.double().t() @ x.double()                     # X^T X rides along in the same launch
+    assert float(((gram - xx).abs() / (x.double().abs().t() @ x.double().abs() + 1e-30)).max()) < 2e-6
+    assert float((gram - S.gram(x_t)).abs().max() / xx.abs().max()) < 2e-6
     keep = torch.from_numpy(unpack_act_bits(bits, m, c)).to(DEV)
     G = go.view(m, c).double() * keep / (1.0 - p)
     ref = G.t() @ x.double()

@@ -93,3 +93,4 @@ print("dedicated kernel: statistics pass %6.1f us | activation pass p=0.25 %6.1f
 print("P from go + bits (fused kernel)   %7.1f us | + post %7.1f us" % (
     timeit(lambda: S.expand_p_from_go(go, gb, bits, 0.25, x_t)),
     timeit(lambda: S.expand_bwd(None, x_t, gram, wp, coef, m, 34, 3, 102, False, partials=S.expand_p_from_go(go, gb, bits, 0.25, x_t)))))
+print("P from go + bits WITH X^T X riding along (+ slice sum) %7.1f us" % timeit(lambda: S.expand_p_from_go(go, gb, bits, 0.25, x_t, want_gram=True)))

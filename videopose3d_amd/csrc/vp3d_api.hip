@@ -284,7 +284,7 @@ int vp3d_expand_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t N, int32_t kpad
 
 int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
                           const uint8_t* act_bits, float p, const void* x_t, int64_t ld_t, const float* x_bound, float* partials,
-                          int32_t* nparts) {
+                          float* gram_partials, int32_t* nparts) {
   VP3D_REQUIRE(M > 0 && C > 0 && C % 64 == 0 && kpad >= 32 && kpad <= 128 && kpad % 32 == 0 && nparts && p >= 0.f && p < 1.f &&
                    M * C * 4 < ((int64_t)1 << 31) && ld_t >= M && ld_t % 64 == 0 && kpad * ld_t * 4 < ((int64_t)1 << 31),
                "expand_bwd_p_s16: bad argument (C %% 64 == 0, kpad 32..128, ld_t %% 64 == 0, go below 2 GiB)");
@@ -293,7 +293,7 @@ int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kp
   VP3D_REQUIRE(go && go_bound && act_bits && x_t && x_bound && aligned16(x_t) && aligned16(partials),
                "expand_bwd_p_s16: null or unaligned pointer");
   return launch_expand_bwd_p_s16((hipStream_t)stream, M, C, kpad, go, go_bound, act_bits, p, (const float*)x_t, ld_t, x_bound,
-                                 *nparts, partials);
+                                 *nparts, partials, gram_partials);
 }
 
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,

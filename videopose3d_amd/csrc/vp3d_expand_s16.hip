@@ -304,12 +304,14 @@ struct ExpandBwdArgs {
   const float* xt;             // S16 transposed X: [kpad][ld_t]
   const float* x_bound;
   float* part;                 // [groups][C][kpad]
+  float* gram_part;            // [groups][kpad][kpad] partials of X^T X (slice 0 only), or NULL
   int32_t M, C, kpad, ld_t;
   uint32_t go_bytes, bits_bytes, xt_bytes;
   int32_t n_slices, groups, rows_per;     // rows_per % 64 == 0
   float inv_keep;
 };
 
+template <int NJ>
 __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[EB_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -321,7 +323,6 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
   const int c0w = slice * (EB_NW * 32) + w * 32;         // first channel of this wave
   const int row_begin = group * p.rows_per, row_end = min(p.M, row_begin + p.rows_per);
   const int n_stage = (max(0, row_end - row_begin) + EB_SLAB - 1) / EB_SLAB;
-  const int nj = p.kpad / 32;
 
   __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)p.go, 0, p.go_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bits, 0, p.bits_bytes, 0x00020000);
@@ -356,11 +357,21 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
     }
   };
 
-  f32x16 acc[4];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // X^T X rides along on the column slice 0 workgroups: the B fragments of X^T ARE its operands (both of them: a fragment of
+  // rows 32 i .. 32 i + 31 is the same registers as A or as B), so the NJ x NJ blocks cost MFMAs only -- wave w takes blocks
+  // (i, j) = (b / NJ, b % NJ) for b = w, w + 8, ...
+  constexpr int NG = (NJ * NJ + EB_NW - 1) / EB_NW;
+  const bool do_gram = p.gram_part != nullptr && slice == 0;      // workgroup-uniform
+  f32x16 accg[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accg[u][r] = 0.f;
 
   const float g_bound = s16_load_bound(p.go_bound) * p.inv_keep;
   const int e_g = s16_exp_for_bound(g_bound);
@@ -368,6 +379,14 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
   const int b_row = cl * EB_ROWB, swz = cl & 15;
 
   auto k_step = [&](int slot, int ks, const char* sB) {
+    // B fragments of all NJ column blocks first (the LDS latency runs under the A-fragment arithmetic below)
+    f16x8 bh[NJ], bl[NJ];
+    const int co = ((4 * ks + 2 * h) ^ swz) * 16;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      bh[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + co);
+      bl[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + (co ^ 16));
+    }
     // A fragment: G[rows 8 h + i][channel cl] = go * keep-scale * bit, split into hi + lo halves
     f16x8 ah, al;
 #pragma unroll
@@ -377,15 +396,30 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
       ah[i] = hh;
       al[i] = (_Float16)(g - (float)hh);
     }
-    const int co = ((4 * ks + 2 * h) ^ swz) * 16;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < nj) {
-        const f16x8 bh = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + co);
-        const f16x8 bl = *reinterpret_cast<const f16x8*>(sB + j * 32 * EB_ROWB + b_row + (co ^ 16));
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+    if (do_gram) {
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int blk = w + u * EB_NW;                 // wave-uniform
+        if (blk < NJ * NJ) {
+          const int gi = blk / NJ, gj = blk % NJ;
+          f16x8 xh = bh[0], xl = bl[0], yh = bh[0], yl = bl[0];
+#pragma unroll
+          for (int j = 1; j < NJ; ++j) {               // (register selects on wave-uniform indices)
+            xh = gi == j ? bh[j] : xh;
+            xl = gi == j ? bl[j] : xl;
+            yh = gj == j ? bh[j] : yh;
+            yl = gj == j ? bl[j] : yl;
+          }
+          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, accg[u], 0, 0, 0);
+          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, accg[u], 0, 0, 0);
+          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, accg[u], 0, 0, 0);
+        }
       }
     }
   };
@@ -416,15 +450,30 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
   ex_wait_vmcnt<0>();
 
   // ---- partial P of this row group: part[group][c][j], scaled ------------------------------------------------------------
-  const float scale = s16_pow2(e_g + s16_exp_of(p.x_bound));
+  const int e_x = s16_exp_of(p.x_bound);
+  const float scale = s16_pow2(e_g + e_x);
   float* out = p.part + (int64_t)group * p.C * p.kpad;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j < nj) {
+  for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int c = c0w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (c < p.C) out[(int64_t)c * p.kpad + j * 32 + cl] = acc[j][reg] * scale;
+    for (int reg = 0; reg < 16; ++reg) {
+      const int c = c0w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (c < p.C) out[(int64_t)c * p.kpad + j * 32 + cl] = acc[j][reg] * scale;
+    }
+  }
+  if (do_gram) {
+    const float sg = s16_pow2(2 * e_x);
+    float* gout = p.gram_part + (int64_t)group * p.kpad * p.kpad;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int blk = w + u * EB_NW;
+      if (blk < NJ * NJ) {
+        const int gi = blk / NJ, gj = blk % NJ;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = gi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          gout[(int64_t)r * p.kpad + gj * 32 + cl] = accg[u][reg] * sg;
+        }
       }
     }
   }
@@ -470,8 +519,9 @@ int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, con
 namespace vp3d {
 int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
                             const uint8_t* bits, float p, const float* xt, int64_t ld_t, const float* x_bound, int32_t groups,
-                            float* part) {
+                            float* part, float* gram_part) {
   ExpandBwdArgs a;
+  a.gram_part = gram_part;
   a.go = go;
   a.go_bound = go_bound;
   a.bits = bits;
@@ -490,7 +540,13 @@ int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, c
   const int64_t slabs = (M + EB_SLAB - 1) / EB_SLAB;
   a.rows_per = (int32_t)((slabs + groups - 1) / groups) * EB_SLAB;
   a.inv_keep = 1.0f / (1.0f - p);
-  hipLaunchKernelGGL(k_expand_bwd_p_s16, dim3(a.n_slices * groups), dim3(EB_NT), 0, s, a);
+  const dim3 grid(a.n_slices * groups), block(EB_NT);
+  switch (kpad / 32) {
+    case 1: hipLaunchKernelGGL(k_expand_bwd_p_s16<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_expand_bwd_p_s16<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_expand_bwd_p_s16<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_expand_bwd_p_s16<4>, grid, block, 0, s, a); break;
+  }
   return check_launch("expand_bwd_p_s16");
 }
 

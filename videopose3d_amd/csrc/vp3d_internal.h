@@ -138,7 +138,7 @@ int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, con
 int expand_bwd_groups(int64_t M, int32_t C);
 int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
                             const uint8_t* bits, float p, const float* xt, int64_t ld_t, const float* x_bound, int32_t groups,
-                            float* part);
+                            float* part, float* gram_part);
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
                       const float* bound);
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound);

@@ -807,24 +807,38 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          double inv_m, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                          float* __restrict__ dw) {
-  __shared__ float w_s[8][128];
+  extern __shared__ double s_lds[];                    // S rows 0 .. kv-1 ([kv][kpad] doubles), then the block's 8 weight rows
+  float* w_s = reinterpret_cast<float*>(s_lds + (size_t)kv * kpad);
   const int cl = threadIdx.x >> 5, jq = threadIdx.x & 31, j0 = jq * 4;
   const int c = blockIdx.x * 8 + cl;
   const bool live = c < C && j0 < kpad;
+  // S = X^T X into LDS (the loop below reads every row of it for every channel: from L2 that was 17 dependent batches)
+  {
+    const int n2 = kv * kpad / 2;                      // double2 units
+    const double2* src = reinterpret_cast<const double2*>(S);
+    double2* dst = reinterpret_cast<double2*>(s_lds);
+    for (int i = threadIdx.x; i < n2; i += 256) dst[i] = src[i];
+  }
   double P[4] = {0.0, 0.0, 0.0, 0.0};
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   if (live) {
-#pragma unroll 8
-    for (int s = 0; s < splits; ++s) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(pws + ((int64_t)s * C + c) * kpad + j0);
+    // the slices in slice order, 16 loads in flight
+    for (int s0 = 0; s0 < splits; s0 += 16) {
+      f32x4 v[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) P[e] += (double)v[e];
+      for (int u = 0; u < 16; ++u)
+        v[u] = s0 + u < splits ? *reinterpret_cast<const f32x4*>(pws + ((int64_t)(s0 + u) * C + c) * kpad + j0)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[e] += (double)v[u][e];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) w4[e] = j0 + e < kv ? wp[(int64_t)c * kpad + j0 + e] : 0.f;
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) w_s[cl][(j0 + e) & 127] = w4[e];
+  for (int e = 0; e < 4; ++e) w_s[cl * 128 + ((j0 + e) & 127)] = w4[e];
   // per-channel sums over the 32 lanes of a channel (half a wave): sum g*y and the bias column
   double sgy = 0.0, db = 0.0;
 #pragma unroll
@@ -848,10 +862,10 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
   const double B = -A * db * inv_m, Cx = -A * is * dg * inv_m;
   double T[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 6
-  for (int i = 0; i < kv; ++i) {                       // (unrolled: the loads of several rows of S in flight, not one)
-    const double wi = (double)w_s[cl][i];
-    const double2 s01 = *reinterpret_cast<const double2*>(S + (int64_t)i * kpad + j0);
-    const double2 s23 = *reinterpret_cast<const double2*>(S + (int64_t)i * kpad + j0 + 2);
+  for (int i = 0; i < kv; ++i) {
+    const double wi = (double)w_s[cl * 128 + i];
+    const double2 s01 = *reinterpret_cast<const double2*>(s_lds + (size_t)i * kpad + j0);
+    const double2 s23 = *reinterpret_cast<const double2*>(s_lds + (size_t)i * kpad + j0 + 2);
     T[0] += wi * s01.x;
     T[1] += wi * s01.y;
     T[2] += wi * s23.x;
@@ -861,7 +875,7 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
   for (int e = 0; e < 4; ++e) {
     const int j = j0 + e;
     if (j >= kv) continue;
-    const double sx = S[(int64_t)j * kpad + one];
+    const double sx = s_lds[(size_t)j * kpad + one];
     const double v = A * P[e] + B * sx + Cx * (T[e] - mu * sx);
     const int k = j / c_in, ci = j - k * c_in;
     dw[((int64_t)c * c_in + ci) * taps + k] = (float)v;
@@ -991,7 +1005,14 @@ int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t t
                    M > 0 && splits > 0 && p_partials && gram && w_packed && scale && mean && invstd && dgamma && dbeta && dw &&
                    aligned16(p_partials),
                "expand_bwd_s16: bad argument (kpad <= 128, a spare padding column for the bias)");
-  hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
+  const size_t lds = (size_t)kv * kpad * sizeof(double) + 8 * 128 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {                                     // > 64 KiB of dynamic LDS needs the opt-in
+    if (hipFuncSetAttribute((const void*)k_expand_bwd_post, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
                      splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw);
   return check_launch("expand_bwd_s16");
 }

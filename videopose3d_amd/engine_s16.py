@@ -329,7 +329,9 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
 
     # X^T X of the expand layer's input (its no-dy backward, below): a small GEMM with nothing upstream -> second stream
     gram_xx, gram_ev = None, None
-    if L[0].one_col >= 0:
+    # (with the dedicated kernel X^T X rides along in the P = G^T X launch at the end of backward: no GEMM of its own)
+    fused_p = L[0].one_col >= 0 and L[0].x_rows is None and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"
+    if L[0].one_col >= 0 and not fused_p:
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -463,9 +465,12 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         spec0 = plan.convs[0]
         rows0 = L[0].x_rows is not None
         p0 = p if L[0].drop is not None else 0.0
-        fused_p = (not rows0) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"     # vp3d_expand_bwd_p_s16: G never stored
-        g0 = None if fused_p else S.act_mask(dh, bounds[0], L[0].bits, p0, transposed=not rows0)
-        part0 = S.expand_p_from_go(dh, bounds[0], L[0].bits, p0, L[0].x_t) if fused_p else None
+        g0, part0 = None, None
+        if fused_p:                                  # vp3d_expand_bwd_p_s16: G = go * keep * bits is never stored
+            ws0, n0, gram_xx = S.expand_p_from_go(dh, bounds[0], L[0].bits, p0, L[0].x_t, want_gram=True)
+            part0 = (ws0, n0)
+        else:
+            g0 = S.act_mask(dh, bounds[0], L[0].bits, p0, transposed=not rows0)
         if gram_ev is not None:
             main.wait_event(gram_ev)
         o_w, o_g, o_bt = view(convs[0].weight), view(bns[0].weight), view(bns[0].bias)

@@ -291,23 +291,30 @@ def expand_rows_form(c_out: int, kpad: int) -> bool:
     return os.environ.get("VP3D_EXPAND_ROWS", "0") == "1" and kpad == 128 and c_out % 256 == 0
 
 
-def expand_p_from_go(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float, x_t: S16) -> Tuple[torch.Tensor, int]:
+def expand_p_from_go(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float, x_t: S16, want_gram: bool = False):
     """Raw partials [n][C][kpad] of P = G^T X straight from the incoming gradient go [B, T, C] and the activation bits
-    (vp3d_expand_bwd_p_s16: G = go * keep * [bn(y) > 0] is formed in registers, go is read once).  x_t: transposed S16 X."""
+    (vp3d_expand_bwd_p_s16: G = go * keep * [bn(y) > 0] is formed in registers, go is read once).  x_t: transposed S16 X.
+    Returns (partials, n) or, with want_gram, (partials, n, X^T X as doubles [kpad][kpad]) -- X^T X rides along in the same
+    launch (the X^T fragments are its operands) and is folded by vp3d_sum_slices."""
     ops._chk(go, "go")
     b, t, c = go.shape
     m = b * t
     kpad, ld_t = x_t.data.shape
     n = C.c_int32(0)
     L = _lib.lib()
-    check(L.vp3d_expand_bwd_p_s16(ops._stream(), m, c, kpad, None, None, None, float(p), None, ld_t, None, None, C.byref(n)),
+    check(L.vp3d_expand_bwd_p_s16(ops._stream(), m, c, kpad, None, None, None, float(p), None, ld_t, None, None, None, C.byref(n)),
           "vp3d_expand_bwd_p_s16(query)")
     ws = torch.empty((n.value, c, kpad), dtype=torch.float32, device=go.device)
+    gws = torch.empty((n.value, kpad, kpad), dtype=torch.float32, device=go.device) if want_gram else None
     ops._timed_call("tconv_wgrad", 2.0 * m * c * kpad, L.vp3d_expand_bwd_p_s16, ops._stream(), m, c, kpad, go.data_ptr(),
                     go_bound.data_ptr(), act_bits.data_ptr(), float(p), x_t.data.data_ptr(), ld_t, x_t.bound_ptr(), ws.data_ptr(),
-                    C.byref(n), nbytes=4.0 * (go.numel() + x_t.data.numel() + c * kpad) + act_bits.numel(),
+                    ops._p(gws), C.byref(n), nbytes=4.0 * (go.numel() + x_t.data.numel() + c * kpad) + act_bits.numel(),
                     shape=(c, kpad, m, "exb", n.value, 1))
-    return ws, n.value
+    if not want_gram:
+        return ws, n.value
+    gram_xx = torch.empty((kpad, kpad), dtype=torch.float64, device=go.device)
+    check(L.vp3d_sum_slices(ops._stream(), kpad * kpad, n.value, gws.data_ptr(), gram_xx.data_ptr()), "vp3d_sum_slices")
+    return ws, n.value, gram_xx
 
 
 def expand_bwd(g: Optional[S16], x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
