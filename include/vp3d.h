@@ -298,7 +298,7 @@ int vp3d_gather_t_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
  *                         the bound go_bound/(1-p), published in g_bound (32 floats, zeroed by the caller)
  *   vp3d_wgrad_rows_s16 / vp3d_tconv_nt_s16   raw partials of  P = G^T X [C][kpad]  (from the rows when kpad == 128,
  *                         else from the transposed copies) and of  S = X^T X [kpad][kpad]  (K = rows)
- *   vp3d_sum_slices       S as doubles (slice order)
+ *   vp3d_sum_slices       S as doubles (fixed summation order)
  *   vp3d_expand_bwd_s16   dbeta = P[:, one_col], dgamma = invstd (<W, P> - mean dbeta), and
  *                         dW = A P + B sX + Cx (W S - mean sX)  (A = scale, B = -A dbeta/M, Cx = -A invstd dgamma/M,
  *                         sX = S[:, one_col]) un-packed to Conv1d.weight layout [C][c_in][taps]. */

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(EX_NT, 3) k_expand_fwd_s16(const ExpandArgs p)
 // (136 + 118 us).  Here a wave owns 32 channels: it loads ITS column of go for 16 rows at a time (8 rows per lane half: exactly
 // the MFMA A fragment, 128-byte runs per load), masks, scales and splits in registers, and multiplies with the B fragments
 // of X^T (the transposed S16 copy the forward already keeps for X^T X; 64-column slabs through a 2-deep LDS ring).  go is
-// read once; the kernel is bound by that read.  Register ring of 4 k-steps of loads in flight per wave (all VMEM operations
+// read once; the kernel is bound by that read.  Register ring of 4 k-steps of loads in flight per wave (9 loads each: 8 rows of go, one bit word that the lanes share by ds_bpermute) (all VMEM operations
 // of a wave are loads, so the counted vmcnt waits are exact).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int EB_NW = 8, EB_NT = EB_NW * 64;
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
 
   // ---- register ring: k-step q -> slot q % 4: 8 rows of go for this lane's channel + their activation-bit words ----------
   float gv[4][8];
-  uint32_t bw[4][8];
+  uint32_t bw[4];                                        // the bit word of row 8 h + (cl & 7): lanes 0..7 of a half hold its 8 rows
   const bool c_ok = c0w + cl < p.C;
   const int g_col = (c0w + cl) * 4;
   const int64_t bits_base = (int64_t)(c0w >> 6) * p.M * 8 + ((c0w & 63) >> 3);
@@ -340,8 +340,9 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
       const int m = row_begin + q * 16 + 8 * h + i;
       const bool ok = m < row_end && c_ok;
       gv[slot][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, ok ? (int)((int64_t)m * p.C * 4 + g_col) : kOobOff, 0, 0));
-      bw[slot][i] = __builtin_amdgcn_raw_buffer_load_b32(rsB, ok ? (int)(bits_base + (int64_t)m * 8) : kOobOff, 0, 0);
     }
+    const int mb = row_begin + q * 16 + 8 * h + (cl & 7);
+    bw[slot] = __builtin_amdgcn_raw_buffer_load_b32(rsB, (mb < row_end && c0w < p.C) ? (int)(bits_base + (int64_t)mb * 8) : kOobOff, 0, 0);
   };
   // X^T slab S -> buffer S & 1: piece pc = 4 rows x 256 B; lane's 16 bytes: row 4 pc + (lane >> 4), chunk position lane & 15
   auto issue_slab = [&](int S) {
@@ -391,7 +392,8 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
     f16x8 ah, al;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float g = ((bw[slot][i] >> cl) & 1u) ? gv[slot][i] * g_scale : 0.f;
+      const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((h * 32 + i) * 4, (int)bw[slot]);      // row 8 h + i
+      const float g = ((word >> cl) & 1u) ? gv[slot][i] * g_scale : 0.f;
       const _Float16 hh = (_Float16)g;
       ah[i] = hh;
       al[i] = (_Float16)(g - (float)hh);
@@ -403,24 +405,22 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
     if (do_gram) {
-#pragma unroll
-      for (int u = 0; u < NG; ++u) {
-        const int blk = w + u * EB_NW;                 // wave-uniform
-        if (blk < NJ * NJ) {
-          const int gi = blk / NJ, gj = blk % NJ;
-          f16x8 xh = bh[0], xl = bl[0], yh = bh[0], yl = bl[0];
-#pragma unroll
-          for (int j = 1; j < NJ; ++j) {               // (register selects on wave-uniform indices)
-            xh = gi == j ? bh[j] : xh;
-            xl = gi == j ? bl[j] : xl;
-            yh = gj == j ? bh[j] : yh;
-            yl = gj == j ? bl[j] : yl;
-          }
-          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, accg[u], 0, 0, 0);
-          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, accg[u], 0, 0, 0);
-          accg[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, accg[u], 0, 0, 0);
-        }
+      // (one case per wave: the fragment indices are compile-time constants -- selecting registers by a run-time index costs
+      //  a v_cndmask per register and candidate: +50 us on the launch)
+#define VP3D_GRAM_BLK(U, BLK)                                                                               \
+      if constexpr ((BLK) < NJ * NJ) {                                                                       \
+        constexpr int gi = (BLK) / NJ, gj = (BLK) % NJ;                                                      \
+        accg[U] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[gi], bh[gj], accg[U], 0, 0, 0);                  \
+        accg[U] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[gi], bl[gj], accg[U], 0, 0, 0);                  \
+        accg[U] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[gi], bh[gj], accg[U], 0, 0, 0);                  \
       }
+#define VP3D_GRAM_CASE(W) case W: VP3D_GRAM_BLK(0, W) if constexpr (NG > 1) { VP3D_GRAM_BLK(NG - 1, W + 8) } break;
+      switch (w) {
+        VP3D_GRAM_CASE(0) VP3D_GRAM_CASE(1) VP3D_GRAM_CASE(2) VP3D_GRAM_CASE(3)
+        VP3D_GRAM_CASE(4) VP3D_GRAM_CASE(5) VP3D_GRAM_CASE(6) VP3D_GRAM_CASE(7)
+      }
+#undef VP3D_GRAM_CASE
+#undef VP3D_GRAM_BLK
     }
   };
 
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
     for (int S = 0; S < n_stage; ++S) {
       // oldest outstanding first: [slab S+... issued after the previous barrier], loads q+1, q+2: the loads of k-step 4 S (and
       // the slab S, older) have landed when at most 32 newer loads are outstanding
-      ex_wait_vmcnt<32>();
+      ex_wait_vmcnt<18>();
       __builtin_amdgcn_s_barrier();                  // slab S visible; everybody is done with slab S-1
       if (S + 1 < n_stage) issue_slab(S + 1);
       const char* sB = smem + (S & 1) * EB_STAGE_B;

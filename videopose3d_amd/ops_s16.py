@@ -181,17 +181,16 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
     m = b * t
     L = _lib.lib()
     if stats is not None:
-        with ops._Timed("tconv_fwd", 2.0 * m * n * kpad, 4.0 * (xd.numel() + wd.numel()), (m, n, kpad, "ex", 1, 1)):
-            check(L.vp3d_expand_fwd_s16(ops._stream(), m, n, kpad, xd.data_ptr(), x.bound_ptr(), wd.data_ptr(), wt.bound_ptr(),
-                                        stats[0].data_ptr(), stats[1].data_ptr(), None, None, None, None, None, None),
-                  "vp3d_expand_fwd_s16(statistics)")
+        ops._timed_call("tconv_fwd", 2.0 * m * n * kpad, L.vp3d_expand_fwd_s16, ops._stream(), m, n, kpad, xd.data_ptr(),
+                        x.bound_ptr(), wd.data_ptr(), wt.bound_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), None, None, None, None,
+                        None, None, nbytes=4.0 * (xd.numel() + wd.numel()), shape=(m, n, kpad, "ex", 1, 1))
         return None
     coef, drop, out_bound, act_bits = act
     out = torch.empty((b, t, n), dtype=torch.float32, device=xd.device)
-    with ops._Timed("tconv_fwd", 2.0 * m * n * kpad, 4.0 * (xd.numel() + wd.numel() + out.numel()), (m, n, kpad, "ex", 1, 1)):
-        check(L.vp3d_expand_fwd_s16(ops._stream(), m, n, kpad, xd.data_ptr(), x.bound_ptr(), wd.data_ptr(), wt.bound_ptr(), None,
-                                    None, coef[0].data_ptr(), coef[1].data_ptr(), C.byref(drop) if drop is not None else None,
-                                    out_bound.data_ptr(), out.data_ptr(), ops._p(act_bits)), "vp3d_expand_fwd_s16(activation)")
+    ops._timed_call("tconv_fwd", 2.0 * m * n * kpad, L.vp3d_expand_fwd_s16, ops._stream(), m, n, kpad, xd.data_ptr(), x.bound_ptr(),
+                    wd.data_ptr(), wt.bound_ptr(), None, None, coef[0].data_ptr(), coef[1].data_ptr(),
+                    C.byref(drop) if drop is not None else None, out_bound.data_ptr(), out.data_ptr(), ops._p(act_bits),
+                    nbytes=4.0 * (xd.numel() + wd.numel() + out.numel()), shape=(m, n, kpad, "ex", 1, 1))
     return S16(out, out_bound)
 
 
