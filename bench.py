@@ -67,7 +67,45 @@ FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_ro
                   "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
+STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r02_step_table.json")}
+
+
 def pmc_traffic(family, math):
+    """Per-launch table first (profiles/r02_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
+    WRITE_SIZE): the family's traffic is the mean over ITS launches, comparable with `algorithmic_bytes`; else the
+    per-kernel-template means of the older profile."""
+    path = STEP_TABLE_JSON.get(math)
+    if path:
+        try:
+            with open(path) as f:
+                rows = [r for r in json.load(f)["launches"] if r["family"] == family and r["fetch_bytes"] is not None]
+            if rows:
+                return (sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows),
+                        "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included), mean over the "
+                        "%d %s launches of one step in %s (algorithmic mean of the same launches: %.1f MB)"
+                        % (len(rows), family, os.path.relpath(path, ROOT), sum(r["algorithmic_bytes"] for r in rows) / len(rows) / 1e6))
+        except (OSError, ValueError, KeyError):
+            pass
+    return _pmc_traffic_templates(family, math)
+
+
+def pmc_traffic_of_cfg(cfg, math):
+    """The same per-launch table, the launches served by one kernel (tile configuration `cfg`)."""
+    path = STEP_TABLE_JSON.get(math)
+    try:
+        with open(path) as f:
+            rows = [r for r in json.load(f)["launches"] if r["cfg"] == cfg and r["fetch_bytes"] is not None]
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None
+    if not rows:
+        return None, None
+    return (sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows),
+            "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included), mean over the %d launches of "
+            "this kernel in one step, %s (algorithmic mean of the same launches: %.1f MB)"
+            % (len(rows), os.path.relpath(path, ROOT), sum(r["algorithmic_bytes"] for r in rows) / len(rows) / 1e6))
+
+
+def _pmc_traffic_templates(family, math):
     """HBM-side bytes per launch of a GEMM family from the committed rocprofv3 PMC passes of THIS command
     (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
     gfx950 correction of MI355X_MICROARCH.md; tools/pmc_traffic.py).  PMC counters cannot be read from inside the
@@ -132,13 +170,14 @@ def cpu_baseline(dev, budget_s=4.0):
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     gen = torch.Generator().manual_seed(1234)
 
-    def run(bsz, iters):
+    def run(bsz, iters, dropout=0.25):
+        """dropout 0.25 = the workload of the GPU headline (timed); 0.0 for the MPJPE comparison (torch's mask stream is not ours)"""
         x, tgt = synthetic_batch(bsz, gen)
         ts, out = [], None
         for _ in range(iters):
             sdi = {k: v.clone() for k, v in sd.items()}
             t0 = time.perf_counter()
-            _, out, _ = T.train_step(sdi, x, tgt, FW, kind="strided")
+            _, out, _ = T.train_step(sdi, x, tgt, FW, kind="strided", dropout=dropout)
             ts.append(time.perf_counter() - t0)
         return x, out, ts
 
@@ -159,8 +198,9 @@ def cpu_baseline(dev, budget_s=4.0):
     torch.set_num_threads(best_t)
     _, _, ts = run(32, 2)                                   # warm-up + calibration at the chosen thread count
     bsz = int(min(B, max(32, round(32 * budget_s / ts[-1] / 32) * 32)))
-    x, y_cpu, ts = run(bsz, 4)
+    _, _, ts = run(bsz, 4)
     dt = float(np.mean(ts[1:]))
+    x, y_cpu, _ = run(bsz, 1, dropout=0.0)               # (un-timed) the deterministic forward both paths can be compared on
     with torch.no_grad():
         y_gpu = m(x.to(dev)).cpu()
     err = float(mpjpe(y_gpu, y_cpu))
@@ -171,7 +211,7 @@ def cpu_baseline(dev, budget_s=4.0):
         cpu_name = "?"
     base = dict(value=bsz / dt, unit="frames/s", cores=int(torch.get_num_threads()), kind="port",
                 sample="oracle/torch_cpu_path.py (ATen/oneDNN conv1d/batch_norm/relu + autograd = what the reference "
-                       "runs on CPU), TemporalModelOptimized1f arc 3,3,3,3,3 C=1024 train fwd+bwd (dropout off), "
+                       "runs on CPU), TemporalModelOptimized1f arc 3,3,3,3,3 C=1024 train fwd+bwd, BN statistics, dropout 0.25 (the headline's workload), "
                        "B=%d x 243 frames, 3 timed iters after 1 warm-up, %.2f s/iter, %d threads (fastest of a 8,16,.. sweep); "
                        "host: %d logical CPUs (%d usable by this container), %s"
                        % (bsz, dt, best_t, os.cpu_count() or 0, cores, cpu_name))
@@ -330,8 +370,35 @@ def instrumented(step, ops, n_prof, math):
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     alg = kernels[dom]["tflops"]
     traffic, traffic_note = pmc_traffic(dom, math)
+    by_kernel = None
     if math == "f16x3":
-        kname = "k_nt_s16<*> (vp3d_tconv_nt_s16: %s form)" % dom
+        # The DOMINANT KERNEL of the step: the launches grouped by the kernel that served them (tile configuration), not by
+        # GEMM form -- one template serves forward and dgrad launches alike
+        names = {22: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>> (256x256 tile, 8 waves of 128x64; forward + dgrad launches)",
+                 20: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>> (128x128 tile, 4 waves, 2 workgroups per CU)",
+                 "tn": "k_tn_s16<2> (rows-form weight gradient, 256x256 tile, transpose reads)",
+                 "ex": "k_expand_fwd_s16 (expand layer forward: statistics + activation pass)",
+                 "exb": "k_expand_bwd_p_s16 (expand layer backward: P = G^T X from go + bits)"}
+        grp = {}
+        for r in per_launch:
+            g = grp.setdefault(r.get("cfg"), dict(us=0.0, flops=0.0, mb=0.0, n=0.0))
+            g["us"] += r["us"] * r["calls_per_step"]
+            g["flops"] += r["tflops"] * r["us"] * r["calls_per_step"]        # TFLOP/s x us = MFLOP
+            g["mb"] += r["algorithmic_MB"] * r["calls_per_step"]
+            g["n"] += r["calls_per_step"]
+        by_kernel = {str(names.get(k, k)): dict(launches_per_step=v["n"], us_per_step=v["us"], tflops=v["flops"] / v["us"],
+                                                 frac_of_peak=v["flops"] / v["us"] / peak_alg,
+                                                 algorithmic_MB_per_launch=v["mb"] / v["n"])
+                     for k, v in grp.items() if v["us"] > 0}
+        kdom = max(grp, key=lambda k: grp[k]["us"])
+        kname = str(names.get(kdom, kdom))
+        alg = grp[kdom]["flops"] / grp[kdom]["us"]
+        kt = pmc_traffic_of_cfg(kdom, math)
+        if kt[0] is not None:
+            traffic, traffic_note = kt
+        kernels[dom] = dict(kernels[dom])
+        dom_launch = dict(calls_per_step=grp[kdom]["n"], avg_launch_ms=grp[kdom]["us"] / grp[kdom]["n"] / 1e3,
+                          algorithmic_bytes_per_launch=grp[kdom]["mb"] / grp[kdom]["n"] * 1e6)
         peak = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3
         extra = {"executed_mfma_tflops": alg * MFMA_PER_MAC_F16X3, "mfma_peak_f16_dense": PEAK_F16_MFMA_TFLOPS,
                  "sustained_mfma_f16_random_operands": SUSTAINED_F16_MFMA_TFLOPS,
@@ -339,7 +406,8 @@ def instrumented(step, ops, n_prof, math):
                  "frac_of_fp32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS,
                  "note": "split-fp16 GEMM: every algorithmic MAC is 3 f16 MFMA MACs (ah*bh + ah*bl + al*bh), so peak = "
                          "2500 / 3 TFLOP/s of algorithmic work; achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the "
-                         "family's launches / sum of their HIP-event durations on the launch stream; frac = executed MFMA "
+                         "dominant kernel's launches / sum of their HIP-event durations on the launch stream (`kernels` holds "
+                         "the same per GEMM form, `by_kernel` per kernel); frac = executed MFMA "
                          "FLOP/s / dense f16 MFMA peak (nominal, 2.4 GHz); frac_of_sustained_mfma = the same against what a bare "
                          "MFMA loop sustains on random operands under this chip's power management (tools/ubench/mfma_peak.hip).  "
                          "frac_of_fp32_mfma_peak > 1 means faster than the exact-fp32 MFMA path could run at 100 % of its roofline"}
@@ -349,11 +417,14 @@ def instrumented(step, ops, n_prof, math):
         peak = PEAK_F32_MFMA_TFLOPS
         extra = {"note": "achieved = sum of algorithmic conv FLOPs (2*M*N*K) of the family's launches / sum of their "
                          "HIP-event durations on the launch stream"}
+    dl = dom_launch if math == "f16x3" else kernels[dom]
     roof = {"bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
             "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes": kernels[dom]["algorithmic_bytes_per_launch"], "kernel": kname,
-            "launches_per_step": kernels[dom]["calls_per_step"], "avg_launch_ms": kernels[dom]["avg_launch_ms"]}
+            "algorithmic_bytes": dl["algorithmic_bytes_per_launch"], "kernel": kname,
+            "launches_per_step": dl["calls_per_step"], "avg_launch_ms": dl["avg_launch_ms"]}
     roof.update(extra)
+    if by_kernel is not None:
+        roof["by_kernel"] = by_kernel            # every GEMM kernel of the step: time, algorithmic TFLOP/s, fraction of the roofline
     roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r02_step_table.txt shows
     roof["streaming"] = streaming[:6]        # from rocprofv3); the two big HBM-bound producers against the achievable HBM rate
     return roof, kernels

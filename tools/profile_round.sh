@@ -29,7 +29,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o write -- $STEP > "$OUT/wr
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
           --kernel-trace -d "$OUT" -o mfma -- $STEP > "$OUT/mfma.log" 2>&1
 python "$R/tools/step_table.py" join "$OUT/hostlog.json" "$OUT/st_results.db" "$OUT/fetch_results.db" "$OUT/write_results.db" \
-       "$OUT/mfma_results.db" > "$OUT/${TAG}_step_table.txt" 2>&1
+       "$OUT/mfma_results.db" "$OUT/${TAG}_step_table.json" > "$OUT/${TAG}_step_table.txt" 2>&1
 python "$R/tools/pmc_traffic.py" "$OUT/fetch_results.db" "$OUT/write_results.db" "$OUT/${TAG}_pmc_traffic.json" \
        "$OUT/${TAG}_pmc_traffic.txt" > "$OUT/pmc_traffic.log" 2>&1
 python "$R/tools/pmc_mfma.py" "$OUT/mfma_results.db" > "$OUT/${TAG}_pmc_mfma_util.txt" 2>&1

@@ -82,8 +82,9 @@ def _fmt(v, f):
     return (f % v) if v is not None else "-"
 
 
-def join(log_path, kt_db, fetch_db=None, write_db=None, mfma_db=None):
+def join(log_path, kt_db, fetch_db=None, write_db=None, mfma_db=None, json_out=None):
     log = json.load(open(log_path))
+    rows_json = []
     calls = log["calls"]
     steps = _last_steps(_dispatches(kt_db))
     gem = [_pick(s, GEMM_NAMES) for s in steps]
@@ -123,6 +124,9 @@ def join(log_path, kt_db, fetch_db=None, write_db=None, mfma_db=None):
         print("%-12s %7d %6d %6d %4s %3d  %-34s %9.1f %8.1f %6.3f %9s %9s %8.1f %6s %6s" % (
             family, m_, n_, k_, cfg, ks, name, us, tf, tf / peak, _fmt(fb, "%.1f"), _fmt(wb, "%.1f"), nbytes / 1e6,
             _fmt(busy, "%.3f"), _fmt(ghz, "%.2f")))
+        rows_json.append({"family": family, "M": m_, "N": n_, "K": k_, "cfg": cfg, "k_slices": ks, "kernel": name, "us": us,
+                          "tflops": tf, "fetch_bytes": None if fb is None else fb * 1e6, "write_bytes": None if wb is None else wb * 1e6,
+                          "algorithmic_bytes": nbytes, "mfma_busy": busy, "ghz": ghz})
         f = fam.setdefault(family, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += us
@@ -132,10 +136,12 @@ def join(log_path, kt_db, fetch_db=None, write_db=None, mfma_db=None):
     for k, (fl, us, n) in fam.items():
         print("#   %-12s %2d launches  %8.1f us  %6.1f TFLOP/s  frac %.3f" % (k, n, us, fl / us / 1e6, fl / us / 1e6 / peak))
     tot_fl, tot_us = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())
-    step_us = sum(s[-1][2] - s[0][1] for s in steps) / len(steps) / 1e3
-    print("#   all GEMMs    %8.1f us  %6.1f TFLOP/s  frac %.3f;   step span (serialised, profiled) %.1f us -> %.1f TFLOP/s, frac %.3f"
-          % (tot_us, tot_fl / tot_us / 1e6, tot_fl / tot_us / 1e6 / peak, step_us, tot_fl / step_us / 1e6,
-             tot_fl / step_us / 1e6 / peak))
+    print("#   all GEMMs    %8.1f us  %6.1f TFLOP/s  frac %.3f   (kernel durations only: under the tracer the host cannot keep the "
+          "queue full, so a step SPAN is not meaningful here -- bench.py times the step)" % (tot_us, tot_fl / tot_us / 1e6, tot_fl / tot_us / 1e6 / peak))
+    if json_out:
+        json.dump({"math": log["math"], "what": "one row per GEMM launch of one cfg3 training step (tools/step_table.py join): "
+                   "rocprofv3 kernel-trace durations, FETCH_SIZE x2 / WRITE_SIZE and MFMA busy from separate --pmc passes",
+                   "launches": rows_json}, open(json_out, "w"), indent=1)
     print("# HBM-bound producers of the same steps (mean us; GB/s against their algorithmic bytes is in bench.py's roofline.streaming):")
     agg = {}
     for s in steps:
