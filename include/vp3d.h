@@ -331,6 +331,14 @@ int vp3d_wgrad_rows_s16(vp3d_stream_t stream, int64_t M, const void* dy, int64_t
 /* fp32 rows -> S16 rows (out, may be NULL) and / or the transposed S16 copy (t_out, may be NULL; taps = 1) */
 int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, int64_t ld_src, const float* bound,
                  void* out, int64_t ld_out, void* t_out, int64_t ld_t);
+/* vp3d_im2row + vp3d_split_t in one pass (the expand conv's operand straight from the [B, T, J*F] input: the 128-wide fp32
+ * staging rows are never written): out = S16 rows [M][kpad], t_out = their transposed S16 copy [kpad][ld_t] (either may be
+ * NULL), both under the exponent of *bound, which must cover the input AND the bias column's 1 (vp3d_amax_floor).
+ * kpad % 64 == 0.  Row map and one_col as vp3d_im2row. */
+int vp3d_im2row_split_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid, int32_t kpad,
+                          int32_t one_col, const float* bound, void* out, void* t_out, int64_t ld_t);
+/* vp3d_amax with a floor: *bound = max(*bound, floor, max|src|) */
+int vp3d_amax_floor(vp3d_stream_t stream, int64_t n, const float* src, float floor, float* bound);
 /* reference Conv1d.weight [c_out][c_in][taps] -> S16 packs with the exponent of *bound (c_out, c_in % 64 == 0, taps <= 3):
  *   wf (may be NULL): Wt[co*ld_f + k*c_in + ci]                    (forward)
  *   wd (may be NULL): strided form  Wd[(k*c_in + ci)*ld_d + co]     (dgrad of a stride == taps conv, plain GEMM)

@@ -570,3 +570,23 @@ def test_expand_backward_p_from_go_equals_masked_gemm(shape):
     ws2, n2 = S.nt_raw(g_t, x_t)
     old = ws2.double().sum(0)
     assert float(((got - old).abs() / (den + 1e-30)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("one_col", [-1, 102, 120])
+def test_im2row_split_equals_two_passes(one_col):
+    """vp3d_im2row_split_s16 (the expand conv's S16 operand and its transposed copy straight from the [B, T, J*F] input)
+    against vp3d_im2row + vp3d_split_t: the same bits under the same bound; vp3d_amax_floor covers the bias column's 1."""
+    g = torch.Generator().manual_seed(3)
+    b, t, c_in = 13, 81, 34
+    x = (torch.randn(b, t, c_in, generator=g) * 0.3).to(DEV)
+    spec = ConvSpec(c_in, 256, 3, 1, 3)
+    kpad = ops.padded_k(spec)
+    assert kpad == 128
+    xin = ops.im2row(x, spec, kpad, one_col)
+    bound = S.amax(x, floor=1.0 if one_col >= 0 else 0.0)
+    assert float(bound.max()) == max(float(x.abs().max()), 1.0 if one_col >= 0 else 0.0)
+    m = xin.shape[0] * xin.shape[1]
+    r_ref, t_ref = S.split_t(xin.view(m, kpad), bound)
+    r, tt = S.im2row_split(x, spec, kpad, one_col, bound)
+    assert torch.equal(r.data.view(m, kpad).view(torch.int32), r_ref.data.view(torch.int32))
+    assert torch.equal(tt.data.view(torch.int32), t_ref.data.view(torch.int32))

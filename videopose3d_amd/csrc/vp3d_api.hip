@@ -316,6 +316,11 @@ int vp3d_amax(vp3d_stream_t stream, int64_t n, const float* src, float* bound) {
   return launch_amax((hipStream_t)stream, n, src, bound);
 }
 
+int vp3d_amax_floor(vp3d_stream_t stream, int64_t n, const float* src, float floor, float* bound) {
+  VP3D_REQUIRE(n > 0 && src && bound && floor >= 0.f, "amax_floor: bad argument");
+  return launch_amax((hipStream_t)stream, n, src, bound, floor);
+}
+
 int vp3d_wgrad_rows_s16(vp3d_stream_t stream, int64_t M, const void* dy, int64_t ld_dy, int32_t c_out,
                         const float* dy_bound, const void* x, int64_t ld_x, int32_t taps, int32_t c_in,
                         const float* x_bound, int32_t splits, float* partials) {

@@ -969,12 +969,18 @@ __global__ void __launch_bounds__(256) k_split_rows(int64_t groups, int groups_p
 }
 
 // *bound = max(*bound, max|src|)   (the caller zeroes *bound; non-negative floats order like their bit patterns)
-__global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict__ src, float* __restrict__ bound) {
-  float m = 0.f;
+__global__ void __launch_bounds__(256) k_amax(int64_t n, const float* __restrict__ src, float* __restrict__ bound, float floor_) {
+  float m = floor_;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? n >> 2 : 0;      // 16-B loads when aligned
   const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads in flight per thread
+    const f32x4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[e]), fabsf(v1[e]))), fmaxf(fabsf(v2[e]), fabsf(v3[e])));
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = s4[i];
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
@@ -1452,9 +1458,9 @@ int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld
   return check_launch("wgrad_rows_s16");
 }
 
-int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound) {
-  const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);          // >= 2 float4 per thread
-  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, src, bound);
+int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound, float floor_) {
+  const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);        // >= 4 float4 per thread
+  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, src, bound, floor_);
   return check_launch("amax");
 }
 

@@ -141,7 +141,7 @@ int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, c
                             float* part, float* gram_part);
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
                       const float* bound);
-int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound);
+int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound, float floor_ = 0.f);
 int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld_dy, int32_t c_out, const float* dy_bound,
                           const float* x, int64_t ld_x, int32_t taps, int32_t c_in, const float* x_bound, int32_t splits,
                           float* part);

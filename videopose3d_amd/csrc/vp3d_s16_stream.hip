@@ -449,10 +449,17 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_strips(int M, int C, int 
   }
 }
 
-// fp32 rows [M][C] (pitch ld_src) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
+// im2row source of k_split_t<true>: row m = (b, t) is the k_valid contiguous floats at x[(b*t_src + t*t_stride)*ldx], zeros
+// behind them, 1 in column one_col (vp3d_im2row's rows, never materialised)
+struct Im2Row {
+  int t_dst, t_src, t_stride, ldx, k_valid, one_col;
+};
+
+// fp32 rows [M][C] (pitch ld_src; IM2ROW: gathered, see above) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
+template <bool IM2ROW>
 __global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __restrict__ src, int64_t ld_src,
                                                  const float* __restrict__ bound, float* __restrict__ out, int64_t ld_out,
-                                                 TOut t) {
+                                                 TOut t, Im2Row g) {
   extern __shared__ float tile[];
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
@@ -462,10 +469,17 @@ __global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __re
     const int64_t m = m0 + r;
     float v[8];
     if (m < M) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c + 4);
+      if (IM2ROW) {
+        const int b = (int)(m / g.t_dst), tt = (int)(m - (int64_t)b * g.t_dst);
+        const float* row = src + ((int64_t)b * g.t_src + (int64_t)tt * g.t_stride) * g.ldx;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? a0[e] : a1[e - 4]) * inv;
+        for (int e = 0; e < 8; ++e) v[e] = (c + e < g.k_valid ? row[c + e] : (c + e == g.one_col ? 1.f : 0.f)) * inv;
+      } else {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + m * ld_src + c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? a0[e] : a1[e - 4]) * inv;
+      }
       if (out != nullptr) {
         f16x8 hi, lo;
         s16_split8(v, 1.f, hi, lo);
@@ -1100,9 +1114,30 @@ int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, i
   TOut t{(float*)t_out, ld_t, 1};
   VP3D_REQUIRE((M + 63) / 64 <= 65535, "split_t: more than 65535 row tiles (M=%lld)", (long long)M);
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
-  hipLaunchKernelGGL(k_split_t, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
-                     src, ld_src, bound, (float*)out, ld_out, t);
+  hipLaunchKernelGGL(k_split_t<false>, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
+                     src, ld_src, bound, (float*)out, ld_out, t, Im2Row{});
   return check_launch("split_t");
+}
+
+int vp3d_im2row_split_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid, int32_t kpad,
+                          int32_t one_col, const float* bound, void* out, void* t_out, int64_t ld_t) {
+  VP3D_REQUIRE(map && x && bound && (out || t_out), "im2row_split_s16: null pointer");
+  VP3D_REQUIRE(one_col < 0 || (one_col >= k_valid && one_col < kpad), "im2row_split_s16: the bias column must be a padding column");
+  VP3D_REQUIRE(map->batch > 0 && map->t_dst > 0 && map->t_src > 0 && k_valid > 0 && kpad >= k_valid && kpad % 64 == 0 &&
+                   (out == nullptr || aligned16(out)),
+               "im2row_split_s16: bad sizes (k_valid=%d kpad=%d: the S16 split works on 64-column tiles)", k_valid, kpad);
+  VP3D_REQUIRE((int64_t)(map->t_dst - 1) * map->t_stride * ldx + k_valid <= (int64_t)map->t_src * ldx,
+               "im2row_split_s16: rows run past the end of a sample");
+  const int64_t M = (int64_t)map->batch * map->t_dst;
+  VP3D_REQUIRE(M < ((int64_t)1 << 31) && (M + 63) / 64 <= 65535, "im2row_split_s16: too many rows (M=%lld)", (long long)M);
+  int rc = check_t("im2row_split_s16", t_out, ld_t, 1, M);
+  if (rc) return rc;
+  TOut t{(float*)t_out, ld_t, 1};
+  const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
+  const Im2Row g{map->t_dst, map->t_src, map->t_stride, ldx, k_valid, one_col < 0 ? -1 : one_col};
+  hipLaunchKernelGGL(k_split_t<true>, dim3(kpad / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, kpad,
+                     x, (int64_t)0, bound, (float*)out, (int64_t)kpad, t, g);
+  return check_launch("im2row_split_s16");
 }
 
 int vp3d_pack_weight_s16(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,

@@ -199,15 +199,25 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
     fuse_expand = (os.environ.get("VP3D_EXPAND_FUSED", "1") != "0" and sync is None and not need_dx and
                    (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1]))
-    xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
+    kpad = ops.padded_k(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
-    m0 = xin.shape[0] * xin.shape[1]
-    xb = S.amax(xin, out=bounds[2 * n_layers])
-    x_rows, x_t = S.split_t(xin.view(m0, kpad), xb, want_rows=True, want_t=save)
-    x_rows = S.S16(x_rows.data.view(xin.shape), xb)
     t_in0 = x3.shape[1]
-    xin_f32 = xin if (save and need_dx) else None     # the expand layer's input gradient runs on the fp32 kernels
-    del xin
+    if kpad % 64 == 0 and not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0":
+        # one pass: maximum over the raw input (and the bias column's 1), then im2row + S16 split fused -- the 128-wide fp32
+        # staging rows are never written
+        spec0 = ConvSpec(kpad, plan.convs[0].c_out, 1, 1, 1)
+        xb = S.amax(x3, out=bounds[2 * n_layers], floor=1.0 if one_col >= 0 else 0.0)
+        x_rows, x_t = S.im2row_split(x3, plan.convs[0], kpad, one_col, xb, want_t=save)
+        m0 = x_rows.data.shape[0] * x_rows.data.shape[1]
+        xin_f32 = None
+    else:
+        xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
+        m0 = xin.shape[0] * xin.shape[1]
+        xb = S.amax(xin, out=bounds[2 * n_layers])
+        x_rows, x_t = S.split_t(xin.view(m0, kpad), xb, want_rows=True, want_t=save)
+        x_rows = S.S16(x_rows.data.view(xin.shape), xb)
+        xin_f32 = xin if (save and need_dx) else None     # the expand layer's input gradient runs on the fp32 kernels
+        del xin
 
     # weight-gradient form of every C x C conv: from the S16 rows (k_tn_s16), from the transposed copy its producer
     # writes (strided conv whose windows tile its input), or from a copy gathered in backward (everything else)

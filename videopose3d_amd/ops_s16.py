@@ -43,12 +43,15 @@ def new_bounds(n: int, device) -> torch.Tensor:
     return torch.zeros((n, BOUND_SLOTS), dtype=torch.float32, device=device)
 
 
-def amax(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """max|t| as a device float (accumulated into ``out`` when given: out = max(out, max|t|))."""
+def amax(t: torch.Tensor, out: Optional[torch.Tensor] = None, floor: float = 0.0) -> torch.Tensor:
+    """max(floor, max|t|) as a device float (accumulated into ``out`` when given: out = max(out, ...))."""
     ops._chk(t, "t")
     if out is None:
         out = new_bound(t.device)
-    check(_lib.lib().vp3d_amax(ops._stream(), t.numel(), t.data_ptr(), out.data_ptr()), "vp3d_amax")
+    if floor > 0.0:
+        check(_lib.lib().vp3d_amax_floor(ops._stream(), t.numel(), t.data_ptr(), float(floor), out.data_ptr()), "vp3d_amax_floor")
+    else:
+        check(_lib.lib().vp3d_amax(ops._stream(), t.numel(), t.data_ptr(), out.data_ptr()), "vp3d_amax")
     return out
 
 
@@ -402,6 +405,23 @@ def split_t(t2d: torch.Tensor, bound: torch.Tensor, want_rows=True, want_t=True)
     check(_lib.lib().vp3d_split_t(ops._stream(), m, c, t2d.data_ptr(), c, bound.data_ptr(), ops._p(rows), c, ops._p(tt),
                                   tt.shape[1] if tt is not None else 0), "vp3d_split_t")
     return (S16(rows, bound) if rows is not None else None), (S16(tt, bound) if tt is not None else None)
+
+
+def im2row_split(x: torch.Tensor, spec: ConvSpec, kpad: int, one_col: int, bound: torch.Tensor, want_t=True):
+    """ops.im2row + split_t in one pass (vp3d_im2row_split_s16): [B, T_in, C_in] -> (S16 im2row rows [B, T_out, kpad], their
+    transposed S16 copy [kpad][roundup(M, 64)] or None); bound must cover max|x| and the bias column's 1."""
+    ops._chk(x, "x")
+    assert spec.dil == 1 and kpad % 64 == 0
+    b, t_in, c_in = x.shape
+    t_out = spec.t_out(t_in)
+    m = b * t_out
+    rows = torch.empty((b, t_out, kpad), dtype=torch.float32, device=x.device)
+    tt = torch.empty((kpad, t_pitch(m)), dtype=torch.float32, device=x.device) if want_t else None
+    rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+    check(_lib.lib().vp3d_im2row_split_s16(ops._stream(), C.byref(rm), x.data_ptr(), c_in, spec.taps * c_in, kpad, one_col,
+                                           bound.data_ptr(), rows.data_ptr(), ops._p(tt), tt.shape[1] if tt is not None else 0),
+          "vp3d_im2row_split_s16")
+    return S16(rows, bound), (S16(tt, bound) if tt is not None else None)
 
 
 def pack_weight(w: torch.Tensor, bound: torch.Tensor, want_fwd=True, want_dgrad=True, dilated_form=False):
