@@ -5,6 +5,8 @@
                        dataset (ragged sequence lengths incl. ones shorter than the padding; augmentation; cameras)
   step_loss.npz        /root/reference/common/loss.py mpjpe / weighted_mpjpe values + autograd gradients, and the
                        TTA fold of run.py:677-680 executed line by line
+  eval_protocol.npz    run.py:652-705 evaluate(): UnchunkedGenerator -> TemporalModel.eval() -> test-time-augmentation fold -> mpjpe
+                       accumulated over ragged sequences, with and without TTA (model, data, per-sequence predictions, e1)
   step_adam.npz        torch.optim.Adam(lr, amsgrad=True) (the reference's optimizer, run.py:252) over 6 steps with
                        the per-epoch lr decay of run.py:583-588
 
@@ -123,6 +125,56 @@ def gen_loss():
     np.savez_compressed(os.path.join(HERE, "step_loss.npz"), **out)
 
 
+def gen_eval_protocol():
+    """run.py:652-705 `evaluate()` composed end to end by the reference's own classes: UnchunkedGenerator (padding, test-time
+    augmentation pair) -> TemporalModel.eval() -> un-flip + average -> mpjpe accumulated over the sequences, with and
+    without test-time augmentation.  Stores the model, the sequences, every per-sequence prediction and the e1 numbers."""
+    from common.model import TemporalModel
+    torch.manual_seed(21)
+    fw = [3, 3, 3]
+    model = TemporalModel(17, 2, 17, fw, causal=False, dropout=0.25, channels=64)
+    # (run a few training-mode batches so that the BatchNorm running statistics are not the initial 0 / 1)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            model(torch.randn(8, 27 + 6, 17, 2) * 0.4)
+    model.eval()
+    rng = np.random.RandomState(11)
+    lens = [40, 97, 61, 130, 28, 75]
+    p2 = [(rng.standard_normal((n, 17, 2)) * 0.4).astype(np.float32) for n in lens]
+    p3 = [(rng.standard_normal((n, 17, 3)) * 0.3).astype(np.float32) for n in lens]
+    pad = (model.receptive_field() - 1) // 2
+    out = {"n_seq": len(lens), "fw": np.array(fw), "channels": 64}
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    for i in range(len(lens)):
+        out["p2_%d" % i], out["p3_%d" % i] = p2[i], p3[i]
+    for tag, augment in (("tta", True), ("plain", False)):
+        gen = UnchunkedGenerator(None, p3, p2, pad=pad, causal_shift=0, augment=augment, kps_left=KPS_LEFT,
+                                 kps_right=KPS_RIGHT, joints_left=JOINTS_LEFT, joints_right=JOINTS_RIGHT)
+        epoch_loss, n = 0.0, 0
+        with torch.no_grad():
+            for s_id, (_, batch, batch_2d) in enumerate(gen.next_epoch()):
+                inputs_2d = torch.from_numpy(batch_2d.astype("float32"))
+                predicted = model(inputs_2d)                                             # run.py:669
+                if gen.augment_enabled():                                                # run.py:674-680
+                    predicted[1, :, :, 0] *= -1
+                    predicted[1, :, JOINTS_LEFT + JOINTS_RIGHT] = predicted[1, :, JOINTS_RIGHT + JOINTS_LEFT]
+                    predicted = torch.mean(predicted, dim=0, keepdim=True)
+                inputs_3d = torch.from_numpy(batch.astype("float32"))
+                inputs_3d[:, :, 0] = 0                                                   # run.py:688
+                if gen.augment_enabled():
+                    inputs_3d = inputs_3d[:1]
+                error = mpjpe(predicted, inputs_3d)                                      # run.py:692
+                epoch_loss += inputs_3d.shape[0] * inputs_3d.shape[1] * error.item()
+                n += inputs_3d.shape[0] * inputs_3d.shape[1]
+                out["%s/pred_%d" % (tag, s_id)] = predicted[0].numpy()
+        out["%s/e1_mm" % tag] = np.float64(epoch_loss / n * 1000)                        # run.py:711
+        out["%s/frames" % tag] = n
+    np.savez_compressed(os.path.join(HERE, "eval_protocol.npz"), **out)
+    print("eval_protocol.npz: e1 %.6f mm (TTA) / %.6f mm (plain) over %d frames" % (out["tta/e1_mm"], out["plain/e1_mm"], n))
+
+
 def gen_adam():
     torch.manual_seed(11)
     shapes = [(33,), (7, 5, 3), (51,), (64, 64, 1)]
@@ -153,8 +205,12 @@ def gen_adam():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":          # only the evaluation-protocol fixture (leaves the others untouched)
+        gen_eval_protocol()
+        sys.exit(0)
     gen_generators()
     gen_loss()
     gen_adam()
-    for f in ("step_generators.npz", "step_loss.npz", "step_adam.npz"):
+    gen_eval_protocol()
+    for f in ("step_generators.npz", "step_loss.npz", "step_adam.npz", "eval_protocol.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -511,3 +511,50 @@ def test_batched_sequence_evaluation_equals_one_by_one():
     with torch.no_grad():
         for s_id, (_, _, b2) in enumerate(gen.next_epoch()):
             assert float((got[s_id] - m(b2)[0]).abs().max()) < 2e-5, s_id
+
+
+def test_evaluation_protocol_vs_reference_golden():
+    """run.py:652-705 `evaluate()` end to end -- UnchunkedGenerator (padding + test-time-augmentation pair) -> eval-mode
+    TemporalModel -> un-flip / average -> mpjpe accumulated over ragged sequences -- against numbers the REFERENCE's own
+    classes produced on the same model and data (tests/golden/eval_protocol.npz, make_golden_step.py eval): every
+    per-sequence prediction, and Protocol #1 error within the north star's 0.1 mm, with and without TTA, one video per call
+    and length-grouped batches."""
+    import os
+    import videopose3d_amd as V
+    from videopose3d_amd import generators as G
+    from videopose3d_amd import loss as vloss
+    from tests.util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "eval_protocol.npz"))
+    n, fw = int(g["n_seq"]), [int(v) for v in g["fw"]]
+    kl, kr = [1, 3, 5, 7, 9, 11, 13, 15], [2, 4, 6, 8, 10, 12, 14, 16]
+    jl, jr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    m = V.TemporalModel(17, 2, 17, fw, channels=int(g["channels"])).to(DEV)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}, strict=True)
+    m.eval()
+    p2 = [g["p2_%d" % i] for i in range(n)]
+    p3 = [g["p3_%d" % i] for i in range(n)]
+    pad = (m.receptive_field() - 1) // 2
+    for tag, augment in (("tta", True), ("plain", False)):
+        gen = G.UnchunkedGenerator(None, p3, p2, pad=pad, causal_shift=0, augment=augment, kps_left=kl, kps_right=kr,
+                                   joints_left=jl, joints_right=jr, device=DEV)
+        total, frames = 0.0, 0
+        with torch.no_grad():
+            for s_id, (_, b3, b2) in enumerate(gen.next_epoch()):
+                pred = m(b2)
+                if gen.augment_enabled():
+                    pred = G.tta_average(pred, jl, jr)
+                tgt = b3.clone()
+                tgt[:, :, 0] = 0
+                if gen.augment_enabled():
+                    tgt = tgt[:1]
+                ref = torch.from_numpy(g["%s/pred_%d" % (tag, s_id)]).to(DEV)
+                assert float((pred[0] - ref).abs().max()) < 2e-5, (tag, s_id)
+                total += tgt.shape[0] * tgt.shape[1] * float(vloss.mpjpe(pred, tgt))
+                frames += tgt.shape[0] * tgt.shape[1]
+        assert frames == int(g["%s/frames" % tag])
+        e1 = total / frames * 1000
+        assert abs(e1 - float(g["%s/e1_mm" % tag])) < 1e-2, (tag, e1, float(g["%s/e1_mm" % tag]))      # (north star: 0.1 mm)
+        batched = G.predict_sequences(m, gen, max_frames=400)                 # several videos per forward call
+        for s_id in range(n):
+            ref = torch.from_numpy(g["%s/pred_%d" % (tag, s_id)]).to(DEV)
+            assert float((batched[s_id] - ref).abs().max()) < 3e-5, (tag, s_id)

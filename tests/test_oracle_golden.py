@@ -82,3 +82,33 @@ def test_torch_cpu_path_matches_reference_golden(name):
             assert rel_err(sd[k].numpy(), v) < 1e-5, k
     for k, v in g["grad"].items():
         assert rel_err(grads[k].numpy(), v) < 1e-4, k
+
+
+def test_oracle_evaluation_protocol_golden():
+    """The oracle's eval forward composed as run.py:652-705 composes the reference (edge padding of generators.py:219-224, the
+    test-time-augmentation pair and its fold, mpjpe over ragged sequences) against tests/golden/eval_protocol.npz, which the
+    reference's own UnchunkedGenerator / TemporalModel / mpjpe produced."""
+    import os
+    g = np.load(os.path.join(GOLDEN, "eval_protocol.npz"))
+    n, fw = int(g["n_seq"]), [int(v) for v in g["fw"]]
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd/")}
+    kl, kr = [1, 3, 5, 7, 9, 11, 13, 15], [2, 4, 6, 8, 10, 12, 14, 16]
+    jl, jr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    pad = (O.receptive_field(fw) - 1) // 2
+    total, frames = 0.0, 0
+    for i in range(n):
+        x = np.pad(g["p2_%d" % i], ((pad, pad), (0, 0), (0, 0)), "edge")[None]
+        xf = x.copy()
+        xf[..., 0] *= -1
+        xf[:, :, kl + kr] = xf[:, :, kr + kl]
+        y, _, _ = O.forward(sd, np.concatenate([x, xf]), fw, kind="dilated", training=False)
+        y[1, :, :, 0] *= -1
+        y[1, :, jl + jr] = y[1, :, jr + jl]
+        pred = y.mean(0)
+        assert np.abs(pred - g["tta/pred_%d" % i]).max() < 2e-5, i
+        tgt = g["p3_%d" % i].copy()
+        tgt[:, 0] = 0
+        total += tgt.shape[0] * mpjpe_np(pred, tgt)
+        frames += tgt.shape[0]
+    assert frames == int(g["tta/frames"])
+    assert abs(total / frames * 1000 - float(g["tta/e1_mm"])) < 1e-2
