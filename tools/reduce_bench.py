@@ -85,3 +85,40 @@ for it in range(300):
     e = max(float((dbet.double() - rb).abs().max() / rb.abs().max()), float((dgam.double() - rg).abs().max() / rg.abs().max()))
     worst = max(worst, e)
 print("hand-off check: 300 launches, worst relative error of dgamma / dbeta vs fp64: %.3e" % worst)
+
+# ---- the same with the inputs rotated over 5 buffer sets (1.1 GB: nothing stays in the 256 MB Infinity Cache) -----------------
+for b, t in ((1024, 27), (1024, 9)):
+    m = b * t
+    sets = []
+    for k in range(5):
+        sets.append((torch.randn(b, t, c, device=DEV), torch.randn(b, t, c, device=DEV) * 1e-4,
+                     torch.randint(0, 255, (m * c // 8,), dtype=torch.uint8, device=DEV)))
+    coef = torch.stack([1 + 0.2 * torch.randn(c), 0.1 * torch.randn(c), 0.05 * torch.randn(c), 1 + 0.1 * torch.rand(c)]).to(DEV)
+    sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
+    gb = S.amax(sets[0][1])
+    nparts, ngroups, ntick, np2 = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    L.vp3d_bn_bwd_reduce_fin_s16(ops._stream(), m, c, None, None, None, None, None, 0.25, None, None, None, None, None, None, None, None,
+                                 C.byref(nparts), C.byref(ngroups), C.byref(ntick))
+    L.vp3d_bn_bwd_reduce_bits(ops._stream(), m, c, None, None, None, None, None, 1.0, None, C.byref(np2))
+    parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=DEV)
+    parts2 = torch.empty((np2.value, 2, c), dtype=torch.float32, device=DEV)
+    tick = torch.zeros(max(ntick.value, 256), dtype=torch.int32, device=DEV)
+    dg = torch.empty(2, c, device=DEV)
+    dyb = S.new_bound(DEV)
+    it = [0]
+
+    def plain():
+        y, go, bits = sets[it[0] % 5]
+        it[0] += 1
+        L.vp3d_bn_bwd_reduce_bits(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), mu, inv, bits.data_ptr(), 1.333, parts2.data_ptr(),
+                                  C.byref(np2))
+
+    def fused():
+        y, go, bits = sets[it[0] % 5]
+        it[0] += 1
+        L.vp3d_bn_bwd_reduce_fin_s16(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), mu, inv, bits.data_ptr(), 0.25, sc, gb.data_ptr(),
+                                     parts.data_ptr(), None, tick.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), dyb.data_ptr(),
+                                     C.byref(nparts), C.byref(ngroups), C.byref(ntick))
+    print("M=%6d rotating buffers: full-row reduce alone %6.1f us (%.0f GB/s) | strip-owned reduce + finalize %6.1f us (%.0f GB/s)"
+          % (m, timed(plain), 2 * m * c * 4 / timed(plain) / 1e3, timed(fused), 2 * m * c * 4 / timed(fused) / 1e3), flush=True)
+    del sets
