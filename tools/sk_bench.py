@@ -12,6 +12,7 @@ from videopose3d_amd._lib import RowMap  # noqa: E402
 from videopose3d_amd.plan import ConvSpec  # noqa: E402
 
 dev = "cuda:0"
+CFGS = tuple(int(a) for a in sys.argv[1:]) or (20, 120, 22, 122)
 
 
 def timeit(fn, iters=6, warm=2):
@@ -35,7 +36,7 @@ def fwd(b, t, taps, c=1024):
     st = ops.stat_buffers(m, c, dev)
     pc, ps = S.plan(m, c, k)
     line = "fwd   M=%6d N=%5d K=%5d | plan(c%d,s%d) %7.1f |" % (m, c, k, pc, ps, timeit(lambda: S.conv_nt(x, w, spec, stats=st)))
-    for cfg in (20, 120, 22, 122):
+    for cfg in CFGS:
         us = timeit(lambda: S.conv_nt(x, w, spec, stats=st, cfg=cfg, splits=1))
         line += " c%d %7.1f (%5.1f TF) |" % (cfg, us, 2.0 * m * c * k / us / 1e6)
     print(line, flush=True)
@@ -53,7 +54,7 @@ def dgrad(bb, t_o, n_taps, c=1024):
     pc, ps = S.plan(m, n_taps * c, c)
     line = "dgrad M=%6d N=%5d K=%5d | plan(c%d,s%d) %7.1f |" % (m, n_taps * c, c, pc, ps, timeit(
         lambda: S.gemm_rows(dy, wd, rm, c, c, n_taps * c, dx, n_taps * t_o * c, n_taps * c, epi=e, amax_out=am, family="tconv_dgrad")))
-    for cfg in (20, 120, 22, 122):
+    for cfg in CFGS:
         us = timeit(lambda: S.gemm_rows(dy, wd, rm, c, c, n_taps * c, dx, n_taps * t_o * c, n_taps * c, epi=e, amax_out=am,
                                         cfg=cfg, splits=1, family="tconv_dgrad"))
         line += " c%d %7.1f (%5.1f TF) |" % (cfg, us, 2.0 * m * n_taps * c * c / us / 1e6)
