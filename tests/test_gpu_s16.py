@@ -199,27 +199,34 @@ def test_act_bound_is_a_bound_for_adversarial_statistics():
     assert float((S.join(a) - a32).abs().max()) < float(bd.max()) * 2.0 ** -20
 
 
-def test_model_level_f16x3_equals_f32_path():
-    """Whole training step and eval forward in both arithmetics on the same weights / dropout stream."""
+@pytest.mark.parametrize("joints,c", [(17, 128), (15, 64), (10, 256), (5, 64)])
+def test_model_level_f16x3_equals_f32_path(joints, c):
+    """Whole training step and eval forward in both arithmetics on the same weights / dropout stream; the joint counts give
+    expand rows of 102 -> 128, 90 -> 96, 60 -> 64 and 30 -> 32 columns (the dedicated expand kernels with partly filled /
+    fewer k-steps, the one-pass input staging only for multiples of 64)."""
     import copy
+    from videopose3d_amd import engine
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})
     torch.manual_seed(0)
     fw = [3, 3, 3]
     V.set_default_math("f32")
     try:
-        m32 = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.25, channels=128).to(DEV).train()
+        m32 = V.TemporalModelOptimized1f(joints, 2, 17, fw, dropout=0.25, channels=c).to(DEV).train()
     finally:
         V.set_default_math(None)
     m16 = copy.deepcopy(m32)
     m16.math = "f16x3"
     for m in (m32, m16):
         m._drop_seed, m._drop_calls = 99, 0
-    x = (torch.randn(16, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+    x = (torch.randn(16, 27, joints, 2, device=DEV) * 0.5).clamp(-1, 1)
     tgt = torch.randn(16, 1, 17, 3, device=DEV) * 0.3
     outs = []
+    n16 = engine.ENGINE_CALLS["s16_train"]
     for m in (m32, m16):
         yv = m(x)
         torch.mean(torch.norm(yv - tgt, dim=3)).backward()
         outs.append(yv.detach())
+    assert engine.ENGINE_CALLS["s16_train"] == n16 + 1          # the second model really ran the split-fp16 engine
     assert float(torch.mean(torch.norm(outs[0] - outs[1], dim=3))) < 1e-5
     for (k, a), (_, q) in zip(m16.named_parameters(), m32.named_parameters()):
         assert float((a.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)) < 5e-5, k

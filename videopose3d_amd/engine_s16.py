@@ -144,12 +144,19 @@ def next_is_not_tcopy(plan: StackPlan, t_in: int) -> bool:
     return (not tiling) or wgrad_from_rows(sp.c_out, sp.c_in)
 
 
+def expand_kpad(spec: ConvSpec) -> int:
+    """Row width of the expand conv's im2row operand in TRAINING: taps * C_in rounded up to 64 columns (the S16 transposing
+    producers work on 64-column tiles: 17 joints -> 102 -> 128, 15 joints -> 90 -> 128, 5 joints -> 30 -> 64)."""
+    k = spec.taps * spec.c_in
+    return (k + 63) // 64 * 64 if (spec.dil == 1 and spec.c_in % 32 != 0) else 0
+
+
 def expand_shortcut_column(plan: StackPlan, sync) -> int:
     """Padding column of the expand conv's im2row rows that carries the constant 1 of the no-dy backward of the expand
     layer (expand_bwd below), or -1 when that backward is not used: no spare padding column, synchronised BatchNorm
     (the formulas need the global sums between the two reductions), or VP3D_EXPAND_BWD=0."""
     spec = plan.convs[0]
-    kpad, kv = ops.padded_k(spec), spec.taps * spec.c_in
+    kpad, kv = expand_kpad(spec), spec.taps * spec.c_in
     if os.environ.get("VP3D_EXPAND_BWD", "1") == "0" or sync is not None or not kpad or kv >= kpad or kpad > 128:
         return -1
     return kv
@@ -199,10 +206,10 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
     fuse_expand = (os.environ.get("VP3D_EXPAND_FUSED", "1") != "0" and sync is None and not need_dx and
                    (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1]))
-    kpad = ops.padded_k(plan.convs[0])
+    kpad = expand_kpad(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
     t_in0 = x3.shape[1]
-    if kpad % 64 == 0 and not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0":
+    if not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0":
         # one pass: maximum over the raw input (and the bias column's 1), then im2row + S16 split fused -- the 128-wide fp32
         # staging rows are never written
         spec0 = ConvSpec(kpad, plan.convs[0].c_out, 1, 1, 1)
@@ -211,7 +218,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         m0 = x_rows.data.shape[0] * x_rows.data.shape[1]
         xin_f32 = None
     else:
-        xin, spec0, kpad = engine._expand_input(plan, x3, one_col)
+        xin, spec0 = ops.im2row(x3, plan.convs[0], kpad, one_col), ConvSpec(kpad, plan.convs[0].c_out, 1, 1, 1)
         m0 = xin.shape[0] * xin.shape[1]
         xb = S.amax(xin, out=bounds[2 * n_layers])
         x_rows, x_t = S.split_t(xin.view(m0, kpad), xb, want_rows=True, want_t=save)
