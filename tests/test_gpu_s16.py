@@ -233,6 +233,17 @@ def test_model_level_f16x3_equals_f32_path(joints, c):
     for (k, a), (_, q) in zip(m16.named_buffers(), m32.named_buffers()):
         if a.dtype.is_floating_point:
             assert torch.allclose(a, q, rtol=1e-5, atol=1e-6), k
+    # eval forward (folded BatchNorm) on the dilated class with the same weights
+    e32 = V.TemporalModel(joints, 2, 17, fw, channels=c).to(DEV)
+    e32.load_state_dict(m32.state_dict())
+    e16 = copy.deepcopy(e32)
+    e32.math, e16.math = "f32", "f16x3"
+    xe = (torch.randn(4, 40, joints, 2, device=DEV) * 0.5).clamp(-1, 1)
+    n16 = engine.ENGINE_CALLS["s16_eval"]
+    with torch.no_grad():
+        ya, yb = e32.eval()(xe), e16.eval()(xe)
+    assert engine.ENGINE_CALLS["s16_eval"] == n16 + (1 if joints * 2 * 3 >= 32 else 0)     # (30 input columns: eval stays on fp32)
+    assert float(torch.mean(torch.norm(ya - yb, dim=3))) < 1e-5
 
 
 def test_unsupported_configurations_fall_back_to_fp32_kernels():

@@ -42,10 +42,11 @@ def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
     produced by the fp32 kernels for the expand layer only."""
     plan: StackPlan = mod._plan
     c = plan.convs[0].c_out
-    if c % 64 != 0 or plan.convs[0].c_in * plan.convs[0].taps > 128:
+    k0 = plan.convs[0].c_in * plan.convs[0].taps
+    if c % 64 != 0 or k0 > 128:
         return False
     if not training:
-        return True
+        return k0 >= 32                              # (eval stages the expand conv through ops.padded_k rows: none below 32 columns)
     return max(spec.taps for spec in plan.convs) <= MAX_TRAIN_TAPS
 
 
