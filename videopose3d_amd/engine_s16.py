@@ -210,7 +210,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     kpad = expand_kpad(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
     t_in0 = x3.shape[1]
-    if not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0":
+    rows0 = x3.shape[0] * plan.convs[0].t_out(t_in0)
+    if not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and rows0 <= 65535 * 64:
         # one pass: maximum over the raw input (and the bias column's 1), then im2row + S16 split fused -- the 128-wide fp32
         # staging rows are never written
         spec0 = ConvSpec(kpad, plan.convs[0].c_out, 1, 1, 1)
@@ -269,7 +270,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
         # the conv output never goes to HBM (its backward, expand_bwd, needs no y either)
         fused0 = idx == 0 and fuse_expand and n_layers > 1
-        dedicated0 = fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"      # vp3d_expand_fwd_s16
+        dedicated0 = (fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
+                      m_rows * kpad * 4 < 2 ** 31)                                     # vp3d_expand_fwd_s16 (32-bit byte offsets)
         y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
         coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
@@ -348,7 +350,8 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # X^T X of the expand layer's input (its no-dy backward, below): a small GEMM with nothing upstream -> second stream
     gram_xx, gram_ev = None, None
     # (with the dedicated kernel X^T X rides along in the P = G^T X launch at the end of backward: no GEMM of its own)
-    fused_p = L[0].one_col >= 0 and L[0].x_rows is None and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0"
+    fused_p = (L[0].one_col >= 0 and L[0].x_rows is None and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
+               L[0].bits is not None and L[0].bits.numel() * 32 < 2 ** 31)      # (the kernel addresses go with 32-bit byte offsets)
     if L[0].one_col >= 0 and not fused_p:
         if side is not None:
             side.wait_stream(main)
