@@ -127,14 +127,16 @@ class _Saved:
                                   # of regenerating the Philox mask
 
 
-def wgrad_from_rows(c_out: int, c_in: int) -> bool:
+def wgrad_from_rows(c_out: int, c_in: int, in_rows: int = 0) -> bool:
     """Default since round 2 (VP3D_WGRAD_ROWS=0 restores the transposed-copy form): the C x C weight gradients read the
     S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16, channels % 256 == 0) and the producers write no
     transposed copies for them; the expand conv (K-padded im2row operand) and narrower models keep the transposed form."""
-    return os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in)
+    # in_rows: rows of the conv's input (B * T_in): vp3d_wgrad_rows_s16 addresses both operands with 32-bit byte offsets
+    return (os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in) and
+            in_rows * max(c_in, c_out) * 4 < 2 ** 31)
 
 
-def next_is_not_tcopy(plan: StackPlan, t_in: int) -> bool:
+def next_is_not_tcopy(plan: StackPlan, t_in: int, batch: int = 0) -> bool:
     """The conv after the expand layer takes its weight-gradient operand from the rows (directly or gathered), i.e. the
     expand layer's producer has no transposed copy to write (the fused GEMM epilogue writes rows only)."""
     if len(plan.convs) < 2:
@@ -142,7 +144,7 @@ def next_is_not_tcopy(plan: StackPlan, t_in: int) -> bool:
     sp = plan.convs[1]
     t1 = plan.convs[0].t_out(t_in)
     tiling = sp.taps == 1 or _tiles(sp, t1)
-    return (not tiling) or wgrad_from_rows(sp.c_out, sp.c_in)
+    return (not tiling) or wgrad_from_rows(sp.c_out, sp.c_in, batch * t1)
 
 
 def expand_kpad(spec: ConvSpec) -> int:
@@ -206,7 +208,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
     fuse_expand = (os.environ.get("VP3D_EXPAND_FUSED", "1") != "0" and sync is None and not need_dx and
-                   (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1]))
+                   (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1], x3.shape[0]))
     kpad = expand_kpad(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
     t_in0 = x3.shape[1]
@@ -236,7 +238,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     for idx in range(1, n_layers):
         sp = plan.convs[idx]
         tiling = sp.taps == 1 or _tiles(sp, t_in_of[idx])
-        wform[idx] = ("rows" if wgrad_from_rows(sp.c_out, sp.c_in) else "tcopy") if tiling else "gather"
+        wform[idx] = ("rows" if wgrad_from_rows(sp.c_out, sp.c_in, b * t_in_of[idx]) else "tcopy") if tiling else "gather"
 
     def next_taps(idx):
         """taps of the conv that consumes the activation of layer idx when its wgrad reduces over the producer-written
