@@ -608,3 +608,17 @@ def test_im2row_split_equals_two_passes(one_col):
     r, tt = S.im2row_split(x, spec, kpad, one_col, bound)
     assert torch.equal(r.data.view(m, kpad).view(torch.int32), r_ref.data.view(torch.int32))
     assert torch.equal(tt.data.view(torch.int32), t_ref.data.view(torch.int32))
+
+
+def test_engines_agree_on_random_configurations():
+    """tools/fuzz_engines.py as a test (30 random model / batch configurations: class, arc incl. 1-tap and single-filter
+    models, causal, dense, channels, joint counts, dropout, input gradients): the split-fp16 engine against the exact-fp32
+    one on the same weights and masks.  This sweep found five configuration bugs in round 2 (96-column and < 32-column
+    expand rows, C_in % 32 == 0 inputs, models without residual blocks, dilated 1-tap convs in backward)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "30", "7"], capture_output=True, text=True,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

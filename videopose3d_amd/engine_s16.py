@@ -150,8 +150,8 @@ def next_is_not_tcopy(plan: StackPlan, t_in: int, batch: int = 0) -> bool:
 def expand_kpad(spec: ConvSpec) -> int:
     """Row width of the expand conv's im2row operand in TRAINING: taps * C_in rounded up to 64 columns (the S16 transposing
     producers work on 64-column tiles: 17 joints -> 102 -> 128, 15 joints -> 90 -> 128, 5 joints -> 30 -> 64)."""
-    k = spec.taps * spec.c_in
-    return (k + 63) // 64 * 64 if (spec.dil == 1 and spec.c_in % 32 != 0) else 0
+    k = spec.taps * spec.c_in                        # (the expand conv always has dilation 1: its taps are adjacent rows)
+    return (k + 63) // 64 * 64 if spec.dil == 1 else 0
 
 
 def expand_shortcut_column(plan: StackPlan, sync) -> int:
@@ -250,7 +250,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     S.amax_multi(ws, bounds[n_layers:])
     w0_packed = ops.pack_weight(ws[0], ld_out=kpad)
     packs = [(S.split(w0_packed, bounds[n_layers]), None)]
-    packs += _packs(ws[1:], plan.convs[1:], bounds[n_layers + 1:], save)
+    if n_layers > 1:
+        packs += _packs(ws[1:], plan.convs[1:], bounds[n_layers + 1:], save)
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
     S.act_bounds_multi(bns, m_all if sync is None else [sync.rows_total(m_) for m_ in m_all], res_from, p, bounds)
@@ -445,7 +446,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, c_in, dx, t_i * c_in, c_in, epi=e, amax_out=amax_out,
                         family="tconv_dgrad")
             return dx
-        assert spec.stride == taps and spec.dil == 1 and taps * t_o <= t_i
+        assert spec.stride == taps and (spec.dil == 1 or taps == 1) and taps * t_o <= t_i      # (a 1-tap conv has no dilation to speak of)
         dx = (torch.empty if taps * t_o == t_i else torch.zeros)((bb, t_i, c_in), dtype=torch.float32, device=dev)
         rm = RowMap(bb, t_o, t_o, 1, 0, 0, 1)
         e = None
