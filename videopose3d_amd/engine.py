@@ -109,16 +109,19 @@ class _Saved:
         self.x, self.y, self.coef, self.drop, self.wt, self.kpad, self.t_in = x, y, coef, drop, wt, kpad, t_in
 
 
-def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
-    """Returns (out3, saved) ; saved is None unless `save`."""
+def _forward_train_f32(mod, x3: torch.Tensor, save: bool, frozen: bool = False):
+    """Returns (out3, saved) ; saved is None unless `save`.  frozen: the differentiable EVAL forward (reference model.py:63-77
+    with the module in .eval(): BatchNorm on its running statistics, no dropout, nothing updated) -- same kernels, the
+    coefficients come from the running statistics instead of the batch's."""
     plan: StackPlan = mod._plan
     plan.lengths(x3.shape[1])
     convs, bns = _convs(mod), _bns(mod)
-    p = float(mod.drop.p)
+    p = 0.0 if frozen else float(mod.drop.p)
     seed, offset = mod._next_dropout_state() if p > 0 else (0, 0)
-    mod._stats_epoch += 1            # running statistics are about to change (written by raw pointer)
+    if not frozen:
+        mod._stats_epoch += 1        # running statistics are about to change (written by raw pointer)
     saved = []
-    sync = mod.__dict__.get("_vp3d_sync_bn")         # dp.SyncBatchNorm: statistics over the global batch
+    sync = None if frozen else mod.__dict__.get("_vp3d_sync_bn")         # dp.SyncBatchNorm: statistics over the global batch
     if sync is not None:
         sync.begin_step(x3.shape[0], x3.device)
 
@@ -130,9 +133,13 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
             h, spec, kpad = _expand_input(plan, h)
         wt = ops.pack_weight(convs[idx].weight.detach(), ld_out=kpad or None)
         m_rows = b * spec.t_out(h.shape[1])
-        stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
-        y = ops.conv_fwd(h, wt, spec, stats=stats)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
+        if frozen:
+            y = ops.conv_fwd(h, wt, spec)
+            coef = ops.bn_eval_coef(bns[idx])
+        else:
+            stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
+            y = ops.conv_fwd(h, wt, spec, stats=stats)
+            coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         a = ops.bn_act_fwd(y, coef, drop, residual)
         if save:
@@ -146,7 +153,7 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool):
     out = _shrink(mod, h)
     if not save:
         return out, None
-    return out, dict(layers=saved, h_last=h, wts=ops.pack_weight(mod.shrink.weight.detach()), x3=x3)
+    return out, dict(layers=saved, h_last=h, wts=ops.pack_weight(mod.shrink.weight.detach()), x3=x3, frozen=frozen)
 
 
 _side_streams = {}
@@ -216,8 +223,11 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # 10.18 ms -- no gain, so the separate kernels stay the default.
     fuse_mode = os.environ.get("VP3D_FUSE_ACT_BWD", "0")
     sync = mod.__dict__.get("_vp3d_sync_bn")
-    if sync is not None:
-        fuse_mode = "0"                              # the fused epilogue reduces with per-replica statistics
+    frozen = bool(saved.get("frozen"))               # eval-mode forward: BatchNorm on running statistics (ops.bn_act_bwd)
+    if sync is not None or frozen:
+        fuse_mode = "0"                              # the fused epilogue reduces with per-replica batch statistics
+    if frozen:
+        sync = None
 
     def upstream(idx):
         return (L[idx].y, L[idx].coef, L[idx].drop)
@@ -260,7 +270,7 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
         if fused is not None:
             dy, dgam, dbet = ops.bn_act_bwd_fused(fused, s.y, s.coef, out_dgamma=o_g, out_dbeta=o_bt)
         else:
-            dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt, sync=sync)
+            dy, dgam, dbet = ops.bn_act_bwd(go, s.y, s.coef, s.drop, out_dgamma=o_g, out_dbeta=o_bt, sync=sync, frozen=frozen)
         grads[3 * idx + 1] = sunk(dgam, o_g)
         grads[3 * idx + 2] = sunk(dbet, o_bt)
 
@@ -363,6 +373,28 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         from . import engine_s16
         return engine_s16.backward_train(mod, saved, gout3, need_dx)
     return _backward_train_f32(mod, saved, gout3, need_dx)
+
+
+class FrozenStackFn(torch.autograd.Function):
+    """The differentiable eval-mode forward (module in .eval(), autograd on): the exact-fp32 kernels with the BatchNorm
+    coefficients taken from the running statistics; the backward is the training backward without the batch-statistic terms."""
+
+    @staticmethod
+    def forward(ctx, mod, x3, *params):
+        ENGINE_CALLS["f32_eval_grad"] += 1
+        out, saved = _forward_train_f32(mod, x3, save=True, frozen=True)
+        ctx.mod = mod
+        ctx.saved = saved
+        ctx.need_dx = x3.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.saved is None:
+            raise RuntimeError("vp3d: backward called twice on the same graph (activations were freed)")
+        grads, dx = _backward_train_f32(ctx.mod, ctx.saved, gout, ctx.need_dx)
+        ctx.saved = None
+        return (None, dx) + tuple(grads)
 
 
 class TemporalStackFn(torch.autograd.Function):

@@ -145,11 +145,14 @@ class TemporalModelBase(nn.Module):
                     with torch.no_grad():
                         out3, _ = engine.forward_train(self, x3, save=False)
             else:
-                if torch.is_grad_enabled() and x.requires_grad:
-                    raise Vp3dError("gradients through the eval-mode (folded BatchNorm) path are not implemented; "
-                                    "call model.train() or wrap evaluation in torch.no_grad() as run.py does")
-                with torch.no_grad():
-                    out3 = engine.forward_eval(self, x3)
+                if torch.is_grad_enabled() and (x3.requires_grad or any(p.requires_grad for p in self.parameters())):
+                    # the reference's eval-mode forward is differentiable (model.py:63-77): BatchNorm on its running
+                    # statistics, exact-fp32 kernels, hand-written backward without the batch-statistic terms.  Evaluation
+                    # under torch.no_grad() (as run.py does it) takes the folded-BatchNorm fast path below.
+                    out3 = engine.FrozenStackFn.apply(self, x3, *engine.param_list(self))
+                else:
+                    with torch.no_grad():
+                        out3 = engine.forward_eval(self, x3)
         return out3.view(b, -1, self.num_joints_out, 3)
 
 

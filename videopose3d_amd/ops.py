@@ -468,10 +468,22 @@ def _sync_sums(dgam, dbet, sync):
     return g[0], g[1]
 
 
+def bn_eval_coef(bn: torch.nn.BatchNorm1d) -> torch.Tensor:
+    """[4, C] = scale, shift, mean, invstd of an eval-mode BatchNorm (running statistics): the coefficient block of
+    bn_finalize, for the differentiable eval forward (torch.nn.functional.batch_norm(training=False))."""
+    with torch.no_grad():
+        invstd = torch.rsqrt(bn.running_var.float() + float(bn.eps))
+        scale = bn.weight.detach().float() * invstd
+        shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+        return torch.stack([scale, shift, bn.running_mean.float(), invstd]).contiguous()
+
+
 def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Optional[Dropout],
-               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None, sync=None):
+               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None, sync=None,
+               frozen: bool = False):
     """Returns (dy, dgamma, dbeta) for a = dropout(relu(bn(y))); dgamma / dbeta are written into the given
-    contiguous fp32 [C] tensors when provided (gradient sink)."""
+    contiguous fp32 [C] tensors when provided (gradient sink).  frozen: the BatchNorm ran on its running statistics
+    (eval mode): mean and variance do not depend on y, so dy = scale * g without the two batch-statistic terms."""
     _chk(go, "go")
     _chk(y, "y")
     b, t, c = y.shape
@@ -496,6 +508,8 @@ def bn_act_bwd(go: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop: Opti
     check(L.vp3d_bn_bwd_finalize(_stream(), c, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr()),
           "vp3d_bn_bwd_finalize")
     a_g, a_b = (dgam, dbet) if sync is None else _sync_sums(dgam, dbet, sync)   # the parameter gradients stay local sums
+    if frozen:
+        a_g = a_b = torch.zeros(c, dtype=torch.float32, device=y.device)
     dy = torch.empty_like(y)
     check(L.vp3d_bn_bwd_apply(_stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, a_g.data_ptr(),
                               a_b.data_ptr(), dy.data_ptr()), "vp3d_bn_bwd_apply")
