@@ -54,8 +54,12 @@ def _dispatches(db_path):
 
 
 def _last_steps(rows):
-    """Split at k_im2row (first kernel of a step); the last N_KEEP steps."""
-    starts = [i for i, r in enumerate(rows) if "k_im2row" in r[0]]
+    """Split at the first kernels of a step -- the maximum over the raw input, then the fused im2row + S16 split
+    (k_split_t<true>; k_im2row on the older path) --; the last N_KEEP steps."""
+    starts = []
+    for i, r in enumerate(rows):
+        if "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
+            starts.append(i - 1 if (i > 0 and "k_amax(" in rows[i - 1][0] and "k_split_t<true>" in r[0]) else i)
     assert len(starts) >= N_KEEP, "fewer steps than expected in the trace"
     bounds = starts[-N_KEEP:] + [len(rows)]
     return [rows[bounds[i]:bounds[i + 1]] for i in range(N_KEEP)]

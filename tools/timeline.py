@@ -5,8 +5,11 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
-# a step starts at k_im2row
-starts = [i for i, r in enumerate(rows) if "k_im2row" in r[0]]
+# a step starts at the maximum over the raw input + the fused im2row / S16 split (k_im2row on the older path)
+starts = []
+for i, r in enumerate(rows):
+    if "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
+        starts.append(i - 1 if (i > 0 and "k_amax(" in rows[i - 1][0] and "k_split_t<true>" in r[0]) else i)
 lo = starts[-1]
 t0 = rows[lo][1]
 last_end = t0
