@@ -6,7 +6,8 @@ Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
 
 Writes tests/golden/*.npz (small-channel full-tensor fixtures) and tests/golden/kat_c1024.json
-(known-answer checksums for seed-initialised C=1024 models).  The fixtures pin
+(known-answer checksums for seed-initialised C=1024 models) and tests/golden/kat_matrix.npz (the C=1024 seed x arc x
+causal x class matrix: outputs in full, gradients and running statistics as norm + seeded projection).  The fixtures pin
 oracle/temporal_oracle.py (tests/test_oracle_golden.py) and, on the GPU, the HIP path
 (tests/test_gpu_*.py).  Nothing here is copied from the reference: it is only *executed*.
 """
@@ -131,6 +132,32 @@ def make_kat():
         print("kat", kind, fw, "y_sum", kats[-1]["y_sum"], "params", n_params)
     with open(os.path.join(HERE, "kat_c1024.json"), "w") as f:
         json.dump(kats, f, indent=1)
+
+
+def make_kat_matrix():
+    """seeds {0,1,2} x arcs {3,3,3 / 3,3,3,3,3} x causal x both classes at C = 1024 (SURVEY 8c's matrix): eval output
+    (T = RF+57 for the dilated class), train-mode output + loss with dropout 0, and norm + one seeded projection of every
+    parameter gradient and post-step running statistic.  tests/util.py holds the recipe both sides follow."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.util import kat_matrix_build, kat_matrix_cases, kat_matrix_summaries
+    out = {}
+    for case in kat_matrix_cases():
+        model, x_eval, x_train, target, proj = kat_matrix_build(case, TemporalModel, TemporalModelOptimized1f)
+        n = case["name"]
+        model.eval()
+        with torch.no_grad():
+            out[n + "|y_eval"] = model(x_eval).numpy().copy()
+        model.train()
+        y = model(x_train)
+        loss = mpjpe(y, target)
+        loss.backward()
+        out[n + "|y_train"] = y.detach().numpy().copy()
+        out[n + "|loss"] = np.float64(loss.item())
+        out[n + "|x_sums"] = np.array([x_eval.double().sum(), x_train.double().sum(), target.double().sum()])
+        for k, v in kat_matrix_summaries(model, proj).items():
+            out[n + "|" + k] = np.array(v, np.float64)
+        print("kat_matrix", n, "loss %.6f" % loss.item())
+    np.savez_compressed(os.path.join(HERE, "kat_matrix.npz"), **out)
 
 
 def make_camera():
@@ -279,12 +306,12 @@ CASES = [
     ("dil_333_c64_drop", "dilated", [3, 3, 3], False, 64, dict(dropout=0.25, batch=3, extra_t=4, seed=5)),
     ("dil_353_c64_dense", "dilated", [3, 5, 3], False, 64, dict(dense=True, batch=2, extra_t=3, seed=3)),
 ]
-EXTRA = {"kat": make_kat, "camera": make_camera, "semi_step": make_semi, "train_loop": make_train_loop}
+EXTRA = {"kat": make_kat, "kat_matrix": make_kat_matrix, "camera": make_camera, "semi_step": make_semi, "train_loop": make_train_loop}
 
 
 if __name__ == "__main__":
     # python tests/golden/make_golden.py            -> everything
-    # python tests/golden/make_golden.py NAME ...   -> only the named fixtures (case names, kat, camera, semi_step, train_loop)
+    # python tests/golden/make_golden.py NAME ...   -> only the named fixtures (case names, kat, kat_matrix, camera, semi_step, train_loop)
     torch.set_num_threads(4)
     want = set(sys.argv[1:])
     known = {c[0] for c in CASES} | set(EXTRA)

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import temporal_oracle as O
-from tests.util import golden_names, load_golden, mpjpe_np, rel_err, GOLDEN
+from tests.util import (golden_names, load_golden, mpjpe_np, rel_err, GOLDEN, kat_matrix_build, kat_matrix_cases,
+                        load_kat_matrix, KAT_GRAD_TOL)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -112,3 +113,32 @@ def test_oracle_evaluation_protocol_golden():
         frames += tgt.shape[0]
     assert frames == int(g["tta/frames"])
     assert abs(total / frames * 1000 - float(g["tta/e1_mm"])) < 1e-2
+
+
+@pytest.mark.parametrize("case", [c for c in kat_matrix_cases() if c["seed"] == 0], ids=lambda c: c["name"])
+def test_oracle_kat_matrix_c1024(case):
+    """SURVEY 8(c)'s matrix at the benchmark width: the oracle, fed the seed-built state (the package's constructors draw
+    the reference's parameters: tests/test_host_cpu.py), against what the reference classes produced from the same
+    recipe -- outputs entry-wise, gradients and running statistics through norm + a seeded projection
+    (tests/util.py: why that tolerance is 1e-2).  Seed 0 here (CPU time); the GPU suite runs all three seeds."""
+    import torch
+    import videopose3d_amd as V
+    ref = load_kat_matrix()[case["name"]]
+    model, x_eval, x_train, target, proj = kat_matrix_build(case, V.TemporalModel, V.TemporalModelOptimized1f)
+    assert abs(float(x_eval.double().sum()) - ref["x_sums"][0]) < 1e-6          # same RNG stream as the generator run
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    kw = dict(causal=case["causal"], kind=case["kind"])
+    y, _, _ = O.forward(sd, x_eval.numpy(), case["filter_widths"], training=False, **kw)
+    assert y.shape == ref["y_eval"].shape and mpjpe_np(y, ref["y_eval"]) < 1e-5
+    y, cache, running = O.forward(sd, x_train.numpy(), case["filter_widths"], training=True, dropout_masks=None,
+                                  momentum=0.1, **kw)
+    assert mpjpe_np(y, ref["y_train"]) < 1e-5
+    assert abs(O.mpjpe(y, target.numpy()) - float(ref["loss"])) < 1e-5
+    grads = O.backward(cache, O.mpjpe_grad(y, target.numpy()))
+    for k, g in grads.items():
+        norm, pr = ref["grad/" + k]
+        assert abs(np.linalg.norm(g.astype(np.float64)) - norm) < KAT_GRAD_TOL * norm, k
+        assert abs(float((g.astype(np.float64) * proj[k].double().numpy()).sum()) - pr) < KAT_GRAD_TOL * norm, k
+    for k, v in running.items():
+        norm, pr = ref["stat/" + k]
+        assert abs(float((np.asarray(v, np.float64) * proj[k].double().numpy()).sum()) - pr) < 1e-5 * max(norm, 1.0), k

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    special = {"camera", "semi_step", "train_loop", "step_generators", "step_loss", "step_adam", "eval_protocol"}          # fixtures with their own layout / tests
+    special = {"camera", "semi_step", "train_loop", "step_generators", "step_loss", "step_adam", "eval_protocol", "kat_matrix"}          # fixtures with their own layout / tests
     return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
                   if n not in special)
 
@@ -95,3 +95,82 @@ def unpack_act_bits(bits, m_rows, c):
     b = np.asarray(bits.detach().cpu().numpy() if hasattr(bits, "detach") else bits, np.uint8).reshape(c // 64, m_rows, 8)
     u = np.unpackbits(b[..., None], axis=-1, bitorder="little")            # [tile][m][byte][bit]
     return u.transpose(1, 0, 2, 3).reshape(m_rows, c).astype(bool)
+
+
+# ---- C = 1024 known-answer matrix (tests/golden/make_golden.py kat_matrix -> tests/golden/kat_matrix.npz) -----
+# Weights are not stored: they follow from torch.manual_seed(seed) + the constructor (tests/test_host_cpu.py pins that the
+# package's classes draw the same parameters as the reference's); BatchNorm state, inputs, targets and the projection
+# vectors follow from a second seeded generator.  The generator script runs this recipe with the REFERENCE classes, the
+# tests with the package's (or feed the state to the oracle).
+KAT_GRAD_TOL = 1e-2
+
+
+def kat_matrix_cases():
+    out = []
+    for seed in (0, 1, 2):
+        for fw in ((3, 3, 3), (3, 3, 3, 3, 3)):
+            for causal in (False, True):
+                for kind in ("dilated", "strided"):
+                    out.append(dict(name="%s_%s_s%d%s" % (kind[:3], "".join(map(str, fw)), seed, "_causal" if causal else ""),
+                                    kind=kind, filter_widths=list(fw), causal=causal, seed=seed))
+    return out
+
+
+def kat_matrix_build(case, dilated_cls, strided_cls, channels=1024):
+    """(model on CPU in train mode with dropout 0, x_eval, x_train, target, {param name: projection vector})."""
+    import torch
+    torch.manual_seed(case["seed"])
+    cls = dilated_cls if case["kind"] == "dilated" else strided_cls
+    model = cls(17, 2, 17, case["filter_widths"], causal=case["causal"], dropout=0.0, channels=channels)
+    gen = torch.Generator().manual_seed(4242 + case["seed"])
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            if k.endswith("running_mean"):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=gen) * 0.1)
+            elif k.endswith("running_var"):
+                sd[k].copy_(torch.rand(sd[k].shape, generator=gen) * 1.5 + 0.5)
+            elif "bn" in k and k.endswith("weight"):
+                sd[k].copy_(1.0 + 0.2 * torch.randn(sd[k].shape, generator=gen))
+            elif "bn" in k and k.endswith("bias"):
+                sd[k].copy_(0.1 * torch.randn(sd[k].shape, generator=gen))
+    rf = model.receptive_field()
+    dil = case["kind"] == "dilated"
+    x_eval = (torch.randn(2, rf + (57 if dil else 0), 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    # 256 rows reach the last BatchNorm layers.  Gradient tolerance of this matrix (KAT_GRAD_TOL): any two fp32 evaluations
+    # of one step may disagree on the sign of a pre-activation that is zero to rounding; one such ReLU flip in a late
+    # layer moves every upstream gradient by ~ 1 / sqrt(rows x C) = 2e-3 of its norm (measured against the fp64 oracle:
+    # oracle-fp32, torch-fp32 and both GPU arithmetics each show 3e-4 .. 8e-3 on some case at 16 rows, 1e-6 on the
+    # others), and the bias gradients of inner BatchNorm layers are small differences of large sums (the next
+    # BatchNorm removes a per-channel shift).  Outputs, loss and running statistics are held to the usual bars.
+    x_train = (torch.randn(8 if dil else 256, rf + (31 if dil else 0), 17, 2, generator=gen) * 0.5).clamp(-1, 1)
+    target = torch.randn(x_train.shape[0], x_train.shape[1] - rf + 1, 17, 3, generator=gen) * 0.3
+    target[:, :, 0] = 0
+    proj = {k: torch.randn(p.shape, generator=gen) for k, p in sorted(model.named_parameters())}
+    for k in sorted(sd):
+        if "running" in k:
+            proj[k] = torch.randn(sd[k].shape, generator=gen)
+    return model, x_eval, x_train, target, proj
+
+
+def kat_matrix_summaries(model, proj):
+    """After loss.backward() on `model` (any device): {key: [norm, projection]} for every parameter gradient and
+    every BatchNorm running statistic, in float64."""
+    out = {}
+    for k, p in model.named_parameters():
+        g = p.grad.detach().double().cpu()
+        out["grad/" + k] = [float(g.norm()), float((g * proj[k].double()).sum())]
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            v = v.detach().double().cpu()
+            out["stat/" + k] = [float(v.norm()), float((v * proj[k].double()).sum())]
+    return out
+
+
+def load_kat_matrix():
+    z = np.load(os.path.join(GOLDEN, "kat_matrix.npz"))
+    out = {}
+    for k in z.files:
+        name, key = k.split("|", 1)
+        out.setdefault(name, {})[key] = z[k]
+    return out
