@@ -68,8 +68,11 @@ typedef struct vp3d_rowmap {
 } vp3d_rowmap;
 
 /* Counter-based dropout (Philox4x32-10): element e of layer `layer` is kept iff
- * uniform(Philox(key=seed, counter=(e>>2, layer, offset))[e&3]) >= p; kept values are scaled by 1/(1-p).
- * The mask is never stored: backward regenerates it from the same (seed, offset, layer). */
+ * u16(e) >= round(p * 65536), where u16(e) is 16-bit half (e & 1) of word ((e & 7) >> 1) of
+ * Philox(key=seed, counter=(e>>3, layer, offset)): one block serves 8 elements, the keep probability is exact for p = 0.25
+ * and within 7.6e-6 of 1 - p otherwise; kept values are scaled by 1/(1-p).
+ * The mask is never stored as a tensor: backward regenerates it from the same (seed, offset, layer), or reads the
+ * forward's activation bits (split-fp16 engine). */
 typedef struct vp3d_dropout {
   float p;
   uint64_t seed;

@@ -9,10 +9,12 @@ namespace vp3d {
 
 // ---------------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: the dropout mask is a pure function of
-// (seed, offset, layer, element index) and is regenerated in backward instead of being stored.
+// (seed, offset, layer, element index): backward regenerates it (fp32 engine) or reads the forward's activation bits
+// (split-fp16 engine); it is never stored as a tensor.
 // ---------------------------------------------------------------------------------------------------------
 struct DropP {
   float p, inv_keep;
+  uint32_t thr;              // an element is dropped when its 16 random bits are < thr = round(p * 65536)
   uint32_t k0, k1, off_lo, layer;
   int on;
   const uint64_t* off_ptr;   // optional device-side step counter added to the offset (hipGraph replays: the launch
@@ -39,15 +41,30 @@ __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, u
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// keep*scale factors of the 4 elements 4*q .. 4*q+3
+// One Philox block (128 bits) serves the 8 elements 8*q8 .. 8*q8+7, 16 random bits each: element e takes the low (e even) or
+// high (e odd) half of word e / 2.  The keep probability is 1 - round(p * 65536) / 65536: exact for p = 0.25, within 7.6e-6
+// of 1 - p otherwise.  (Round 1 spent a block per 4 elements, 24 bits each: the 20 quarter-rate multiplies of a block were
+// half of the VALU work of the activation epilogues.)
+__device__ __forceinline__ void drop8(const DropP& d, uint64_t q8, float (&mk)[8]) {
+  uint32_t r[4];
+  philox4((uint32_t)q8, (uint32_t)(q8 >> 32), d.layer, d.off_lo, d.k0, d.k1, r);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint32_t u = (e & 1) ? (r[e >> 1] >> 16) : (r[e >> 1] & 0xffffu);
+    mk[e] = (u >= d.thr) ? d.inv_keep : 0.f;
+  }
+}
+
+// keep*scale factors of the 4 elements 4*q .. 4*q+3 (the same mask: half of the block of q / 2)
 __device__ __forceinline__ void drop4(const DropP& d, uint64_t q, float (&mk)[4]) {
   uint32_t r[4];
-  philox4((uint32_t)q, (uint32_t)(q >> 32), d.layer, d.off_lo, d.k0, d.k1, r);
+  const uint64_t q8 = q >> 1;
+  philox4((uint32_t)q8, (uint32_t)(q8 >> 32), d.layer, d.off_lo, d.k0, d.k1, r);
+  const bool up = (q & 1) != 0;
+  const uint32_t ra = up ? r[2] : r[0], rb = up ? r[3] : r[1];
+  const uint32_t u[4] = {ra & 0xffffu, ra >> 16, rb & 0xffffu, rb >> 16};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float u = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
-    mk[e] = (u >= d.p) ? d.inv_keep : 0.f;
-  }
+  for (int e = 0; e < 4; ++e) mk[e] = (u[e] >= d.thr) ? d.inv_keep : 0.f;
 }
 
 
@@ -56,6 +73,7 @@ inline DropP make_drop(const vp3d_dropout* d) {
   r.on = (d != nullptr && d->p > 0.f) ? 1 : 0;
   r.p = r.on ? d->p : 0.f;
   r.inv_keep = r.on ? 1.0f / (1.0f - d->p) : 1.f;
+  r.thr = r.on ? (uint32_t)(d->p * 65536.0f + 0.5f) : 0u;
   r.k0 = r.on ? (uint32_t)d->seed : 0u;
   r.k1 = r.on ? (uint32_t)(d->seed >> 32) : 0u;
   r.off_lo = r.on ? (uint32_t)d->offset : 0u;

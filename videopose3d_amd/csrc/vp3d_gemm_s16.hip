@@ -592,14 +592,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
         const int64_t e0 = (int64_t)m * p.N + n8;      // element index in the [M][N] activation (the mask's counter)
         float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
         if (d.on) {
-          float ma[4], mb[4];
-          drop4(d, (uint64_t)(e0 >> 2), ma);
-          drop4(d, (uint64_t)(e0 >> 2) + 1, mb);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            mk[c] = ma[c];
-            mk[4 + c] = mb[c];
-          }
+          drop8(d, (uint64_t)(e0 >> 3), mk);             // (e0 % 8 == 0: N % 8 == 0, n8 % 8 == 0)
         }
         float v[8];
         uint32_t bits = 0;

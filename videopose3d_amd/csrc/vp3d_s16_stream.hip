@@ -94,14 +94,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
       const f32x4 y1 = *reinterpret_cast<const f32x4*>(y + e0 + 4);
       float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
       if (d.on) {
-        float a[4], b[4];
-        drop4(d, (uint64_t)(e0 >> 2), a);
-        drop4(d, (uint64_t)(e0 >> 2) + 1, b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          mk[e] = a[e];
-          mk[4 + e] = b[e];
-        }
+        drop8(d, (uint64_t)(e0 >> 3), mk);               // (e0 % 8 == 0: C % 64 == 0, c % 8 == 0)
       }
       float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (rm.res != nullptr) {
@@ -225,14 +218,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_s16(int M, int C, const fl
 #pragma unroll
           for (int e = 0; e < 8; ++e) mk[e] = 1.f;
           if (d.on) {
-            float a[4], b[4];
-            drop4(d, (uint64_t)(e0 >> 2), a);
-            drop4(d, (uint64_t)(e0 >> 2) + 1, b);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              mk[e] = a[e];
-              mk[4 + e] = b[e];
-            }
+            drop8(d, (uint64_t)(e0 >> 3), mk);
           }
         }
 #pragma unroll
