@@ -37,6 +37,9 @@ CASES = [  # (B, T, spec, cfg, splits)
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 20, 1),
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 22, 1),
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 13, 1),
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 26, 1),        # 256x256 by four waves of 128x128 (accumulators in AGPRs)
+    (5, 27, ConvSpec(160, 96, 3, 1, 3), 26, 3),         # ... ragged N, split-K
+    (11, 67, ConvSpec(64, 2368, 1), 26, 1),
     (5, 27, ConvSpec(160, 96, 3, 1, 3), 0, 1),          # N = 96 (ragged column tile), strided
     (5, 27, ConvSpec(160, 96, 3, 1, 3), 22, 3),         # split-K + finishing pass
     (5, 27, ConvSpec(160, 96, 3, 1, 3), 21, 1),         # register-pipelined fragments, ragged N
@@ -267,7 +270,7 @@ def test_unsupported_configurations_fall_back_to_fp32_kernels():
     assert engine.use_s16(big, 243, True, batch=1024) and not engine.use_s16(big, 243, True, batch=64)
 
 
-@pytest.mark.parametrize("cfg", [20, 22])
+@pytest.mark.parametrize("cfg", [20, 22, 26])
 def test_s16_output_and_s16_residual_chain(cfg):
     """Eval chaining: the epilogue writes S16 rows under the device-evaluated one-layer bound l1[0]*amax(in)+l1[1]+amax(res),
     reads an S16 residual, and still measures the true maximum."""
@@ -482,7 +485,7 @@ def test_gather_transposed_operand_vs_torch():
 
 
 @pytest.mark.parametrize("kc", [(128, 256), (96, 64), (64, 1024)])
-@pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1)])
+@pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1), (0.25, 26)])
 def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg, kc):
     """The expand layer's fused forward: pass 1 (no_output) writes only the BatchNorm slab statistics, pass 2 applies
     BatchNorm + ReLU + dropout in the GEMM epilogue and writes S16 rows + activation bits -- bit for bit what

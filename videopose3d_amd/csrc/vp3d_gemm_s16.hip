@@ -1407,6 +1407,10 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     // per-wave operand reuse of the 256x256 tiling, but one workgroup's epilogue / barrier waits run under the other's MFMAs
     case 24: rc = launch_cfg<Cfg<2, 2, 4, 2, 3, 16, 0, 1>>(s, a, splits); break;   // 256x128
     case 25: rc = launch_cfg<Cfg<2, 2, 2, 4, 3, 16, 0, 1>>(s, a, splits); break;   // 128x256
+    // 256x256 by FOUR waves of 128x128 (one per SIMD; the 256 accumulator registers of a wave live in AGPRs): a third
+    // fewer LDS fragment reads per MFMA than the 8-wave tiling, but nothing runs under a wave's stage-start LDS latency
+    // and barrier wait: measured 8 % slower than cfg 22 on the large shapes
+    case 26: rc = launch_cfg<Cfg<2, 2, 4, 4, 2, 32, 0, 1>>(s, a, splits); break;
     default:
       set_error("nt_s16: unknown tile configuration %d", cfg);
       return VP3D_E_INVALID;
