@@ -59,6 +59,25 @@ __device__ __forceinline__ void s16_join8(const f16x8& hi, const f16x8& lo, floa
   for (int j = 0; j < 8; ++j) v[j] = ((float)hi[j] + (float)lo[j]) * scale;
 }
 
+// n / d for 0 <= n < 2^31, 1 <= d < 2^31, as one 32 x 32 -> 64 multiply and a shift (the row -> (sample, frame) split of the
+// streaming kernels: a 64-bit integer division is ~120 VALU instructions, as much as the rest of a row's work).
+// s = ceil(log2 d), mul = ceil(2^(31+s) / d) <= 2^32 - 1:  n * mul / 2^(31+s) = n/d + n*e/2^(31+s) with 0 <= e < 1, and
+// n*e / 2^(31+s) < 2^-s <= 1/d, so the floor is exact.
+struct FastDiv {
+  uint32_t mul, shift, d;
+};
+inline FastDiv make_fastdiv(int64_t d_) {
+  FastDiv f;
+  const uint64_t d = d_ > 0 ? (uint64_t)d_ : 1;
+  uint32_t s = 0;
+  while (((uint64_t)1 << s) < d) ++s;
+  f.shift = 31 + s;
+  f.mul = (uint32_t)((((uint64_t)1 << f.shift) + d - 1) / d);
+  f.d = (uint32_t)d;
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) { return (uint32_t)(((uint64_t)n * f.mul) >> f.shift); }
+
 __device__ __forceinline__ float s16_pow2(int e) { return ldexpf(1.0f, e); }
 
 // "activation bits": one byte per (row, 8 consecutive channels), bit e = [bn(y) > 0 and the element was kept by the

@@ -62,6 +62,7 @@ struct ResS16 {
   const float* res;           // S16 rows
   const float* bound;
   int t_dst, r_t, r_stride, r_off, r_ld;
+  FastDiv div_t;              // row m -> sample m / t_dst
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -98,8 +99,8 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd_s16(int M, int C, const floa
       }
       float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (rm.res != nullptr) {
-        const int b = (int)(m / rm.t_dst);
-        const int tt = (int)(m - (int64_t)b * rm.t_dst);
+        const int b = (int)fastdiv((uint32_t)m, rm.div_t);
+        const int tt = (int)m - b * rm.t_dst;
         const f16x8* rp = reinterpret_cast<const f16x8*>(
             rm.res + ((int64_t)b * rm.r_t + (int64_t)tt * rm.r_stride + rm.r_off) * rm.r_ld + c);
         s16_join8(rp[0], rp[1], rscale, rv);
@@ -439,6 +440,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_strips(int M, int C, int 
 // behind them, 1 in column one_col (vp3d_im2row's rows, never materialised)
 struct Im2Row {
   int t_dst, t_src, t_stride, ldx, k_valid, one_col;
+  FastDiv div_t;
 };
 
 // fp32 rows [M][C] (pitch ld_src; IM2ROW: gathered, see above) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __re
     float v[8];
     if (m < M) {
       if (IM2ROW) {
-        const int b = (int)(m / g.t_dst), tt = (int)(m - (int64_t)b * g.t_dst);
+        const int b = (int)fastdiv((uint32_t)m, g.div_t), tt = (int)m - b * g.t_dst;
         const float* row = src + ((int64_t)b * g.t_src + (int64_t)tt * g.t_stride) * g.ldx;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (c + e < g.k_valid ? row[c + e] : (c + e == g.one_col ? 1.f : 0.f)) * inv;
@@ -925,7 +927,7 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   if (rc) return rc;
   if (drop) VP3D_REQUIRE(drop->p >= 0.f && drop->p < 1.f, "bn_act_fwd_s16: dropout p=%f", drop->p);
   const DropP d = make_drop(drop);
-  ResS16 rm{(const float*)res, res_bound, t_dst > 0 ? t_dst : 1, r_t, r_stride, r_off, r_ld};
+  ResS16 rm{(const float*)res, res_bound, t_dst > 0 ? t_dst : 1, r_t, r_stride, r_off, r_ld, make_fastdiv(t_dst)};
   TOut t{(float*)t_out, ld_t, t_out ? taps : 1};
   const int R = 64 * t.taps;
   VP3D_REQUIRE((M + R - 1) / R <= 65535, "bn_act_fwd_s16: more than 65535 row tiles (M=%lld)", (long long)M);
@@ -1120,7 +1122,7 @@ int vp3d_im2row_split_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const fl
   if (rc) return rc;
   TOut t{(float*)t_out, ld_t, 1};
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
-  const Im2Row g{map->t_dst, map->t_src, map->t_stride, ldx, k_valid, one_col < 0 ? -1 : one_col};
+  const Im2Row g{map->t_dst, map->t_src, map->t_stride, ldx, k_valid, one_col < 0 ? -1 : one_col, make_fastdiv(map->t_dst)};
   hipLaunchKernelGGL(k_split_t<true>, dim3(kpad / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, kpad,
                      x, (int64_t)0, bound, (float*)out, (int64_t)kpad, t, g);
   return check_launch("im2row_split_s16");
