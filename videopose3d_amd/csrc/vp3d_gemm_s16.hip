@@ -628,8 +628,33 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
     const int rc8 = n8 - e.r_col0;
     const bool rcol_ok8 = e.R != nullptr && rc8 >= 0 && rc8 < e.r_cols;
+    // Residual rows are fetched TWO 32-row blocks at a time, before the blocks' stores: a wave that mixes loads and stores
+    // only ever gets s_waitcnt vmcnt(0) from hipcc, so a load issued between stores exposes a full load + store latency
+    // (8 times per tile with the loads inside the row loop: ~22 us per round of 256x256 tiles).  The K loop's
+    // operand registers are dead here: 2 x NPS x 8 VGPRs hold the prefetched S16 groups.
+    constexpr int NPS = 32 / ERPP8;
+    constexpr bool PRE = !SK && NPS <= 4 && RB % 2 == 0;      // (the stream-K instances have no registers to spare)
+    f16x8 rh[PRE ? 2 * NPS : 1], rl[PRE ? 2 * NPS : 1];
+    auto fetch_res = [&](int i0) {
+#pragma unroll
+      for (int q = 0; q < 2 * NPS; ++q) {
+        const int lr = (wm * RB + i0 + q / NPS) * 32 + (q % NPS) * ERPP8 + rr8;
+        const int b = tab_b[lr], t = tab_t[lr];
+        const int tr = t * e.r_stride + e.r_off;
+        const bool ok = rcol_ok8 && m0 + lr < p.m_end && n8 < Nlim && (unsigned)tr < (unsigned)e.r_t;
+        const f16x8* rp = reinterpret_cast<const f16x8*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc8);
+        f16x8 z;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) z[c] = (_Float16)0.f;
+        rh[q] = ok ? rp[0] : z;
+        rl[q] = ok ? rp[1] : z;
+      }
+    };
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
+      if constexpr (PRE) {
+        if (i % 2 == 0 && e.R != nullptr) fetch_res(i);
+      }
 #pragma unroll
       for (int j = 0; j < CB; ++j)
 #pragma unroll
@@ -638,8 +663,8 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
           wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
         }
       epi_stage_sync();
-#pragma unroll 2
-      for (int ps = 0; ps < 32 / ERPP8; ++ps) {
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
         const int r = ps * ERPP8 + rr8;
         const int lr = (wm * RB + i) * 32 + r;
         if (m0 + lr >= p.m_end || n8 >= Nlim) continue;
@@ -648,10 +673,14 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const int b = tab_b[lr], t = tab_t[lr];
         float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int tr = t * e.r_stride + e.r_off;
-        if (rcol_ok8 && (unsigned)tr < (unsigned)e.r_t) {
-          const f16x8* rp = reinterpret_cast<const f16x8*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc8);
-          s16_join8(rp[0], rp[1], rscale, rv);
+        if constexpr (PRE) {
+          if (e.R != nullptr) s16_join8(rh[(i & 1) * NPS + ps], rl[(i & 1) * NPS + ps], rscale, rv);   // (zeros where there is none)
+        } else {
+          const int tr = t * e.r_stride + e.r_off;
+          if (rcol_ok8 && (unsigned)tr < (unsigned)e.r_t) {
+            const f16x8* rp = reinterpret_cast<const f16x8*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld + rc8);
+            s16_join8(rp[0], rp[1], rscale, rv);
+          }
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
