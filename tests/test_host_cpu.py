@@ -290,3 +290,49 @@ def test_dropout_seed_is_reproducible_across_processes():
             "print(a._next_dropout_state()[0], b._next_dropout_state()[0])\n")
     outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT).stdout.split() for _ in range(2)]
     assert len(outs[0]) == 2 and outs[0] == outs[1] and outs[0][0] != outs[0][1]
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """vp3d_s16.h's FastDiv (row -> (sample, frame) split of the streaming kernels): the host-side magic numbers against
+    plain division over edge cases and random (n, d) with 0 <= n < 2^31, 1 <= d < 2^31 (host build of the same header)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "fd.hip"
+    src.write_text(r'''
+#include "vp3d_s16.h"
+#include <cstdio>
+#include <cstdint>
+static uint64_t rng = 88172645463325252ull;
+static uint64_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; }
+static int check(uint32_t n, uint32_t d) {
+  const vp3d::FastDiv f = vp3d::make_fastdiv(d);
+  const uint32_t q = (uint32_t)(((uint64_t)n * f.mul) >> f.shift);      // = fastdiv() on the device
+  if (q != n / d) { printf("n=%u d=%u got %u want %u\n", n, d, q, n / d); return 1; }
+  return 0;
+}
+int main() {
+  const uint32_t top = 0x7fffffffu;
+  int bad = 0;
+  const uint32_t ds[] = {1, 2, 3, 5, 7, 9, 27, 81, 243, 1024, 1025, 65535, 65536, 65537, 0x3fffffffu, 0x40000000u, 0x40000001u, top - 1, top};
+  for (uint32_t d : ds) {
+    const uint32_t k = top / d;
+    const uint32_t ns[] = {0, 1, d - 1, d, d + 1 <= top ? d + 1 : top, k * d, k * d ? k * d - 1 : 0, top, top - 1};
+    for (uint32_t n : ns) bad += check(n & top, d);
+  }
+  for (int i = 0; i < 2000000; ++i) {
+    const uint32_t d = (uint32_t)(next() >> (33 + (next() % 31)));      // all magnitudes
+    bad += check((uint32_t)(next() & top), d ? d : 1);
+  }
+  printf("bad=%d\n", bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / "fd"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(root, "videopose3d_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:]
