@@ -105,6 +105,9 @@ def join(log_path, kt_db, fetch_db=None, write_db=None, mfma_db=None, json_out=N
     print("# roofline %.1f TFLOP/s of algorithmic work; MB_fetch = FETCH_SIZE x 2 (gfx950 correction), MB_write = WRITE_SIZE: separate"
           % peak)
     print("# --pmc passes; MB_alg = every operand once + the result once; busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x clocks)")
+    print("# launches below ~100 us depend on how fast the traced host refills the queue (an empty queue drops the clocks): three\n"
+          "# collections of the same build on three boxes agree within 3 % on the large launches and differ by 15-40 % on the\n"
+          "# small ones; bench.py's HIP-event numbers (untraced) are the reference for those")
     print("%-12s %7s %6s %6s %4s %3s  %-34s %9s %8s %6s %9s %9s %8s %6s %6s" % (
         "family", "M", "N", "K", "cfg", "ks", "kernel", "us", "TFLOP/s", "frac", "MB_fetch", "MB_write", "MB_alg", "busy", "GHz"))
     pos, fam = 0, {}
