@@ -336,3 +336,32 @@ int main() {
                     "-I", os.path.join(root, "videopose3d_amd", "csrc"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:]
+
+
+def test_engine_selection_rules(monkeypatch):
+    """Which arithmetic serves a call is host logic (engine.use_s16 / engine_s16.supported): pinned here so that a GPU
+    run cannot silently move a configuration to the other engine."""
+    from videopose3d_amd import engine, engine_s16
+    from videopose3d_amd.plan import ConvSpec
+    mk = lambda cls=V.TemporalModelOptimized1f, fw=(3, 3, 3), c=128, j=17, **kw: cls(j, 2, 17, list(fw), channels=c, **kw)
+    m = mk()
+    assert engine_s16.supported(m, 27, True) and engine_s16.supported(m, 27, False) and engine_s16.supported(m, 27, True, True)
+    assert not engine_s16.supported(mk(c=96), 27, True) and not engine_s16.supported(mk(c=96), 27, False)    # channels % 64
+    assert engine_s16.supported(mk(V.TemporalModel, c=64), 40, True)                        # dilated class, any window
+    assert not engine_s16.supported(mk(fw=(5, 3)), 15, True) and not engine_s16.supported(mk(fw=(5, 3)), 15, False)   # 5 x 34 = 170 columns
+    assert engine_s16.supported(mk(fw=(5, 3), j=10), 15, True) and engine_s16.supported(mk(fw=(5, 3), j=10), 15, False)  # 100 columns
+    assert engine_s16.supported(mk(j=5), 27, True) and not engine_s16.supported(mk(j=5), 27, False)          # 30 columns: train only
+    dense = mk(V.TemporalModel, fw=(3, 5, 3), c=64, dense=True)                             # dense kernels: 3, 7, 31 taps
+    assert not engine_s16.supported(dense, 50, True) and engine_s16.supported(dense, 50, False)
+    # the module attribute decides first, then the size threshold
+    m.math = "f32"
+    assert not engine.use_s16(m, 27, True, batch=1024)
+    m.math = "f16x3"
+    assert engine.use_s16(m, 27, True, batch=1 << 20) and not engine.use_s16(m, 27, True, batch=1)
+    # expand operand width and the 32-bit-offset guards
+    assert [engine_s16.expand_kpad(ConvSpec(k, 64, 3, 1, 3)) for k in (34, 30, 10, 42)] == [128, 128, 64, 128]
+    monkeypatch.delenv("VP3D_WGRAD_ROWS", raising=False)
+    assert engine_s16.wgrad_from_rows(1024, 1024, 1024 * 243) and not engine_s16.wgrad_from_rows(1024, 1024, 8192 * 243)
+    assert not engine_s16.wgrad_from_rows(128, 128, 100)
+    monkeypatch.setenv("VP3D_WGRAD_ROWS", "0")
+    assert not engine_s16.wgrad_from_rows(1024, 1024, 1024)
