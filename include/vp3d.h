@@ -233,6 +233,10 @@ int vp3d_expand_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t N, int32_t kpad
                         const void* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const float* out_bound, void* out, uint8_t* act_bits);
 /* Workspace of a vp3d_tconv_nt_s16 launch in configuration (cfg, splits): floats (0: none) and int32 tickets (0: none). */
+/* 1 when the library was built with -DVP3D_BUILD_EXPERIMENTS (the measured-and-not-adopted S16 GEMM instances: stream-K
+ * 120 / 122, register-pipelined 10 / 13 / 21 / 23, 256x128 / 128x256 pairs 24 / 25, four-wave 256x256 26, hybrid pair 30);
+ * the default build has only what the planner uses (20 / 22 and their flat-address forms 0 / 4) and rejects the others. */
+int vp3d_has_experiments(void);
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
                           int32_t* tickets);
 /* y = conv(x; wt) exactly as vp3d_tconv_fwd (same row gather, same epilogue), with x and wt in S16 form
@@ -414,6 +418,12 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                      float* save_mean, float* save_invstd);
+/* The same with the momentum read from device memory (momentum_dev[0]) at execution time: a launch captured into a
+ * hipGraph follows run.py's per-epoch set_bn_momentum (run.py:590-593, model.py:36-39) without a re-capture. */
+int vp3d_bn_finalize_dm(vp3d_stream_t stream, int32_t C, int64_t M, const float* stat_sum, const float* stat_m2,
+                        const float* gamma, const float* beta, float eps, const float* momentum_dev, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                        float* save_mean, float* save_invstd);
 
 /* out[m][c] = (res ? res[resrow(m)][c] : 0) + dropout(relu(y[m][c]*scale[c] + shift[c])).
  * resrow(m = b*t_dst + t) = b*r_t + t*r_stride + r_off (row pitch r_ld).  drop may be NULL (p = 0). */

@@ -160,6 +160,46 @@ def make_kat_matrix():
     np.savez_compressed(os.path.join(HERE, "kat_matrix.npz"), **out)
 
 
+def make_kat_grads():
+    """FULL reference gradients of four C = 1024 training steps (both arcs x causal, strided class, seed 0: the kat_matrix
+    recipe of tests/util.py): BatchNorm / shrink / expand-conv gradients whole, every C x C weight gradient as 64 seeded rows
+    (tests/util.kat_grad_rows), and the reference's ReLU decisions wherever its pre-activation is within 1e-4 of zero -- the
+    only places where another fp32 evaluation of the same step can legitimately decide differently.  The consumers count
+    such flips explicitly instead of widening a tolerance."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.util import kat_matrix_build, kat_grad_cases, kat_grad_rows, KAT_NEAR_ZERO
+    out = {}
+    for case in kat_grad_cases():
+        model, _, x_train, target, _ = kat_matrix_build(case, TemporalModel, TemporalModelOptimized1f)
+        n = case["name"]
+        bns = [model.expand_bn] + list(model.layers_bn)
+        zs = [None] * len(bns)
+        hooks = []
+        for i, bn in enumerate(bns):     # (the hook fires before the in-place ReLU overwrites the BatchNorm output)
+            hooks.append(bn.register_forward_hook(lambda mod, inp, o, i=i: zs.__setitem__(i, o.detach().permute(0, 2, 1).contiguous().clone())))
+        model.train()
+        y = model(x_train)
+        loss = mpjpe(y, target)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        out[n + "|loss"] = np.float64(loss.item())
+        for k, p_ in model.named_parameters():
+            g = p_.grad.detach()
+            rows = kat_grad_rows(k, tuple(g.shape))
+            out[n + "|grad/" + k] = (g if rows is None else g[rows]).numpy().copy()
+        n_cand = 0
+        for i, z in enumerate(zs):
+            flat = z.reshape(-1)
+            idx = torch.nonzero(flat.abs() < KAT_NEAR_ZERO).reshape(-1)
+            out[n + "|near_idx/%d" % i] = idx.numpy().astype(np.int64)
+            out[n + "|near_pos/%d" % i] = (flat[idx] > 0).numpy()
+            out[n + "|near_z/%d" % i] = flat[idx].numpy().copy()
+            n_cand += idx.numel()
+        print("kat_grads", n, "loss %.6f" % loss.item(), "near-zero pre-activations:", n_cand)
+    np.savez_compressed(os.path.join(HERE, "kat_grads.npz"), **out)
+
+
 def make_camera():
     gen = torch.Generator().manual_seed(7)
     n = 6
@@ -306,12 +346,12 @@ CASES = [
     ("dil_333_c64_drop", "dilated", [3, 3, 3], False, 64, dict(dropout=0.25, batch=3, extra_t=4, seed=5)),
     ("dil_353_c64_dense", "dilated", [3, 5, 3], False, 64, dict(dense=True, batch=2, extra_t=3, seed=3)),
 ]
-EXTRA = {"kat": make_kat, "kat_matrix": make_kat_matrix, "camera": make_camera, "semi_step": make_semi, "train_loop": make_train_loop}
+EXTRA = {"kat": make_kat, "kat_matrix": make_kat_matrix, "kat_grads": make_kat_grads, "camera": make_camera, "semi_step": make_semi, "train_loop": make_train_loop}
 
 
 if __name__ == "__main__":
     # python tests/golden/make_golden.py            -> everything
-    # python tests/golden/make_golden.py NAME ...   -> only the named fixtures (case names, kat, kat_matrix, camera, semi_step, train_loop)
+    # python tests/golden/make_golden.py NAME ...   -> only the named fixtures (case names, kat, kat_matrix, kat_grads, camera, semi_step, train_loop)
     torch.set_num_threads(4)
     want = set(sys.argv[1:])
     known = {c[0] for c in CASES} | set(EXTRA)

@@ -31,6 +31,17 @@ def _ref_conv(x, w, spec, bias=None):
     return y.permute(0, 2, 1), den.permute(0, 2, 1)
 
 
+EXPERIMENT_CFGS = {10, 13, 21, 23, 24, 25, 26, 30, 120, 122}
+
+
+def need_cfg(cfg):
+    """Tile configurations the planner never picks are built only with -DVP3D_BUILD_EXPERIMENTS (include/vp3d.h:
+    vp3d_has_experiments); the default library rejects them -- their tests then have nothing to certify."""
+    from videopose3d_amd import _lib
+    if cfg in EXPERIMENT_CFGS and not _lib.lib().vp3d_has_experiments():
+        pytest.skip("tile configuration %d: library built without VP3D_BUILD_EXPERIMENTS" % cfg)
+
+
 CASES = [  # (B, T, spec, cfg, splits)
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 0, 1),
     (8, 27, ConvSpec(256, 256, 3, 3, 1), 4, 1),
@@ -58,6 +69,7 @@ CASES = [  # (B, T, spec, cfg, splits)
     c[0], c[1], c[2].c_in, c[2].c_out, c[2].taps, c[2].dil, c[2].stride, c[3], c[4]))
 def test_nt_gemm_vs_fp64(case):
     b, t, spec, cfg, splits = case
+    need_cfg(cfg)
     g = torch.Generator().manual_seed(3)
     x = (torch.relu(torch.randn(b, t, spec.c_in, generator=g)) * 1.3).to(DEV)
     w = ((torch.rand(spec.c_out, spec.c_in, spec.taps, generator=g) * 2 - 1) * 0.03).to(DEV)
@@ -274,6 +286,7 @@ def test_unsupported_configurations_fall_back_to_fp32_kernels():
 def test_s16_output_and_s16_residual_chain(cfg):
     """Eval chaining: the epilogue writes S16 rows under the device-evaluated one-layer bound l1[0]*amax(in)+l1[1]+amax(res),
     reads an S16 residual, and still measures the true maximum."""
+    need_cfg(cfg)
     g = torch.Generator().manual_seed(13)
     b, t, c = 5, 40, 128
     spec = ConvSpec(c, c, 3, 3, 1)
@@ -490,6 +503,7 @@ def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg, kc):
     """The expand layer's fused forward: pass 1 (no_output) writes only the BatchNorm slab statistics, pass 2 applies
     BatchNorm + ReLU + dropout in the GEMM epilogue and writes S16 rows + activation bits -- bit for bit what
     vp3d_bn_act_fwd_s16 makes of the stored conv output."""
+    need_cfg(cfg)
     g = torch.Generator().manual_seed(17)
     b, t = 37, 27                                       # M = 999: ragged last tile
     k, c = kc
@@ -532,6 +546,7 @@ def test_stream_k_equals_plain_launch(cfg, shape):
     """Stream-K configurations (shared K-tiles of the last round + in-kernel fix-up by the last contributor): same result as
     the plain launch of the same tiling up to the summation order of the K ranges (fp32 accumulators: ~1e-6 of sum|a||b|),
     fused epilogue included (bias, ReLU, residual, BatchNorm slab statistics, amax) -- and bit-identical run to run."""
+    need_cfg(cfg)
     b, t, c_in, c_out, taps = shape
     g = torch.Generator().manual_seed(cfg + b)
     spec = ConvSpec(c_in, c_out, taps, 1, taps) if taps > 1 else ConvSpec(c_in, c_out, 1)

@@ -5,7 +5,8 @@ import pytest
 
 from oracle import temporal_oracle as O
 from tests.util import (golden_names, load_golden, mpjpe_np, rel_err, GOLDEN, kat_matrix_build, kat_matrix_cases,
-                        load_kat_matrix, KAT_GRAD_TOL)
+                        load_kat_matrix, KAT_GRAD_TOL, kat_grad_cases, kat_grad_rows, kat_reference_relu_pos, load_kat_grads,
+                        KAT_FULL_GRAD_TOL)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -142,3 +143,32 @@ def test_oracle_kat_matrix_c1024(case):
     for k, v in running.items():
         norm, pr = ref["stat/" + k]
         assert abs(float((np.asarray(v, np.float64) * proj[k].double().numpy()).sum()) - pr) < 1e-5 * max(norm, 1.0), k
+
+
+@pytest.mark.parametrize("case", kat_grad_cases(), ids=lambda c: c["name"])
+def test_oracle_full_gradients_c1024_vs_reference(case):
+    """Tensor-level gradients at the benchmark width against the reference's own run (tests/golden/kat_grads.npz: BatchNorm /
+    shrink / expand-conv gradients whole, every C x C weight gradient as 64 seeded rows), at 5e-4 of each tensor's maximum --
+    the bar of the small fixtures, NOT the 1e-2 norm / projection bar of the matrix.  What made that bar necessary is handled
+    explicitly: the fixture also holds the reference's ReLU decisions wherever its pre-activation is within 1e-4 of zero; the
+    oracle's own decisions are counted against them (flips), then pinned to the reference's for the comparison."""
+    import videopose3d_amd as V
+    ref = load_kat_grads()[case["name"]]
+    model, _, x_train, target, _ = kat_matrix_build(case, V.TemporalModel, V.TemporalModelOptimized1f)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    y, cache, _ = O.forward(sd, x_train.numpy(), case["filter_widths"], training=True, dropout_masks=None, momentum=0.1,
+                            causal=case["causal"], kind=case["kind"])
+    assert abs(O.mpjpe(y, target.numpy()) - float(ref["loss"])) < 1e-5
+    n_layers = len(cache["layers"])
+    for i, L in enumerate(cache["layers"]):          # the oracle's pre-activations agree with the reference's where those are tiny
+        z = L["z"].reshape(-1)[ref["near_idx/%d" % i]]
+        assert np.abs(z - ref["near_z/%d" % i]).max() < 2e-5, i
+    own = [L["z"] > 0 for L in cache["layers"]]
+    pos, flips = kat_reference_relu_pos(own, ref, n_layers)
+    total = sum(p.size for p in own)
+    assert flips <= max(3, 2e-6 * total), (flips, total)
+    grads = O.backward(cache, O.mpjpe_grad(y, target.numpy()), relu_pos=pos)
+    for k, g in grads.items():
+        rows = kat_grad_rows(k, g.shape)
+        got = g if rows is None else g[rows.numpy()]
+        assert rel_err(got, ref["grad/" + k]) < KAT_FULL_GRAD_TOL, (k, rel_err(got, ref["grad/" + k]), flips)

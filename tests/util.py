@@ -167,6 +167,50 @@ def kat_matrix_summaries(model, proj):
     return out
 
 
+# ---- full reference gradients for four of the matrix's cases (tests/golden/make_golden.py kat_grads -> kat_grads.npz) ----
+KAT_NEAR_ZERO = 1e-4          # |pre-activation| below which the reference's ReLU decision is stored (flip candidates)
+KAT_FULL_GRAD_TOL = 5e-4      # max-norm relative, per tensor -- with the ReLU decisions accounted for, not absorbed
+KAT_GRAD_ROWS = 64
+
+
+def kat_grad_cases():
+    return [c for c in kat_matrix_cases() if c["kind"] == "strided" and c["seed"] == 0]
+
+
+def kat_grad_rows(name, shape):
+    """Rows (output channels) of a C x C conv weight gradient that the fixture stores: 64 seeded ones; None = whole tensor."""
+    import torch
+    if not (name.startswith("layers_conv") and len(shape) == 3 and shape[0] > KAT_GRAD_ROWS and shape[1] > KAT_GRAD_ROWS):
+        return None
+    gen = torch.Generator().manual_seed(97 + sum(ord(ch) for ch in name))
+    return torch.sort(torch.randperm(shape[0], generator=gen)[:KAT_GRAD_ROWS]).values
+
+
+def load_kat_grads():
+    z = np.load(os.path.join(GOLDEN, "kat_grads.npz"))
+    out = {}
+    for k in z.files:
+        name, key = k.split("|", 1)
+        out.setdefault(name, {})[key] = z[k]
+    return out
+
+
+def kat_reference_relu_pos(own_pos, ref, n_layers):
+    """ReLU decisions of the reference for one kat_grads case, given another fp32 evaluation's decisions `own_pos` (list of
+    bool arrays [B,T,C]): identical except where the reference stored a near-zero pre-activation with the other sign.
+    Returns (pos as the reference decided, number of flips).  Outside the stored candidates |z_ref| >= KAT_NEAR_ZERO, two
+    fp32 evaluations agreeing to ~1e-6 cannot differ in sign there."""
+    pos, flips = [], 0
+    for i in range(n_layers):
+        p = np.array(own_pos[i], dtype=bool, copy=True)
+        flat = p.reshape(-1)
+        idx, rp = ref["near_idx/%d" % i], ref["near_pos/%d" % i].astype(bool)
+        flips += int((flat[idx] != rp).sum())
+        flat[idx] = rp
+        pos.append(p)
+    return pos, flips
+
+
 def load_kat_matrix():
     z = np.load(os.path.join(GOLDEN, "kat_matrix.npz"))
     out = {}

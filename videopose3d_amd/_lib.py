@@ -79,6 +79,7 @@ SIGNATURES = {
     "vp3d_amax_floor": (C.c_int, [_vp, _i64, _vp, _f32, _vp]),
     "vp3d_expand_fwd_s16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp]),
     "vp3d_expand_bwd_p_s16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _vp, _vp, _P(_i32)]),
+    "vp3d_has_experiments": (C.c_int, []),
     "vp3d_nt_s16_workspace": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _i32, _P(_i64), _P(_i32)]),
     "vp3d_tconv_nt_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
                                     _P(S16Opts)]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "vp3d_im2row": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _i32, _vp]),
     "vp3d_bn_fold": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vp3d_bn_finalize": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_bn_finalize_dm": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_bn_act_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _P(Dropout), _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vp3d_bn_bwd_reduce": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _P(_i32)]),
     "vp3d_bn_bwd_finalize": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),

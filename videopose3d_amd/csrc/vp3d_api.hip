@@ -296,6 +296,8 @@ int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kp
                                  *nparts, partials, gram_partials);
 }
 
+int vp3d_has_experiments(void) { return nt_s16_has_experiments(); }
+
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
                           int32_t* tickets) {
   VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && ws_floats && tickets, "nt_s16_workspace: bad argument");

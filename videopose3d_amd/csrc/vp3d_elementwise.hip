@@ -20,9 +20,13 @@ constexpr int FIN_CH = 16, FIN_GROUPS = 64;
 
 __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
     int C, int64_t M, int nslab, const float* __restrict__ psum, const float* __restrict__ pm2,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-    float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean, float* save_invstd) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum_arg,
+    const float* __restrict__ momentum_dev, float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+    float* save_mean, float* save_invstd) {
   __shared__ double s1[FIN_GROUPS][FIN_CH], s2[FIN_GROUPS][FIN_CH];
+  // momentum from device memory when given: a captured launch (hipGraph replay) then follows run.py's per-epoch
+  // set_bn_momentum without a re-capture
+  const float momentum = momentum_dev != nullptr ? momentum_dev[0] : momentum_arg;
   const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   double a1 = 0.0, a2 = 0.0;
@@ -510,9 +514,23 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
                "bn_finalize: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
   hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
-                     stat_m2, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
-                     save_mean, save_invstd);
+                     stat_m2, gamma, beta, eps, momentum, (const float*)nullptr, running_mean, running_var, num_batches_tracked,
+                     scale, shift, save_mean, save_invstd);
   return check_launch("bn_finalize");
+}
+
+int vp3d_bn_finalize_dm(vp3d_stream_t stream, int32_t C, int64_t M, const float* stat_sum, const float* stat_m2,
+                        const float* gamma, const float* beta, float eps, const float* momentum_dev, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                        float* save_mean, float* save_invstd) {
+  VP3D_REQUIRE(C > 0 && M > 0, "bn_finalize_dm: C=%d M=%lld", C, (long long)M);
+  VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd && momentum_dev,
+               "bn_finalize_dm: null pointer");
+  const int nslab = (int)vp3d_stat_slabs(M);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+                     stat_m2, gamma, beta, eps, 0.f, momentum_dev, running_mean, running_var, num_batches_tracked, scale, shift,
+                     save_mean, save_invstd);
+  return check_launch("bn_finalize_dm");
 }
 
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,

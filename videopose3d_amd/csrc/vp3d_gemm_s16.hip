@@ -1220,6 +1220,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   return check_launch("nt_s16");
 }
 
+#ifdef VP3D_BUILD_EXPERIMENTS
 // ---- stream-K geometry (host): which tiles are shared, by how many workgroups, workspace ------------------------------------
 struct SkGeom {
   int t_dp, t_sk, blocks, max_seg;
@@ -1273,12 +1274,15 @@ int launch_cfg_sk(hipStream_t s, RowsGemmArgs a, float* ws, int64_t ws_floats, i
   return check_launch("nt_s16(stream-K)");
 }
 
+#endif  // VP3D_BUILD_EXPERIMENTS
+
 }  // namespace
 
 // Workspace of a launch in configuration cfg: floats (0 = none) and zeroed int32 tickets (0 = none).
 void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets) {
   *ws_floats = (splits > 1 || raw) ? (int64_t)(splits > 1 ? splits : 1) * M * N : 0;
   *tickets = 0;
+#ifdef VP3D_BUILD_EXPERIMENTS
   SkGeom g;
   bool sk = false;
   if (cfg == 120) sk = sk_geometry<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(M, N, K, &g);
@@ -1287,6 +1291,21 @@ void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t
     *ws_floats = g.ws_floats;
     *tickets = g.t_sk;
   }
+#else
+  (void)K; (void)cfg;
+#endif
+}
+
+// 1 when the library was built with -DVP3D_BUILD_EXPERIMENTS: the measured-and-not-adopted S16 GEMM instances (stream-K
+// 120 / 122, register-pipelined 10 / 13 / 21 / 23, the 256x128 / 128x256 pairs 24 / 25, four-wave 256x256 26, the hybrid
+// launch pair 30: DESIGN.md 4.6-4.7) exist.  The default build leaves them out: 40 % of the library's compile time, the only
+// instances with register spills, and surface the planner never uses.
+int nt_s16_has_experiments() {
+#ifdef VP3D_BUILD_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 // Tile configuration and split-K factor of an [M,N,K] S16 GEMM: cost model in microseconds, least-squares fit (10 % rms)
@@ -1393,6 +1412,13 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   const int64_t a_bytes = ((a_rows - 1) * a.lda + a.c_src) * 4, b_bytes = ((int64_t)(a.N - 1) * a.ldb + a.K) * 4;
   a.a_bytes = (uint32_t)a_bytes;
   a.b_bytes = (uint32_t)b_bytes;
+#ifndef VP3D_BUILD_EXPERIMENTS
+  VP3D_REQUIRE(cfg == 0 || cfg == 4 || cfg == 20 || cfg == 22,
+               "nt_s16: tile configuration %d is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)", cfg);
+  (void)tickets;
+  if ((cfg == 20 || cfg == 22) && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31)))
+    cfg = cfg == 20 ? 0 : 4;                     // operands of 2 GiB and more: the flat-address form of the same tiling
+#else
   if (cfg == 120 || cfg == 122) {                // stream-K instances of 20 / 22 (whole-launch configurations: no split-K)
     const bool flat = a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31);
     if (flat || raw_partials || a.epi.no_out || a.epi.act_scale != nullptr) {
@@ -1420,16 +1446,20 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
                   : launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, 1, m_split, a.M);
     }
   }
+#endif  // VP3D_BUILD_EXPERIMENTS
   int rc;
   switch (cfg) {
     // flat-address LDS-DMA (operands of any size)
     case 0: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 0>>(s, a, splits); break;    // 128x128, 4 waves, 2 x 32-element stages, 2 WG/CU
     case 4: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 0>>(s, a, splits); break;    // 256x256, 8 waves of 128x64, 2 x 32
+#ifdef VP3D_BUILD_EXPERIMENTS
     case 10: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 0>>(s, a, splits); break;   // 128x128, register-pipelined fragments
     case 13: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 0>>(s, a, splits); break;   // 256x256, register-pipelined, 4 x 16-element ring
+#endif
     // buffer-descriptor LDS-DMA (operands < 2 GiB): what plan_nt_s16 picks
     case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break;
     case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break;
+#ifdef VP3D_BUILD_EXPERIMENTS
     case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break;   // measured alternatives
     case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break;
     // two INDEPENDENT 4-wave workgroups of 128x64 sub-tiles per CU (3 x 16-element stages each: 2 x 74 KiB of LDS): the
@@ -1440,6 +1470,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     // fewer LDS fragment reads per MFMA than the 8-wave tiling, but nothing runs under a wave's stage-start LDS latency
     // and barrier wait: measured 8 % slower than cfg 22 on the large shapes
     case 26: rc = launch_cfg<Cfg<2, 2, 4, 4, 2, 32, 0, 1>>(s, a, splits); break;
+#endif  // VP3D_BUILD_EXPERIMENTS
     default:
       set_error("nt_s16: unknown tile configuration %d", cfg);
       return VP3D_E_INVALID;

@@ -130,6 +130,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, float* ws, int64_t ws_floats,
                   bool raw_partials, int32_t* tickets = nullptr);
 void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets);
+int nt_s16_has_experiments();
 // expand layer, forward (vp3d_expand_s16.hip): statistics pass (stat_sum != nullptr) or activation pass (out != nullptr)
 int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
                           const float* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,

@@ -1022,11 +1022,17 @@ int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t t
                    aligned16(p_partials),
                "expand_bwd_s16: bad argument (kpad <= 128, a spare padding column for the bias)");
   const size_t lds = (size_t)kv * kpad * sizeof(double) + 8 * 128 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {                                     // > 64 KiB of dynamic LDS needs the opt-in
-    if (hipFuncSetAttribute((const void*)k_expand_bwd_post, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
-      (void)hipGetLastError();
-    attr_set = true;
+  // > 64 KiB of dynamic LDS needs the opt-in, and the attribute is PER DEVICE: one flag per device ordinal (a process that
+  // drives several GPUs launches this on each of them); a failed opt-in is reported, not swallowed
+  static bool attr_set[64] = {};
+  int dev_id = 0;
+  VP3D_REQUIRE(hipGetDevice(&dev_id) == hipSuccess && dev_id >= 0 && dev_id < 64, "expand_bwd_s16: hipGetDevice failed");
+  if (!attr_set[dev_id]) {
+    const hipError_t st = hipFuncSetAttribute((const void*)k_expand_bwd_post, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024 - 4096);
+    if (st != hipSuccess) (void)hipGetLastError();
+    VP3D_REQUIRE(st == hipSuccess, "expand_bwd_s16: cannot opt in to %zu B of dynamic LDS (%s)", lds, hipGetErrorString(st));
+    attr_set[dev_id] = true;
   }
   hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
                      splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw);

@@ -139,7 +139,7 @@ def _forward_train_f32(mod, x3: torch.Tensor, save: bool, frozen: bool = False):
         else:
             stats = ops.stat_buffers(m_rows, spec.c_out, h.device)
             y = ops.conv_fwd(h, wt, spec, stats=stats)
-            coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
+            coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr())
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         a = ops.bn_act_fwd(y, coef, drop, residual)
         if save:
@@ -206,7 +206,10 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # Optional gradient sink (dp.FlatGradSync(direct_module=...)): every parameter gradient is written straight
     # into its view of the flat all-reduce buffer instead of being returned to autograd and accumulated into the
     # pre-existing .grad by one extra add kernel per tensor (29 launches per step for arc 3,3,3,3,3).
-    sink = mod.__dict__.get("_vp3d_grad_sink")
+    frozen = bool(saved.get("frozen"))               # eval-mode forward: BatchNorm on running statistics (ops.bn_act_bwd)
+    # (the differentiable eval-mode forward hands its gradients back to autograd: it must neither overwrite the flat
+    # training gradients nor start the sink's bucket collectives)
+    sink = None if frozen else mod.__dict__.get("_vp3d_grad_sink")
     convs, bns = _convs(mod), _bns(mod)
 
     def view(p):
@@ -223,7 +226,6 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # 10.18 ms -- no gain, so the separate kernels stay the default.
     fuse_mode = os.environ.get("VP3D_FUSE_ACT_BWD", "0")
     sync = mod.__dict__.get("_vp3d_sync_bn")
-    frozen = bool(saved.get("frozen"))               # eval-mode forward: BatchNorm on running statistics (ops.bn_act_bwd)
     if sync is not None or frozen:
         fuse_mode = "0"                              # the fused epilogue reduces with per-replica batch statistics
     if frozen:
@@ -336,7 +338,7 @@ def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Option
     if getattr(mod, "math", "f32") != "f16x3":
         return False
     from . import engine_s16
-    if not engine_s16.supported(mod, t_in, training, need_dx):
+    if not engine_s16.supported(mod, t_in, training, need_dx, batch=batch or 0):
         return False
     return batch is None or mod._plan.forward_flops(batch, t_in) >= S16_MIN_FORWARD_FLOPS[bool(training)]
 

@@ -34,7 +34,10 @@ from .plan import ConvSpec, StackPlan
 MAX_TRAIN_TAPS = 8      # widest conv the training path packs / gathers (dense=True models with pad >= 4 train on the fp32 kernels)
 
 
-def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
+GATHER_T_MAX_ROWS = 65535 * 64      # vp3d_gather_t_s16: one grid row per 64-row tile, at most 65535 of them
+
+
+def supported(mod, t_in: int, training: bool, need_dx: bool = False, batch: int = 0) -> bool:
     """What the split-fp16 engine implements: channel counts that are multiples of 64 and an expand conv of at most 128
     input columns (taps * J_in * in_features; 17 x 2 x 3 = 102).  Training covers both classes (dilated / strided), causal
     or not, any window length and filter widths up to 8 taps per conv -- a dense=True model with wider kernels (2*pad + 1
@@ -47,7 +50,18 @@ def supported(mod, t_in: int, training: bool, need_dx: bool = False) -> bool:
         return False
     if not training:
         return k0 >= 32                              # (eval stages the expand conv through ops.padded_k rows: none below 32 columns)
-    return max(spec.taps for spec in plan.convs) <= MAX_TRAIN_TAPS
+    if max(spec.taps for spec in plan.convs) > MAX_TRAIN_TAPS:
+        return False
+    if batch:
+        # convs whose weight-gradient operand is gathered in backward (dilated class, windows that do not tile): the gather
+        # kernel's row limit -- a larger call trains on the fp32 kernels instead of failing in the middle of backward
+        t_len = plan.lengths(t_in)
+        for idx in range(1, len(plan.convs)):
+            sp = plan.convs[idx]
+            t_i = t_in if idx == 0 else t_len[(idx - 1) // 2]
+            if not (sp.taps == 1 or _tiles(sp, t_i)) and batch * sp.t_out(t_i) > GATHER_T_MAX_ROWS:
+                return False
+    return True
 
 
 def _tiles(spec: ConvSpec, t_in: int) -> bool:
@@ -276,7 +290,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         dedicated0 = (fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
                       m_rows * kpad * 4 < 2 ** 31)                                     # vp3d_expand_fwd_s16 (32-bit byte offsets)
         y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr())
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:
@@ -353,8 +367,10 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     # X^T X of the expand layer's input (its no-dy backward, below): a small GEMM with nothing upstream -> second stream
     gram_xx, gram_ev = None, None
     # (with the dedicated kernel X^T X rides along in the P = G^T X launch at the end of backward: no GEMM of its own)
+    # (vp3d_expand_bwd_p_s16 addresses go and the transposed X with 32-bit byte offsets: M * C * 4 and kpad * ld_t * 4 < 2 GiB)
     fused_p = (L[0].one_col >= 0 and L[0].x_rows is None and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
-               L[0].bits is not None and L[0].bits.numel() * 32 < 2 ** 31)      # (the kernel addresses go with 32-bit byte offsets)
+               L[0].bits is not None and L[0].bits.numel() * 32 < 2 ** 31 and
+               L[0].x_t is not None and L[0].x_t.data.numel() * 4 < 2 ** 31)
     if L[0].one_col >= 0 and not fused_p:
         if side is not None:
             side.wait_stream(main)

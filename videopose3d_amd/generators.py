@@ -209,6 +209,12 @@ class ChunkedGenerator:
         while True:
             first, order = self.next_pairs()
             table = self._device_table(order)
+            if first == 0 and self.shard is not None and all(self._batch_rows(b_i, len(order)) is None
+                                                              for b_i in range(self.num_batches)):
+                # (an endless generator would otherwise spin here forever without ever yielding)
+                raise ValueError("sharded ChunkedGenerator: no batch of this epoch can be split over %d ranks "
+                                 "(%d chunks, batch size %d: every rank needs at least 2 samples per batch)"
+                                 % (self.shard[1], len(order), self.batch_size))
             for b_i in range(first, self.num_batches):
                 rows = self._batch_rows(b_i, len(order))
                 if self.endless:

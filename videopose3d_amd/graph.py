@@ -11,8 +11,12 @@ What makes a replay a new step although the launch arguments are frozen:
   * dropout masks: the kernels add a device-side step counter to the (frozen) Philox offset (``vp3d_dropout.offset_ptr``)
     and the graph itself bumps the counter;
   * BatchNorm running statistics / ``num_batches_tracked`` live in device memory and are updated in place;
-  * the BatchNorm momentum (run.py:590-593 changes it every epoch) IS a launch argument: it is part of the cache key, a
-    new value re-captures.
+  * the BatchNorm momentum (run.py:590-593 changes it every epoch) is read from device memory by the captured finalize
+    launches (vp3d_bn_finalize_dm; ``model.set_bn_momentum`` / a changed ``bn.momentum`` refreshes that float before the
+    replay) -- no re-capture per epoch.  Only per-layer DIFFERENT momenta fall back to launch arguments + re-capture.
+A captured graph owns a private memory pool that holds every activation and gradient of the step (several GB at B = 1024):
+there is ONE live entry per (shapes, device, arithmetic); when parameter addresses (optim.FlatAdam adoption, ``.to()``),
+dropout probability or per-layer momenta change, the stale entry is dropped -- pool and all -- before the new capture.
 Gradients land in the flat buffer of a ``dp.FlatGradSync`` (the parameters' ``.grad`` are views of it), so
 ``optimizer.step()`` -- torch Adam or ``optim.FlatAdam`` -- follows unchanged; with more than one rank the gradient
 exchange runs after the replay (``sync.sync()``: one all-reduce of the flat buffer).
@@ -33,8 +37,38 @@ from . import dp, engine, loss as vloss
 from ._lib import Vp3dError
 
 
+DEBUG_DOT_PATH = None      # tools/graph_branches.py: write hipGraphDebugDotPrint's .dot of the next capture here
+
+
 class _Entry:
-    __slots__ = ("graph", "x", "t", "loss", "keep")
+    __slots__ = ("graph", "x", "t", "loss", "keep", "guard", "grads")
+
+
+def _momentum_guard(m):
+    """None when the model's BatchNorm layers share one momentum (then read from device memory: any value replays), else the
+    tuple of launch-argument momenta the capture froze."""
+    if m._uniform_bn_momentum() is not None:
+        return None
+    return (m.expand_bn.momentum,) + tuple(bn.momentum for bn in m.layers_bn)
+
+
+def _arm_device_momentum(m, dev):
+    if m._uniform_bn_momentum() is not None and m._bn_momentum_dev is None:
+        m._bn_momentum_host = m._uniform_bn_momentum()
+        m._bn_momentum_dev = torch.full((1,), m._bn_momentum_host, dtype=torch.float32, device=dev)
+    m._momentum_dev_ptr()                              # value in step with the modules BEFORE anything is captured
+
+
+def _new_graph():
+    g = torch.cuda.CUDAGraph()
+    if DEBUG_DOT_PATH:
+        g.enable_debug_mode()
+    return g
+
+
+def _dump_dot(g):
+    if DEBUG_DOT_PATH:
+        g.debug_dump(DEBUG_DOT_PATH)
 
 
 class GraphedTrainStep:
@@ -66,13 +100,20 @@ class GraphedTrainStep:
         return lval
 
     def _key(self, x, t):
+        """What selects an entry (one live graph per key) ..."""
         m = self.model
-        # the captured launches hold raw device addresses: parameters re-pointed after a capture (optim.FlatAdam adopting
-        # them into its flat buffer, model.to(), a new FlatGradSync) must re-capture, not replay on stale pointers
+        return (tuple(x.shape), tuple(t.shape), x.device.index, m.math,
+                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]))
+
+    def _guard(self):
+        """... and what invalidates it: the captured launches hold raw device addresses and launch-argument scalars.
+        Parameters re-pointed after a capture (optim.FlatAdam adopting them into its flat buffer, model.to(), a new
+        FlatGradSync), another dropout probability or per-layer BatchNorm momenta must re-capture, not replay stale values.
+        The address TUPLE itself is compared (a hash could collide and replay on stale pointers)."""
+        m = self.model
         addrs = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers()) + \
             (self.sync.flat.data_ptr(),)
-        return (tuple(x.shape), tuple(t.shape), x.device.index, m.math, float(m.drop.p), m.expand_bn.momentum,
-                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]), hash(addrs))
+        return (addrs, float(m.drop.p), _momentum_guard(m))
 
     def _capture(self, x, t) -> _Entry:
         m = self.model
@@ -82,7 +123,10 @@ class GraphedTrainStep:
             raise Vp3dError("GraphedTrainStep: synchronised BatchNorm puts collectives inside the step; not captured")
         if m._drop_counter is None:
             m._drop_counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+        _arm_device_momentum(m, x.device)
         e = _Entry()
+        e.guard = self._guard()
+        e.grads = None
         e.x = x.detach().to(torch.float32).contiguous().clone()
         e.t = t.detach().to(torch.float32).contiguous().clone()
         # one eager warm-up step (creates the lazily built helpers, loads the code objects, sizes the allocator) with the
@@ -106,7 +150,7 @@ class GraphedTrainStep:
         key = x.device.index
         cached = engine._side_streams.get(key)
         engine._side_streams[key] = torch.cuda.Stream(device=x.device)
-        e.graph = torch.cuda.CUDAGraph()
+        e.graph = _new_graph()
         try:
             with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):   # (an RCCL watchdog thread may be alive)
                 e.loss = self._step(e.x, e.t)
@@ -114,7 +158,8 @@ class GraphedTrainStep:
             e.keep = engine._side_streams.pop(key)
             if cached is not None:
                 engine._side_streams[key] = cached
-        m._stats_epoch = counters[1]
+        _dump_dot(e.graph)
+        m._drop_calls, m._stats_epoch = counters[0], counters[1]   # capture executes nothing: host-side counters as before
         return e
 
     def __call__(self, inputs_2d: torch.Tensor, inputs_3d: torch.Tensor) -> torch.Tensor:
@@ -123,9 +168,13 @@ class GraphedTrainStep:
             raise Vp3dError("GraphedTrainStep runs on the GPU only")
         key = self._key(inputs_2d, inputs_3d)
         e = self._cache.get(key)
+        if e is not None and e.guard != self._guard():
+            del self._cache[key]                      # stale addresses / scalars: release the graph AND its memory pool first
+            e = None
         if e is None:
             e = self._capture(inputs_2d, inputs_3d)
             self._cache[key] = e
+        self.model._momentum_dev_ptr()                # set_bn_momentum / bn.momentum since the last step -> device float
         e.x.copy_(inputs_2d.reshape(e.x.shape))
         e.t.copy_(inputs_3d.reshape(e.t.shape))
         self.model._stats_epoch += 1                  # the running statistics are about to change (eval-fold cache key)
@@ -147,14 +196,16 @@ class GraphedStep:
         step = GraphedStep(step_fn, models=(model_pos_train, model_traj_train))
         for ...:
             loss = step(inputs_2d_cat, inputs_3d, cam)      # copies the arguments into the static buffers, replays
-            optimizer.step()                                # do NOT zero the gradients: every replay overwrites them
+            optimizer.step()                                # (zeroing the gradients in between is unnecessary: every replay overwrites them)
 
     ``fn`` runs under autograd inside the capture: the parameters' ``.grad`` are set to None before it, so the gradients that
     backward produces BECOME the ``.grad`` tensors (no accumulate kernel) and live in the graph's memory pool -- a replay
     overwrites them in place, which is why ``zero_grad(set_to_none=True)`` between replays must be left out.  Dropout masks
     advance through the models' device-side step counters, BatchNorm statistics are updated in place (as GraphedTrainStep).
     ``fn`` must be capturable: no host<->device copies or synchronisation inside (build index tensors beforehand, no
-    ``.item()`` / Python-list indexing).  Re-captures when an argument's shape, a model's arithmetic / dropout / BatchNorm momentum or a parameter address changes."""
+    ``.item()`` / Python-list indexing).  Re-captures when an argument's shape, a model's arithmetic / dropout probability or a parameter
+    address changes (the stale graph and its memory pool are released first); ``zero_grad(set_to_none=True)`` between replays
+    is harmless: every call re-attaches the captured gradient tensors."""
 
     def __init__(self, fn: Callable, models: Sequence, warmup: int = 2):
         self.fn, self.models, self.warmup = fn, list(models), warmup
@@ -170,10 +221,14 @@ class GraphedStep:
 
     def _key(self, args):
         k = tuple((tuple(a.shape), a.dtype, a.device.index) if torch.is_tensor(a) else a for a in args)
+        return k + tuple((m.math, m.training) for m in self.models)
+
+    def _guard(self):
+        g = ()
         for m in self.models:
             addrs = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())
-            k += (m.math, float(m.drop.p), m.expand_bn.momentum, m.training, hash(addrs))
-        return k
+            g += (addrs, float(m.drop.p), _momentum_guard(m))
+        return g
 
     def _capture(self, args) -> _Entry:
         dev = next(self.models[0].parameters()).device
@@ -183,7 +238,9 @@ class GraphedStep:
                                 "buffers inside the step; use GraphedTrainStep for the data-parallel step")
             if m._drop_counter is None:
                 m._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+            _arm_device_momentum(m, dev)
         e = _Entry()
+        e.guard = self._guard()
         e.x = [a.detach().clone() if torch.is_tensor(a) else a for a in args]
         e.t = None
         state = [[b_.clone() for b_ in m.buffers()] for m in self.models]
@@ -208,7 +265,7 @@ class GraphedStep:
         key = dev.index
         cached = engine._side_streams.get(key)
         engine._side_streams[key] = torch.cuda.Stream(device=dev)      # (a fresh second stream: see GraphedTrainStep._capture)
-        e.graph = torch.cuda.CUDAGraph()
+        e.graph = _new_graph()
         try:
             with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):
                 e.loss = self._run(e.x)
@@ -216,8 +273,11 @@ class GraphedStep:
             e.keep = engine._side_streams.pop(key)
             if cached is not None:
                 engine._side_streams[key] = cached
+        _dump_dot(e.graph)
         for m, cn in zip(self.models, counters):
-            m._stats_epoch = cn[1]
+            m._drop_calls, m._stats_epoch = cn[0], cn[1]
+        # the gradients the captured backward produced ARE the graph's output buffers: a replay overwrites them in place
+        e.grads = [p.grad for p in self._params()]
         return e
 
     def __call__(self, *args):
@@ -226,6 +286,9 @@ class GraphedStep:
             raise Vp3dError("GraphedStep runs on the GPU only")
         key = self._key(args)
         e = self._cache.get(key)
+        if e is not None and e.guard != self._guard():
+            del self._cache[key]                      # (graph + its memory pool go before the new capture allocates)
+            e = None
         if e is None:
             e = self._capture(args)
             self._cache[key] = e
@@ -234,5 +297,11 @@ class GraphedStep:
                 dst.copy_(src)
         for m in self.models:
             m._stats_epoch += 1
+            m._momentum_dev_ptr()
         e.graph.replay()
+        # optimizer.zero_grad() defaults to set_to_none=True: without this the next optimizer.step() would silently skip
+        # every parameter.  The replay has just rewritten the captured gradient buffers: hand them back.
+        for p, g in zip(self._params(), e.grads):
+            if p.grad is not g:
+                p.grad = g
         return e.loss

@@ -11,7 +11,9 @@ fixes the state_dict names and reproduces the reference's default initialisation
 """
 from __future__ import annotations
 
+import copy
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -41,6 +43,7 @@ class TemporalModelBase(nn.Module):
 
     _kind = None
     _n_models = 0
+    _warned_eval_grad = False
 
     def __init__(self, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels):
         super().__init__()
@@ -62,6 +65,9 @@ class TemporalModelBase(nn.Module):
         TemporalModelBase._n_models += 1
         self._ordinal = TemporalModelBase._n_models      # construction order in this process: separates the models' mask streams
         self._drop_counter = None       # optional device uint64 step counter added to the dropout offset (graph.py)
+        self._bn_momentum_host = None
+        self._bn_momentum_dev = None    # optional device float read by the BatchNorm finalize launches instead of their
+                                        # momentum argument (graph.py: a captured step follows set_bn_momentum)
         # GEMM arithmetic (not part of the reference API / state_dict): "f16x3" = split-fp16 operands on
         # v_mfma_f32_32x32x16_f16 (fp32-class results: 22+ operand bits, exact products, fp32 accumulation; ~3x the
         # fp32 matrix rate) wherever engine_s16.supported() says so, "f32" = v_mfma_f32_32x32x2_f32 everywhere.
@@ -90,6 +96,41 @@ class TemporalModelBase(nn.Module):
         self.expand_bn.momentum = momentum
         for bn in self.layers_bn:
             bn.momentum = momentum
+        if self._bn_momentum_dev is not None:
+            self._bn_momentum_dev.fill_(float(momentum))
+
+    def _uniform_bn_momentum(self):
+        """The one momentum all BatchNorm layers share (what set_bn_momentum / the constructor leave behind), else None."""
+        moms = {self.expand_bn.momentum} | {bn.momentum for bn in self.layers_bn}
+        mom = next(iter(moms))
+        return float(mom) if len(moms) == 1 and mom is not None else None
+
+    def _momentum_dev_ptr(self):
+        """Device address the BatchNorm finalize launches read their momentum from, or None (launch argument).  Kept in
+        step with the modules' ``momentum`` attributes here, so setting ``bn.momentum`` directly also reaches a replay."""
+        t = self._bn_momentum_dev
+        if t is None:
+            return None
+        mom = self._uniform_bn_momentum()
+        if mom is None:
+            return None                               # per-layer momenta: launch arguments (a graph re-captures on change)
+        if mom != self._bn_momentum_host:
+            t.fill_(mom)
+            self._bn_momentum_host = mom
+        return t.data_ptr()
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        # a copy is a model of its own: its own dropout mask stream (the seed mixes the ordinal) and device-side counters
+        TemporalModelBase._n_models += 1
+        new._ordinal = TemporalModelBase._n_models
+        new._drop_seed = None
+        new._drop_counter = None
+        new._bn_momentum_dev = None
+        return new
 
     def receptive_field(self):
         """Total receptive field of this model as # of frames."""
@@ -149,6 +190,12 @@ class TemporalModelBase(nn.Module):
                     # the reference's eval-mode forward is differentiable (model.py:63-77): BatchNorm on its running
                     # statistics, exact-fp32 kernels, hand-written backward without the batch-statistic terms.  Evaluation
                     # under torch.no_grad() (as run.py does it) takes the folded-BatchNorm fast path below.
+                    if not x3.requires_grad and not TemporalModelBase._warned_eval_grad:
+                        TemporalModelBase._warned_eval_grad = True
+                        warnings.warn("videopose3d_amd: eval-mode forward with autograd enabled runs the differentiable "
+                                      "exact-fp32 path and keeps every activation for backward (like the reference); wrap "
+                                      "evaluation in torch.no_grad() -- as run.py does -- for the folded-BatchNorm fast path",
+                                      stacklevel=3)
                     out3 = engine.FrozenStackFn.apply(self, x3, *engine.param_list(self))
                 else:
                     with torch.no_grad():

@@ -419,9 +419,10 @@ def _bn_finalize_sync(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync) -> tor
     return buf
 
 
-def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None) -> torch.Tensor:
+def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None, momentum_dev: Optional[int] = None) -> torch.Tensor:
     """Returns a [4, C] tensor: scale, shift, mean, invstd.  Updates the running buffers in place.
-    sync: a dp.SyncBatchNorm -> statistics over the global batch."""
+    sync: a dp.SyncBatchNorm -> statistics over the global batch.  momentum_dev: device address of a float the kernel reads
+    the momentum from at execution time (hipGraph replays follow set_bn_momentum), instead of bn.momentum as an argument."""
     if sync is not None:
         return _bn_finalize_sync(bn, m_rows, stats, sync)
     c = bn.num_features
@@ -433,12 +434,14 @@ def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None) -> torc
     momentum = 0.0 if bn.momentum is None else float(bn.momentum)
     if bn.momentum is None and track:
         momentum = 1.0 / float(int(bn.num_batches_tracked.item()) + 1)   # cumulative average (not used by run.py)
-    check(_lib.lib().vp3d_bn_finalize(
-        _stream(), c, m_rows, stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-        float(bn.eps), momentum, bn.running_mean.data_ptr() if track else None,
-        bn.running_var.data_ptr() if track else None,
-        bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
-        buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()), "vp3d_bn_finalize")
+    tail = (bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+            bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
+            buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr())
+    head = (_stream(), c, m_rows, stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps))
+    if momentum_dev is not None and track and bn.momentum is not None:
+        check(_lib.lib().vp3d_bn_finalize_dm(*head, momentum_dev, *tail), "vp3d_bn_finalize_dm")
+    else:
+        check(_lib.lib().vp3d_bn_finalize(*head, momentum, *tail), "vp3d_bn_finalize")
     return buf
 
 
