@@ -365,3 +365,64 @@ def test_engine_selection_rules(monkeypatch):
     assert not engine_s16.wgrad_from_rows(128, 128, 100)
     monkeypatch.setenv("VP3D_WGRAD_ROWS", "0")
     assert not engine_s16.wgrad_from_rows(1024, 1024, 1024)
+
+
+def test_deepcopy_gets_its_own_dropout_stream_and_device_counters():
+    """copy.deepcopy(model) is a model of its own: a new construction ordinal (hence another mask stream) and no shared
+    device-side step counter / momentum scalar; its parameters are copies."""
+    import copy
+    torch.manual_seed(3)
+    a = V.TemporalModelOptimized1f(17, 2, 17, [3, 3], channels=32)
+    a._drop_counter = torch.zeros(1, dtype=torch.int64)
+    a._bn_momentum_dev = torch.full((1,), 0.1)
+    sa = a._next_dropout_state()[0]
+    b = copy.deepcopy(a)
+    assert b._ordinal != a._ordinal and b._drop_counter is None and b._bn_momentum_dev is None
+    assert b._next_dropout_state()[0] != sa
+    assert b.expand_conv.weight.data_ptr() != a.expand_conv.weight.data_ptr()
+    assert torch.equal(b.expand_conv.weight, a.expand_conv.weight)
+    assert b.receptive_field() == a.receptive_field() and list(b.state_dict()) == list(a.state_dict())
+
+
+def test_bn_momentum_bookkeeping_for_captured_steps():
+    """graph.py reads the BatchNorm momentum from device memory when all layers share one value (what set_bn_momentum leaves
+    behind, model.py:36-39); per-layer momenta fall back to launch arguments (guarded re-capture)."""
+    from videopose3d_amd import graph as G
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=32)
+    assert m._uniform_bn_momentum() == 0.1 and G._momentum_guard(m) is None and m._momentum_dev_ptr() is None
+    m._bn_momentum_dev = torch.full((1,), 0.1)           # (a CPU tensor stands in for the device scalar)
+    m._bn_momentum_host = 0.1
+    m.set_bn_momentum(0.03)
+    assert abs(float(m._bn_momentum_dev) - 0.03) < 1e-9 and m._momentum_dev_ptr() == m._bn_momentum_dev.data_ptr()
+    m.layers_bn[1].momentum = 0.5                         # someone sets one layer by hand: no single scalar any more
+    assert m._uniform_bn_momentum() is None and m._momentum_dev_ptr() is None
+    assert G._momentum_guard(m) == (0.03, 0.03, 0.5, 0.03, 0.03)
+    m.set_bn_momentum(0.02)
+    m.expand_bn.momentum = 0.07                           # ... or all of them, bypassing set_bn_momentum: the pointer call refreshes
+    for bn in m.layers_bn:
+        bn.momentum = 0.07
+    m._momentum_dev_ptr()
+    assert abs(float(m._bn_momentum_dev) - 0.07) < 1e-9
+
+
+def test_sharded_endless_generator_raises_instead_of_spinning():
+    """An epoch in which NO batch can feed every rank (fewer than 2 samples per rank) must raise: an endless generator
+    (the semi-supervised one, run.py:330-343) would otherwise loop forever without yielding."""
+    from videopose3d_amd.generators import ChunkedGenerator
+    g = ChunkedGenerator.__new__(ChunkedGenerator)
+    g.batch_size, g.num_batches, g.endless, g.shard, g.state = 4, 2, True, (0, 4), None
+    g.next_pairs = lambda: (0, list(range(7)))
+    g._device_table = lambda order: None
+    with pytest.raises(ValueError, match="no batch of this epoch"):
+        next(g.next_epoch())
+
+
+def test_s16_engine_rejects_gather_form_training_beyond_the_kernel_row_limit():
+    """vp3d_gather_t_s16 addresses at most 65535 row tiles: a dilated-class training call beyond that runs on the fp32
+    engine instead of failing in the middle of backward (engine_s16.supported(batch=...))."""
+    from videopose3d_amd import engine_s16
+    m = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=64)
+    assert engine_s16.supported(m, 243, True, batch=64)
+    assert not engine_s16.supported(m, 243, True, batch=65535 * 64 // 200)
+    s = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=64)      # windows tile: no gathered operand at all
+    assert engine_s16.supported(s, 27, True, batch=65535 * 64)

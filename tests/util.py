@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    special = {"camera", "semi_step", "train_loop", "step_generators", "step_loss", "step_adam", "eval_protocol", "kat_matrix"}          # fixtures with their own layout / tests
+    special = {"camera", "semi_step", "train_loop", "step_generators", "step_loss", "step_adam", "eval_protocol", "kat_matrix", "kat_grads"}          # fixtures with their own layout / tests
     return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
                   if n not in special)
 
