@@ -296,6 +296,18 @@ int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kp
                                  *nparts, partials, gram_partials);
 }
 
+int vp3d_tail_fwd_s16(vp3d_stream_t stream, const vp3d_tail_fwd* desc) { return launch_tail_fwd((hipStream_t)stream, desc); }
+int vp3d_tail_bwd_s16(vp3d_stream_t stream, const vp3d_tail_bwd* desc) { return launch_tail_bwd((hipStream_t)stream, desc); }
+int vp3d_tail_workspace(int32_t C, int32_t n_layers, const int64_t* M, const int32_t* taps, int64_t* fwd_floats,
+                        int64_t* dpart_floats, int64_t* wpart_floats) {
+  VP3D_REQUIRE(C > 0 && n_layers > 0 && n_layers <= tail_max_layers() && M && taps && fwd_floats && dpart_floats && wpart_floats,
+               "tail_workspace: bad argument");
+  return tail_workspace(C, n_layers, M, taps, fwd_floats, dpart_floats, wpart_floats);
+}
+int vp3d_tail_max_layers(void) { return tail_max_layers(); }
+int vp3d_tail_sync_bytes(void) { return tail_sync_bytes(); }
+int vp3d_tail_barrier_grouped(void) { return tail_barrier_grouped(); }
+
 int vp3d_has_experiments(void) { return nt_s16_has_experiments(); }
 
 int vp3d_nt_s16_workspace(int64_t M, int32_t N, int32_t K, int32_t cfg, int32_t splits, int32_t raw_partials, int64_t* ws_floats,
