@@ -60,18 +60,19 @@ def mpjpe(pred, target):                                                        
     return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))
 
 
-PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
-            "f16x3": os.path.join(ROOT, "profiles", "r01_s16_pmc_traffic.json")}
+PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r03f32_pmc_traffic.json"),
+            "f16x3": os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")}
 FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"},
                   # one kernel serves all three GEMM forms of the split-fp16 path (all are "NT")
                   "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
-STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r02_step_table.json")}
+STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r03_step_table.json"),
+                   "f32": os.path.join(ROOT, "profiles", "r03f32_step_table.json")}
 
 
 def pmc_traffic(family, math):
-    """Per-launch table first (profiles/r02_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
+    """Per-launch table first (profiles/r03_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
     WRITE_SIZE): the family's traffic is the mean over ITS launches, comparable with `algorithmic_bytes`; else the
     per-kernel-template means of the older profile."""
     path = STEP_TABLE_JSON.get(math)
@@ -107,7 +108,7 @@ def pmc_traffic_of_cfg(cfg, math):
 
 def _pmc_traffic_templates(family, math):
     """HBM-side bytes per launch of a GEMM family from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
+    (profiles/r03*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
     gfx950 correction of MI355X_MICROARCH.md; tools/pmc_traffic.py).  PMC counters cannot be read from inside the
     timed process, so the value is the committed measurement, averaged over the family's launches like `achieved`."""
     path = PMC_JSON[math]
@@ -425,7 +426,7 @@ def instrumented(step, ops, n_prof, math):
     roof.update(extra)
     if by_kernel is not None:
         roof["by_kernel"] = by_kernel            # every GEMM kernel of the step: time, algorithmic TFLOP/s, fraction of the roofline
-    roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r02_step_table.txt shows
+    roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r03_step_table.txt shows
     roof["streaming"] = streaming[:6]        # from rocprofv3); the two big HBM-bound producers against the achievable HBM rate
     return roof, kernels
 

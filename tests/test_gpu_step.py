@@ -409,16 +409,31 @@ def test_graphed_train_step_equals_eager_steps(p_drop):
     assert len(step._cache) == 1                       # one capture, three replays
     if p_drop > 0:
         assert len({round(v, 9) for v in losses_g}) == 3
-    # a new BatchNorm momentum (run.py:590-593) re-captures instead of replaying the stale launch arguments
-    m_g.set_bn_momentum(0.05)
-    m_e.set_bn_momentum(0.05)
-    x = (torch.randn(16, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(DEV)
-    tgt = (torch.randn(16, 1, 17, 3, generator=gen) * 0.3).to(DEV)
+    # a new BatchNorm momentum (run.py:590-593, every epoch) reaches the replay through device memory (vp3d_bn_finalize_dm):
+    # no re-capture, no second memory pool -- whether it is set through set_bn_momentum or on the modules directly
+    for k, mom in enumerate((0.05, 0.02)):
+        if k == 0:
+            m_g.set_bn_momentum(mom)
+        else:
+            for bn in [m_g.expand_bn] + list(m_g.layers_bn):
+                bn.momentum = mom
+        m_e.set_bn_momentum(mom)
+        x = (torch.randn(16, 27, 17, 2, generator=gen) * 0.5).clamp(-1, 1).to(DEV)
+        tgt = (torch.randn(16, 1, 17, 3, generator=gen) * 0.3).to(DEV)
+        sync_e.zero_grad()
+        vloss.mpjpe(m_e(x), tgt).backward()
+        step(x, tgt)
+        assert len(step._cache) == 1
+        assert torch.allclose(m_e.expand_bn.running_var, m_g.expand_bn.running_var, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(m_e.layers_bn[3].running_mean, m_g.layers_bn[3].running_mean, rtol=1e-6, atol=1e-7)
+    # per-layer DIFFERENT momenta are launch arguments again: the stale entry (and its memory pool) is dropped, one re-capture
+    old_entry = next(iter(step._cache.values()))
+    m_g.layers_bn[0].momentum = m_e.layers_bn[0].momentum = 0.3
     sync_e.zero_grad()
     vloss.mpjpe(m_e(x), tgt).backward()
     step(x, tgt)
-    assert len(step._cache) == 2
-    assert torch.allclose(m_e.expand_bn.running_var, m_g.expand_bn.running_var, rtol=1e-6, atol=1e-7)
+    assert len(step._cache) == 1 and next(iter(step._cache.values())) is not old_entry
+    assert torch.allclose(m_e.layers_bn[0].running_var, m_g.layers_bn[0].running_var, rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.25])
@@ -468,8 +483,12 @@ def test_graphed_generic_step_equals_eager_semi_supervised_step(p_drop):
         cam = torch.tensor([1.15, 1.15, 0.0, 0.0, -0.2, 0.25, 0.0, 0.0, 0.0]).repeat(bsz, 1).to(DEV)
         pos_e.zero_grad(set_to_none=True)
         traj_e.zero_grad(set_to_none=True)
+        if k == 1:            # what an unmodified training loop does between steps (optimizer.zero_grad(): set_to_none=True):
+            pos_g.zero_grad(set_to_none=True)      # the replay must hand the captured gradient tensors back, or
+            traj_g.zero_grad(set_to_none=True)     # optimizer.step() would silently skip every parameter
         le = float(eager(cat, y3, cam))
         lg = float(step(cat, y3, cam))
+        assert all(p_.grad is not None for p_ in list(pos_g.parameters()) + list(traj_g.parameters()))
         losses.append(lg)
         assert abs(le - lg) < 1e-6 * max(1.0, abs(le)), (k, le, lg)
         for me, mg in ((pos_e, pos_g), (traj_e, traj_g)):

@@ -1,0 +1,166 @@
+// Micro-benchmark (stand-alone): where does the K loop of the 256x256 split-fp16 GEMM tile (k_nt_s16<Cfg<2,4,4,2,2,32,0,1>>:
+// 8 waves of 128x64, two 64-KiB LDS stages, operands through buffer-descriptor LDS-DMA) lose its time?  The same loop with
+// parts of the operand path removed -- an upper bound of what moving the weight operand off the LDS path could give:
+//   ABL 0  the library's loop              1  no B DMA (stale LDS)       2  no B DMA, no B fragment reads (B in registers)
+//   ABL 3  no DMA at all (LDS reads kept)  4  MFMAs + barrier only
+//   hipcc --offload-arch=gfx950 -O3 -I../../include -I../../videopose3d_amd/csrc kloop.hip -o kloop && ./kloop
+#include "vp3d_s16_mma.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+using namespace vp3d;
+using namespace vp3d::mma;
+namespace vp3d { void set_error(const char*, ...) {} int check_launch(const char*) { return 0; } }
+
+typedef Cfg<2, 4, 4, 2, 2, 32, 0, 1> C22;
+
+template <int ABL>
+__global__ void __launch_bounds__(C22::NT, 2) k_loop(const float* __restrict__ A, const float* __restrict__ B, float* out, int M,
+                                                     int N, int K, int n_tiles) {
+  using C = C22;
+  constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, PA = C::PA, PB = C::PB, BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP;
+  constexpr int CPR = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / C::WN, wn = w % C::WN;
+  const int h = lane >> 5, cl = lane & 31;
+  const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = K / BK;
+  f32x16 acc[RB][CB];
+  for (int i = 0; i < RB; ++i)
+    for (int j = 0; j < CB; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)M * K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)N * K * 4), 0x00020000);
+  int a_cur[PA], b_cur[PB];
+  for (int i = 0; i < PA; ++i) {
+    const int r = (w * PA + i) * RPP + lane / CPR, chunk = (lane & (CPR - 1)) ^ C::swz(r);
+    a_cur[i] = ((m0 + r) * K + chunk * 4) * 4;
+  }
+  for (int i = 0; i < PB; ++i) {
+    const int r = (w * PB + i) * RPP + lane / CPR, chunk = (lane & (CPR - 1)) ^ C::swz(r);
+    b_cur[i] = ((n0 + r) * K + chunk * 4) * 4;
+  }
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * C::STAGE_B;
+    char* sB = sA + C::A_B;
+    if (ABL < 3) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) blds16(rsA, a_cur[i], sA + (w * PA + i) * 1024);
+    }
+    if (ABL == 0) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) blds16(rsB, b_cur[i], sB + (w * PB + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_cur[i] += BK * 4;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_cur[i] += BK * 4;
+  };
+  const int sw = C::swz(cl);
+  const int off0 = ((2 * (0 + h)) ^ sw) * 16, off1 = ((2 * (2 + h)) ^ sw) * 16;
+  const int a_row = (wm * RB * 32 + cl) * ROWB, b_row = (wn * CB * 32 + cl) * ROWB;
+  f16x8 bh[2][CB], bl[2][CB];
+  for (int s = 0; s < 2; ++s)
+    for (int j = 0; j < CB; ++j) {
+      bh[s][j] = *reinterpret_cast<const f16x8*>(B + (int64_t)(n0 + wn * 64 + j * 32 + cl) * K + s * 16 + h * 8);
+      bl[s][j] = *reinterpret_cast<const f16x8*>(B + (int64_t)(n0 + wn * 64 + j * 32 + cl) * K + s * 16 + h * 8 + 4);
+    }
+  issue(0);
+  int st_c = 0, st_i = 1;
+  for (int it = 0; it < nkt; ++it) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    issue(st_i);
+    const char* sA = smem + st_c * C::STAGE_B + a_row;
+    const char* sB = smem + st_c * C::STAGE_B + C::A_B + b_row;
+    if (ABL == 0 || ABL == 1 || ABL == 3) {
+      compute_tile<RB, CB, 2, ROWB>(sA, sB, acc, off0, off1);
+    } else {
+      f16x8 ah[2][RB], al[2][RB];
+      if (ABL == 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int off = s == 0 ? off0 : off1;
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + off);
+            al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + (off ^ 16));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            ah[s][i] = bh[s][i & 1];
+            al[s][i] = bl[s][i & 1];
+          }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    st_c ^= 1;
+    st_i ^= 1;
+  }
+  wait_vmcnt<0>();
+  float s = 0.f;
+  for (int i = 0; i < RB; ++i)
+    for (int j = 0; j < CB; ++j)
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[(int64_t)blockIdx.x * C::NT + tid] = s;
+}
+
+int main() {
+  const int M = 32768, N = 1024, K = 3072;          // 128 x 4 = 512 tiles of 256x256: two full rounds of 256 CUs
+  std::vector<_Float16> ha((size_t)M * K * 2), hb((size_t)N * K * 2);
+  for (auto& v : ha) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
+  for (auto& v : hb) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
+  float *A, *B, *out;
+  hipMalloc(&A, (size_t)M * K * 4);
+  hipMalloc(&B, (size_t)N * K * 4);
+  hipMalloc(&out, (size_t)512 * 512 * 4);
+  hipMemcpy(A, ha.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int tiles = (M / 256) * (N / 256);
+  const char* names[5] = {"library loop", "no B DMA", "no B DMA, no B LDS reads", "no DMA at all", "MFMA + barrier only"};
+  for (int abl = 0; abl < 5; ++abl) {
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0);
+      switch (abl) {
+        case 0: hipLaunchKernelGGL(k_loop<0>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, K, N / 256); break;
+        case 1: hipLaunchKernelGGL(k_loop<1>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, K, N / 256); break;
+        case 2: hipLaunchKernelGGL(k_loop<2>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, K, N / 256); break;
+        case 3: hipLaunchKernelGGL(k_loop<3>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, K, N / 256); break;
+        default: hipLaunchKernelGGL(k_loop<4>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, K, N / 256); break;
+      }
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (rep && ms < best) best = ms;
+    }
+    printf("ABL %d  %-28s %.3f ms   %.0f TFLOP/s algorithmic (%.0f executed)   %.2f us per K-tile\n", abl, names[abl], best,
+           2.0 * M * N * K / best / 1e9, 6.0 * M * N * K / best / 1e9, best * 1e3 / 2 / (K / 32));
+  }
+  return 0;
+}
