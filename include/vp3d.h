@@ -232,6 +232,23 @@ int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int3
 int vp3d_expand_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t N, int32_t kpad, const void* x, const float* x_bound,
                         const void* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,
                         const float* shift, const vp3d_dropout* drop, const float* out_bound, void* out, uint8_t* act_bits);
+/* The per-step prologue of the split-fp16 training forward as TWO launches (untraced, the seven dependent launches they
+ * replace -- vp3d_amax_floor, vp3d_im2row_split_s16, vp3d_amax_multi, vp3d_pack_weight, vp3d_split_rows,
+ * vp3d_pack_weight_s16_multi, vp3d_act_bounds_multi -- take 125 us before the first GEMM of the cfg3 step):
+ *   A: every maximum (tensor i: bound[i] = max(bound[i], floor[i], max|src[i]|), 32-slot bounds zeroed by the caller) and the
+ *      activation bounds of vp3d_act_bounds_multi (n_layers == 0: none) -- nothing here depends on anything else;
+ *   B: what needs only those: the raw input's im2row + S16 split (vp3d_im2row_split_s16's arguments), the expand conv's weight
+ *      W0 [c0][cin0][taps0] -> fp32 pack [c0][kpad] + its S16 rows under *w0_bound, and the C x C weight packs of
+ *      vp3d_pack_weight_s16_multi (n_layers == 0: none). */
+int vp3d_prologue_a_s16(vp3d_stream_t stream, int32_t n_tensors, const float* const* src, const int64_t* n, float* const* bound,
+                        const float* floor_, int32_t n_layers, int32_t C, const float* const* gamma, const float* const* beta,
+                        const int64_t* M, const int32_t* res_from, float p, float* act_bounds);
+int vp3d_prologue_b_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid, int32_t kpad,
+                        int32_t one_col, const float* x_bound, void* x_rows, void* x_t, int64_t ld_t, const float* w0, int32_t c0,
+                        int32_t cin0, int32_t taps0, const float* w0_bound, float* w0_packed, void* w0_s16, int32_t n_layers,
+                        const float* const* w, const int32_t* taps, int32_t c_out, int32_t c_in, const float* w_bounds,
+                        void* const* wf, void* const* wd);
+
 /* ---- the small-M tail of the strided training stack as one persistent launch per direction (vp3d_tail_s16.hip) ----------
  * Replaces, for the trailing blocks of TemporalModelOptimized1f whose convs produce few rows (B * T_out of a few thousand
  * at most), the reference's

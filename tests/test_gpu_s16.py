@@ -640,3 +640,39 @@ def test_engines_agree_on_random_configurations():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "30", "7"], capture_output=True, text=True,
                        cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("joints,c,arc", [(17, 128, [3, 3, 3]), (15, 64, [3, 3, 3, 3]), (17, 256, [3, 1, 3])])
+def test_fused_prologue_is_bit_identical(joints, c, arc, monkeypatch):
+    """The two-launch prologue (vp3d_prologue_a_s16: every maximum + the activation bounds; vp3d_prologue_b_s16: input staging +
+    all weight packs) against the seven launches it replaces: same arithmetic, so output, gradients and running statistics
+    must agree bit for bit."""
+    from videopose3d_amd import engine
+    keep = dict(engine.S16_MIN_FORWARD_FLOPS)
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})
+    try:
+        torch.manual_seed(9)
+        m = V.TemporalModelOptimized1f(joints, 2, 17, arc, dropout=0.25, channels=c).to(DEV).train()
+        m.math = "f16x3"
+        m._drop_seed = 0xF00D
+        rf = m.receptive_field()
+        x = (torch.randn(24, rf, joints, 2, device=DEV) * 0.5).clamp(-1, 1)
+        tgt = torch.randn(24, 1, 17, 3, device=DEV) * 0.3
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        res = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("VP3D_PROLOGUE_FUSED", fused)
+            m.load_state_dict(sd0)
+            m._drop_calls = 0
+            m.zero_grad(set_to_none=True)
+            y = m(x)
+            torch.mean(torch.norm(y - tgt, dim=3)).backward()
+            res.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: v.clone() for k, v in m.state_dict().items()}))
+        assert torch.equal(res[0][0], res[1][0])
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], res[1][2][k]), k
+    finally:
+        engine.S16_MIN_FORWARD_FLOPS.update(keep)

@@ -107,6 +107,10 @@ SIGNATURES = {
     "vp3d_amax_floor": (C.c_int, [_vp, _i64, _vp, _f32, _vp]),
     "vp3d_expand_fwd_s16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp]),
     "vp3d_expand_bwd_p_s16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _vp, _vp, _P(_i32)]),
+    "vp3d_prologue_a_s16": (C.c_int, [_vp, _i32, _P(_vp), _P(_i64), _P(_vp), _P(_f32), _i32, _i32, _P(_vp), _P(_vp), _P(_i64),
+                                      _P(_i32), _f32, _vp]),
+    "vp3d_prologue_b_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp,
+                                      _vp, _vp, _i32, _P(_vp), _P(_i32), _i32, _i32, _vp, _P(_vp), _P(_vp)]),
     "vp3d_tail_fwd_s16": (C.c_int, [_vp, _P(TailFwd)]),
     "vp3d_tail_bwd_s16": (C.c_int, [_vp, _P(TailBwd)]),
     "vp3d_tail_workspace": (C.c_int, [_i32, _i32, _P(_i64), _P(_i32), _P(_i64), _P(_i64), _P(_i64)]),

@@ -244,13 +244,12 @@ struct Im2Row {
 
 // fp32 rows [M][C] (pitch ld_src; IM2ROW: gathered, see above) -> S16 rows (optional) and transposed S16 (optional, taps = 1)
 template <bool IM2ROW>
-__global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __restrict__ src, int64_t ld_src,
-                                                 const float* __restrict__ bound, float* __restrict__ out, int64_t ld_out,
-                                                 TOut t, Im2Row g) {
-  extern __shared__ float tile[];
+__device__ __forceinline__ void split_t_body(int M, int C, const float* __restrict__ src, int64_t ld_src,
+                                             const float* __restrict__ bound, float* __restrict__ out, int64_t ld_out,
+                                             const TOut& t, const Im2Row& g, float* tile, int bx, int by) {
   const int g8 = threadIdx.x & 7, rsub = threadIdx.x >> 3;
-  const int c0 = blockIdx.x * TCH, c = c0 + g8 * 8;
-  const int64_t m0 = (int64_t)blockIdx.y * 64;
+  const int c0 = bx * TCH, c = c0 + g8 * 8;
+  const int64_t m0 = (int64_t)by * 64;
   const float inv = bound != nullptr ? s16_pow2(-s16_exp_of(bound)) : 1.f;
   for (int r = rsub; r < 64; r += 32) {
     const int64_t m = m0 + r;
@@ -285,7 +284,15 @@ __global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __re
   }
   if (t.ptr == nullptr) return;
   __syncthreads();
-  tile_store_t(tile, t, C, c0, (int64_t)blockIdx.y * 64);
+  tile_store_t(tile, t, C, c0, (int64_t)by * 64);
+}
+
+template <bool IM2ROW>
+__global__ void __launch_bounds__(256) k_split_t(int M, int C, const float* __restrict__ src, int64_t ld_src,
+                                                 const float* __restrict__ bound, float* __restrict__ out, int64_t ld_out,
+                                                 TOut t, Im2Row g) {
+  extern __shared__ float tile[];
+  split_t_body<IM2ROW>(M, C, src, ld_src, bound, out, ld_out, t, g, tile, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -424,14 +431,12 @@ struct PackMulti {
   int c_out, c_in;
 };
 
-__global__ void __launch_bounds__(256) k_pack_weight_s16_multi(PackMulti a) {
-  extern __shared__ float tile[];                 // [taps][64 co][TPITCH]
-  const int li = blockIdx.z;
+__device__ __forceinline__ void pack_weight_s16_multi_body(const PackMulti& a, float* tile, int bx, int by, int li) {
   const int taps = a.taps[li], c_in = a.c_in, c_out = a.c_out;
   const float* __restrict__ w = a.w[li];
   float* __restrict__ wf = a.wf[li];
   float* __restrict__ wd = a.wd[li];
-  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const int co0 = by * 64, ci0 = bx * 64;
   const float inv = s16_pow2(-s16_exp_of(a.bounds + li * kBoundSlots));
   const int row_f = 64 * taps;
   for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
@@ -469,6 +474,11 @@ __global__ void __launch_bounds__(256) k_pack_weight_s16_multi(PackMulti a) {
   }
 }
 
+__global__ void __launch_bounds__(256) k_pack_weight_s16_multi(PackMulti a) {
+  extern __shared__ float tile[];                 // [taps][64 co][TPITCH]
+  pack_weight_s16_multi_body(a, tile, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 struct ActBoundsMulti {
   const float* gamma[kMaxLayers];
   const float* beta[kMaxLayers];
@@ -494,6 +504,128 @@ __global__ void __launch_bounds__(1024) k_act_bounds_multi(ActBoundsMulti a) {
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The prologue of a training forward as TWO launches (vp3d_prologue_a_s16 / vp3d_prologue_b_s16) instead of seven: untraced
+// the dependent chain amax(x) -> im2row + split | amax(weights) -> expand-weight pack -> its S16 split -> weight packs |
+// activation bounds takes 125 us before the first GEMM (tools/region_time.py) -- launch A holds everything that depends on
+// nothing (all maxima, the activation bounds), launch B everything that needs only those.
+// ---------------------------------------------------------------------------------------------------------
+struct PrologueA {
+  const float* src[kMaxLayers];
+  int64_t n[kMaxLayers];
+  float* bound[kMaxLayers];    // 32-slot bound of tensor i (zeroed by the caller)
+  float floor_[kMaxLayers];
+  int n_tensors;
+  ActBoundsMulti ab;           // ab.n_layers == 0: none
+};
+
+__global__ void __launch_bounds__(256) k_prologue_a(PrologueA a) {
+  __shared__ float red[4];
+  __shared__ float done[kMaxLayers];
+  const int ti = blockIdx.y;
+  if (ti < a.n_tensors) {
+    const float* src = a.src[ti];
+    const int64_t n = a.n[ti];
+    float m = a.floor_[ti];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? n >> 2 : 0;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {       // four 16-byte loads in flight per thread
+      const f32x4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[e]), fabsf(v1[e]))), fmaxf(fabsf(v2[e]), fabsf(v3[e])));
+    }
+    for (; i < n4; i += stride) {
+      const f32x4 v = s4[i];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = fmaxf(m, fabsf(src[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) s16_atomic_bound(a.bound[ti], fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    return;
+  }
+  if (blockIdx.x != 0) return;                           // one block: the activation bounds of all layers (k_act_bounds_multi)
+  const ActBoundsMulti& b = a.ab;
+  for (int li = 0; li < b.n_layers; ++li) {
+    float m = 0.f;
+    for (int c = threadIdx.x; c < b.C; c += 256) m = fmaxf(m, fabsf(b.gamma[li][c]) * b.sqrt_m1[li] + fabsf(b.beta[li][c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * b.inv_keep + (b.res_from[li] >= 0 ? done[b.res_from[li]] : 0.f);
+      done[li] = v;
+      b.bounds[li * kBoundSlots] = v;
+    }
+    __syncthreads();
+  }
+}
+
+struct PrologueB {
+  // blocks [0, n_in): im2row + S16 split of the raw input (k_split_t<true>): (kpad / 64) x row tiles
+  int M, kpad, n_in;
+  const float* x;
+  const float* x_bound;
+  float* x_rows;
+  TOut x_t;
+  Im2Row g;
+  // blocks [n_in, n_in + n_w0): the expand conv's weight W0 [c0][cin0][taps0] -> fp32 pack [c0][kpad] (zero padded) and its
+  // S16 rows (vp3d_pack_weight + vp3d_split_rows): 16 rows x (kpad / 8) groups per block
+  int n_w0, c0, cin0, taps0;
+  const float* w0;
+  const float* w0_bound;
+  float* w0_packed;
+  float* w0_s16;
+  // blocks behind: the C x C weight packs (k_pack_weight_s16_multi): (c_in / 64) x (c_out / 64) x layers
+  PackMulti pk;
+  int pk_layers;
+};
+
+__global__ void __launch_bounds__(256) k_prologue_b(PrologueB a) {
+  extern __shared__ float tile[];
+  int b = blockIdx.x;
+  if (b < a.n_in) {
+    const int gx = a.kpad / 64;
+    split_t_body<true>(a.M, a.kpad, a.x, (int64_t)0, a.x_bound, a.x_rows, (int64_t)a.kpad, a.x_t, a.g, tile, b % gx, b / gx);
+    return;
+  }
+  b -= a.n_in;
+  if (b < a.n_w0) {
+    const int groups = a.kpad / 8, rows_per = 256 / groups;
+    const int r = threadIdx.x / groups, g8 = threadIdx.x % groups;
+    const int co = b * rows_per + r;
+    if (r >= rows_per || co >= a.c0) return;
+    const int kv = a.cin0 * a.taps0;
+    const float inv = s16_pow2(-s16_exp_of(a.w0_bound));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = g8 * 8 + e;
+      const int k = j / a.cin0, ci = j - k * a.cin0;
+      v[e] = j < kv ? a.w0[((int64_t)co * a.cin0 + ci) * a.taps0 + k] : 0.f;
+    }
+    float* dst = a.w0_packed + (int64_t)co * a.kpad + g8 * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    f16x8 hi, lo;
+    s16_split8(v, inv, hi, lo);
+    f16x8* o = reinterpret_cast<f16x8*>(a.w0_s16 + (int64_t)co * a.kpad + g8 * 8);
+    o[0] = hi;
+    o[1] = lo;
+    return;
+  }
+  b -= a.n_w0;
+  const int gx = a.pk.c_in / 64, gy = a.pk.c_out / 64;
+  const int li = b / (gx * gy), q = b - li * (gx * gy);
+  if (li < a.pk_layers) pack_weight_s16_multi_body(a.pk, tile, q % gx, q / gx, li);
 }
 
 // BN backward finalize (dgamma, dbeta from the partial sums, fp64) + the bound of dy in the same launch:
@@ -1026,6 +1158,88 @@ int vp3d_act_bounds_multi(vp3d_stream_t stream, int32_t n_layers, int32_t C, con
   a.inv_keep = 1.0f / (1.0f - p);
   hipLaunchKernelGGL(k_act_bounds_multi, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return check_launch("act_bounds_multi");
+}
+
+int vp3d_prologue_a_s16(vp3d_stream_t stream, int32_t n_tensors, const float* const* src, const int64_t* n, float* const* bound,
+                        const float* floor_, int32_t n_layers, int32_t C, const float* const* gamma, const float* const* beta,
+                        const int64_t* M, const int32_t* res_from, float p, float* act_bounds) {
+  VP3D_REQUIRE(n_tensors > 0 && n_tensors <= kMaxLayers && src && n && bound && n_layers >= 0 && n_layers <= kMaxLayers &&
+                   (n_layers == 0 || (C > 0 && gamma && beta && M && res_from && act_bounds)) && p >= 0.f && p < 1.f,
+               "prologue_a_s16: bad argument (at most %d tensors / layers)", kMaxLayers);
+  PrologueA a{};
+  int64_t nmax = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    VP3D_REQUIRE(src[i] && n[i] > 0 && bound[i], "prologue_a_s16: tensor %d", i);
+    a.src[i] = src[i];
+    a.n[i] = n[i];
+    a.bound[i] = bound[i];
+    a.floor_[i] = floor_ ? floor_[i] : 0.f;
+    nmax = n[i] > nmax ? n[i] : nmax;
+  }
+  a.n_tensors = n_tensors;
+  for (int i = 0; i < n_layers; ++i) {
+    VP3D_REQUIRE(gamma[i] && beta[i] && res_from[i] < i, "prologue_a_s16: layer %d", i);
+    a.ab.gamma[i] = gamma[i];
+    a.ab.beta[i] = beta[i];
+    a.ab.sqrt_m1[i] = sqrtf((float)(M[i] > 1 ? M[i] - 1 : 1));
+    a.ab.res_from[i] = res_from[i];
+  }
+  a.ab.bounds = act_bounds;
+  a.ab.n_layers = n_layers;
+  a.ab.C = C;
+  a.ab.inv_keep = 1.0f / (1.0f - p);
+  int64_t blocks = (nmax + 256 * 32 - 1) / (256 * 32);
+  blocks = blocks < 512 ? blocks : 512;
+  hipLaunchKernelGGL(k_prologue_a, dim3((unsigned)blocks, n_tensors + 1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("prologue_a_s16");
+}
+
+int vp3d_prologue_b_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, int32_t ldx, int32_t k_valid, int32_t kpad,
+                        int32_t one_col, const float* x_bound, void* x_rows, void* x_t, int64_t ld_t, const float* w0, int32_t c0,
+                        int32_t cin0, int32_t taps0, const float* w0_bound, float* w0_packed, void* w0_s16, int32_t n_layers,
+                        const float* const* w, const int32_t* taps, int32_t c_out, int32_t c_in, const float* w_bounds,
+                        void* const* wf, void* const* wd) {
+  VP3D_REQUIRE(map && x && x_bound && x_rows && w0 && w0_bound && w0_packed && w0_s16, "prologue_b_s16: null pointer");
+  VP3D_REQUIRE(one_col < 0 || (one_col >= k_valid && one_col < kpad), "prologue_b_s16: the bias column must be a padding column");
+  VP3D_REQUIRE(map->batch > 0 && map->t_dst > 0 && map->t_src > 0 && k_valid > 0 && kpad >= k_valid && kpad % 64 == 0 && kpad <= 128 &&
+                   aligned16(x_rows) && aligned16(w0_packed) && aligned16(w0_s16) && c0 > 0 && cin0 > 0 && taps0 > 0 &&
+                   cin0 * taps0 == k_valid,
+               "prologue_b_s16: bad sizes (k_valid=%d kpad=%d)", k_valid, kpad);
+  VP3D_REQUIRE((int64_t)(map->t_dst - 1) * map->t_stride * ldx + k_valid <= (int64_t)map->t_src * ldx,
+               "prologue_b_s16: rows run past the end of a sample");
+  const int64_t M = (int64_t)map->batch * map->t_dst;
+  VP3D_REQUIRE(M < ((int64_t)1 << 31) && (M + 63) / 64 <= 65535 * (int64_t)16, "prologue_b_s16: too many rows (M=%lld)", (long long)M);
+  int rc = check_t("prologue_b_s16", x_t, ld_t, 1, M);
+  if (rc) return rc;
+  VP3D_REQUIRE(n_layers >= 0 && n_layers <= kMaxLayers && (n_layers == 0 || (w && taps && w_bounds && wf && wd && c_out > 0 && c_in > 0 &&
+                                                                              c_out % 64 == 0 && c_in % 64 == 0)),
+               "prologue_b_s16: bad weight-pack argument");
+  PrologueB a{};
+  a.M = (int)M; a.kpad = kpad; a.n_in = (kpad / 64) * (int)((M + 63) / 64);
+  a.x = x; a.x_bound = x_bound; a.x_rows = (float*)x_rows;
+  a.x_t = TOut{(float*)x_t, ld_t, 1};
+  a.g = Im2Row{map->t_dst, map->t_src, map->t_stride, ldx, k_valid, one_col < 0 ? -1 : one_col, make_fastdiv(map->t_dst)};
+  const int rows_per = 256 / (kpad / 8);
+  a.n_w0 = (c0 + rows_per - 1) / rows_per; a.c0 = c0; a.cin0 = cin0; a.taps0 = taps0;
+  a.w0 = w0; a.w0_bound = w0_bound; a.w0_packed = w0_packed; a.w0_s16 = (float*)w0_s16;
+  int tmax = 1;
+  for (int i = 0; i < n_layers; ++i) {
+    VP3D_REQUIRE(w[i] && taps[i] >= 1 && taps[i] <= 3 && (wf[i] || wd[i]) && aligned16(wf[i]) && aligned16(wd[i]),
+                 "prologue_b_s16: layer %d (taps 1..3, 16-byte aligned outputs)", i);
+    a.pk.w[i] = w[i];
+    a.pk.wf[i] = (float*)wf[i];
+    a.pk.wd[i] = (float*)wd[i];
+    a.pk.taps[i] = taps[i];
+    tmax = taps[i] > tmax ? taps[i] : tmax;
+  }
+  a.pk.bounds = w_bounds;
+  a.pk.c_out = c_out;
+  a.pk.c_in = c_in;
+  a.pk_layers = n_layers;
+  const int n_pk = n_layers ? (c_in / 64) * (c_out / 64) * n_layers : 0;
+  const size_t lds = (size_t)(n_layers ? tmax : 1) * 64 * TPITCH * 4;
+  hipLaunchKernelGGL(k_prologue_b, dim3((unsigned)(a.n_in + a.n_w0 + n_pk)), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("prologue_b_s16");
 }
 
 int vp3d_bn_bwd_finalize_s16(vp3d_stream_t stream, int32_t C, int64_t M, const float* partials, int32_t nparts,

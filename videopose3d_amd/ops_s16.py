@@ -631,6 +631,57 @@ def act_bounds_multi(bns, m_rows, res_from, p: float, bounds: torch.Tensor):
           "vp3d_act_bounds_multi")
 
 
+def prologue_a(tensors, tensor_bounds, floors, bns, m_rows, res_from, p: float, act_bounds: torch.Tensor):
+    """Launch A of the fused prologue (vp3d_prologue_a_s16): tensor_bounds[i] = max(floors[i], max|tensors[i]|) for every
+    tensor and act_bounds[l] = guaranteed bound of layer l's activation -- amax / amax_multi / act_bounds_multi in one launch."""
+    n, nl = len(tensors), len(bns)
+    for t in tensors:
+        ops._chk(t, "t")
+    check(_lib.lib().vp3d_prologue_a_s16(ops._stream(), n, _ptr_array(tensors), (C.c_int64 * n)(*[t.numel() for t in tensors]),
+                                         _ptr_array(tensor_bounds), (C.c_float * n)(*floors), nl, bns[0].num_features,
+                                         _ptr_array([b.weight for b in bns]), _ptr_array([b.bias for b in bns]),
+                                         (C.c_int64 * nl)(*m_rows), (C.c_int32 * nl)(*res_from), float(p), act_bounds.data_ptr()),
+          "vp3d_prologue_a_s16")
+
+
+def prologue_b(x: torch.Tensor, spec: ConvSpec, kpad: int, one_col: int, x_bound: torch.Tensor, want_t: bool, w0: torch.Tensor,
+               w0_bound: torch.Tensor, weights, w_bounds: torch.Tensor, want_dgrad: bool):
+    """Launch B of the fused prologue (vp3d_prologue_b_s16): im2row_split(x) + pack_weight / split of the expand conv's weight
+    + pack_weights_multi(weights) in one launch.  Returns (x_rows S16, x_t S16 or None, w0_packed fp32 [C][kpad], w0 S16,
+    [(S16 fwd pack, S16 dgrad pack or None)] for `weights`)."""
+    ops._chk(x, "x")
+    assert spec.dil == 1 and kpad % 64 == 0
+    b, t_in, c_in0 = x.shape
+    t_out = spec.t_out(t_in)
+    m = b * t_out
+    dev = x.device
+    rows = torch.empty((b, t_out, kpad), dtype=torch.float32, device=dev)
+    tt = torch.empty((kpad, t_pitch(m)), dtype=torch.float32, device=dev) if want_t else None
+    c0 = w0.shape[0]
+    w0_packed = torch.empty((c0, kpad), dtype=torch.float32, device=dev)
+    w0_s16 = torch.empty((c0, kpad), dtype=torch.float32, device=dev)
+    wfs, wds, taps = [], [], []
+    c_out = c_in = 0
+    if weights:
+        c_out, c_in = weights[0].shape[0], weights[0].shape[1]
+        for w in weights:
+            assert w.shape[0] == c_out and w.shape[1] == c_in
+            k = w.shape[2]
+            taps.append(k)
+            wfs.append(torch.empty((c_out, k * c_in), dtype=torch.float32, device=dev))
+            wds.append(torch.empty((k * c_in, c_out), dtype=torch.float32, device=dev) if want_dgrad else None)
+    rm = RowMap(b, t_out, t_in, spec.stride, 0, 0, 1)
+    nl = len(weights)
+    check(_lib.lib().vp3d_prologue_b_s16(ops._stream(), C.byref(rm), x.data_ptr(), c_in0, spec.taps * c_in0, kpad, one_col,
+                                         x_bound.data_ptr(), rows.data_ptr(), ops._p(tt), tt.shape[1] if tt is not None else 0,
+                                         w0.data_ptr(), c0, w0.shape[1], w0.shape[2], w0_bound.data_ptr(), w0_packed.data_ptr(),
+                                         w0_s16.data_ptr(), nl, _ptr_array(weights), (C.c_int32 * max(nl, 1))(*(taps or [1])),
+                                         c_out, c_in, w_bounds.data_ptr() if nl else None, _ptr_array(wfs), _ptr_array(wds)),
+          "vp3d_prologue_b_s16")
+    packs = [(S16(wf, w_bounds[i]), S16(wd, w_bounds[i]) if wd is not None else None) for i, (wf, wd) in enumerate(zip(wfs, wds))]
+    return S16(rows, x_bound), (S16(tt, x_bound) if tt is not None else None), w0_packed, S16(w0_s16, w0_bound), packs
+
+
 # --------------------------------------------------------------------------------------------------------
 # persistent small-M tail (vp3d_tail_fwd_s16 / vp3d_tail_bwd_s16: csrc/vp3d_tail_s16.hip)
 # --------------------------------------------------------------------------------------------------------
