@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-( timeout 300 python -m pytest tests/test_gpu_s16.py tests/test_gpu_tail.py -m gpu -x -q -k "fused_prologue or tail" ) 2>&1 | tail -5
+for n in 0 4 8 2; do
+  echo "VP3D_SIDE_CU_SKIP=$n"
+  VP3D_SIDE_CU_SKIP=$n python tools/env_ab.py VP3D_OVERLAP 1 1 2 25 2>&1 | grep -v amdgpu | tail -1
+done

@@ -11,8 +11,11 @@ import sys
 import tempfile
 
 B = "/opt/rocm/lib/llvm/bin/"
-lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "videopose3d_amd", "libvp3d.so")
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+args = sys.argv[1:]
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "videopose3d_amd", "libvp3d.so")
+if args and os.path.exists(args[0]):
+    lib = args.pop(0)
+flt = args[0] if args else ""
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 with tempfile.TemporaryDirectory() as d:
     fat = os.path.join(d, "fat.bin")
