@@ -426,3 +426,33 @@ def test_s16_engine_rejects_gather_form_training_beyond_the_kernel_row_limit():
     assert not engine_s16.supported(m, 243, True, batch=65535 * 64 // 200)
     s = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=64)      # windows tile: no gathered operand at all
     assert engine_s16.supported(s, 27, True, batch=65535 * 64)
+
+
+def test_tail_structs_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors of vp3d_tail_fwd / vp3d_tail_bwd (+ their per-layer structs) against include/vp3d.h compiled by the C
+    compiler: size and the offset of EVERY field (a silently shifted pointer would be read as garbage by the kernels)."""
+    import shutil
+    import subprocess
+    import ctypes as C
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("vp3d_tail_fwd_layer", _lib.TailFwdLayer), ("vp3d_tail_fwd", _lib.TailFwd), ("vp3d_tail_bwd_layer", _lib.TailBwdLayer),
+             ("vp3d_tail_bwd", _lib.TailBwd), ("vp3d_dropout", _lib.Dropout), ("vp3d_rowmap", _lib.RowMap)]
+    lines = ['#include "vp3d.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        got = [int(v) for v in line.split()[1:]]
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert got == want, (cname, got, want)
