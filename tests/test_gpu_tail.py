@@ -131,3 +131,21 @@ def test_tail_step_vs_oracle(monkeypatch):
             assert float(np.abs(sd1[k].cpu().numpy() - v).max() / (np.abs(v).max() + 1e-12)) < 1e-4, k
     finally:
         engine.S16_MIN_FORWARD_FLOPS.update(keep)
+
+
+def test_flat_barrier_fallback_in_a_fresh_process():
+    """The barrier flavour is chosen once per process and device (probe launch); VP3D_TAIL_FLAT_BARRIER=1 forces the fallback in
+    which every workgroup does its own cache write-back / invalidate: one parity case through it, in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VP3D_TAIL_FLAT_BARRIER="1")
+    code = ("import videopose3d_amd as V\n"
+            "from videopose3d_amd import _lib\n"
+            "import pytest, sys\n"
+            "rc = pytest.main(['-q', '-x', '-m', 'gpu', 'tests/test_gpu_tail.py', '-k', 'B64_arc333 or step_vs_oracle'])\n"
+            "assert _lib.lib().vp3d_tail_barrier_grouped() == 0\n"
+            "sys.exit(int(rc))\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-500:]

@@ -32,6 +32,7 @@
 #include "vp3d_s16_stream_bodies.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace vp3d {
@@ -688,8 +689,10 @@ struct TailGrid {
   int grouped = 0;  // 1: a probe launch of that grid put workgroup b on XCD b % 8
 };
 TailGrid g_grid[64];
+std::mutex g_grid_mutex;                               // (first use per device: occupancy query + probe launch)
 
 int tail_grid(bool fwd, int* wgs) {
+  std::lock_guard<std::mutex> lock(g_grid_mutex);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
     set_error("tail: hipGetDevice failed");

@@ -723,6 +723,25 @@ def tail_error(device) -> int:
     return int(_tail_sync(device)[0].item())
 
 
+_tail_flag_host = {}
+
+
+def _tail_watch(device):
+    """Time-outs must not pass silently: after every launch the error flag is copied (stream-ordered, non-blocking) into a
+    pinned host word, and before every launch the word of the EARLIER launches is looked at -- no synchronisation, at most a
+    step of delay.  A time-out means some workgroup was never resident (another process on the GPU, a grid larger than the
+    occupancy): the results of that launch are invalid."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    h = _tail_flag_host.get(key)
+    if h is None:
+        h = _tail_flag_host[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    elif int(h[0]) != 0:
+        h[0] = 0
+        raise _lib.Vp3dError("a grid barrier of an earlier persistent-tail launch timed out (VP3D_TAIL=1): its results were invalid; "
+                             "run with VP3D_TAIL=0 (the default per-layer launches)")
+    return h
+
+
 def tail_fwd(c: int, x0: S16, layers, eps: float, momentum: float, momentum_dev: Optional[int] = None):
     """Forward of the tail's layers in one launch.  layers: list of dicts with
          M, taps, res_start, wf (S16), gamma, beta, running_mean, running_var, nbt (tensors or None), y, coef, a (tensors),
@@ -757,8 +776,11 @@ def tail_fwd(c: int, x0: S16, layers, eps: float, momentum: float, momentum_dev:
     d.sync = _tail_sync(dev).data_ptr()
     d.trace = ops._p(TAIL_TRACE["fwd"])
     TAIL_CALLS["fwd"] += 1
+    watch = _tail_watch(dev)
     ops._timed_call("tconv_fwd", flops, _lib.lib().vp3d_tail_fwd_s16, ops._stream(), C.byref(d), nbytes=nbytes,
                     shape=(layers[0]["M"], c, layers[0]["taps"] * c, "tail", n, 1))
+    if not torch.cuda.is_current_stream_capturing():
+        watch.copy_(_tail_sync(dev)[:1], non_blocking=True)
 
 
 def tail_bwd(c: int, p: float, layers, dx0: torch.Tensor, dx0_bound: torch.Tensor):
@@ -792,5 +814,8 @@ def tail_bwd(c: int, p: float, layers, dx0: torch.Tensor, dx0_bound: torch.Tenso
     d.sync = _tail_sync(dev).data_ptr()
     d.trace = ops._p(TAIL_TRACE["bwd"])
     TAIL_CALLS["bwd"] += 1
+    watch = _tail_watch(dev)
     ops._timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tail_bwd_s16, ops._stream(), C.byref(d), nbytes=nbytes,
                     shape=(layers[0]["M"], layers[0]["taps"] * c, c, "tail", n, 1))
+    if not torch.cuda.is_current_stream_capturing():
+        watch.copy_(_tail_sync(dev)[:1], non_blocking=True)
