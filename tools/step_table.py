@@ -58,7 +58,9 @@ def _last_steps(rows):
     (k_split_t<true>; k_im2row on the older path) --; the last N_KEEP steps."""
     starts = []
     for i, r in enumerate(rows):
-        if "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
+        if "k_prologue_a" in r[0]:                     # round 3: the two-launch prologue opens a step
+            starts.append(i)
+        elif "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
             starts.append(i - 1 if (i > 0 and "k_amax(" in rows[i - 1][0] and "k_split_t<true>" in r[0]) else i)
     assert len(starts) >= N_KEEP, "fewer steps than expected in the trace"
     bounds = starts[-N_KEEP:] + [len(rows)]

@@ -8,7 +8,9 @@ rows = db.execute("select name, start, end, queue_id, stream_id from kernels ord
 # a step starts at the maximum over the raw input + the fused im2row / S16 split (k_im2row on the older path)
 starts = []
 for i, r in enumerate(rows):
-    if "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
+    if "k_prologue_a" in r[0]:                         # round 3: the two-launch prologue opens a step
+        starts.append(i)
+    elif "k_im2row" in r[0] or "k_split_t<true>" in r[0]:
         starts.append(i - 1 if (i > 0 and "k_amax(" in rows[i - 1][0] and "k_split_t<true>" in r[0]) else i)
 lo = starts[-1]
 t0 = rows[lo][1]
