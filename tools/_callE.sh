@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-( timeout 600 python -m pytest tests/test_gpu_tail.py -m gpu -x -q ) 2>&1 | tail -5
+for mr in 16384 8192 2048; do
+  echo "min rows $mr"
+  VP3D_FWD_SPLIT_MIN_ROWS=$mr python tools/env_ab.py VP3D_FWD_SPLIT 0 1 3 30 2>&1 | grep -v amdgpu
+done
