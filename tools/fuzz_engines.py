@@ -86,5 +86,7 @@ for case in range(n_cases):
     except Exception as e:                               # noqa: BLE001  (report and go on: this is a bug hunt)
         bad += 1
         print("EXC  %-86s %s" % (tag, repr(e)[:300]), flush=True)
+from videopose3d_amd import ops_s16 as _S  # noqa: E402
+print("tail launches: %d forward, %d backward" % (_S.TAIL_CALLS["fwd"], _S.TAIL_CALLS["bwd"]))
 print("%d / %d cases failed" % (bad, n_cases))
 sys.exit(1 if bad else 0)
