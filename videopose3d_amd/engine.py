@@ -175,6 +175,32 @@ def _wgrad_stream(device, default_on: bool = False) -> Optional[torch.cuda.Strea
     return st
 
 
+# graph.py's piecewise capture: while set, the main -> second-stream hand-overs of backward END the graph being captured on
+# one stream and BEGIN the next one on the other (instead of an event dependency inside ONE graph, which hipGraph replays
+# serially on this runtime); the replay re-creates the dependencies with events between the graph launches
+_segmenter = None
+
+
+def fork_to_side(main, side, ev) -> None:
+    """Everything queued on `main` so far happens before what is queued on `side` from here on."""
+    if _segmenter is not None:
+        _segmenter.to_side()
+    else:
+        ev.record(main)
+        side.wait_event(ev)
+
+
+def fork_back() -> None:
+    """The second-stream work of this hand-over has been queued (pairs with fork_to_side)."""
+    if _segmenter is not None:
+        _segmenter.to_main()
+
+
+def join_side(main, side) -> None:
+    if _segmenter is None:
+        main.wait_stream(side)
+
+
 _fork_events = {}
 
 

@@ -179,6 +179,9 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
     return kv
 
 
+# piecewise graph capture: hand-overs of layers below this many rows stay on the main stream (measured at B = 1024: every
+# hand-over kept is worth its graph boundary -- 4.55 ms with all of them, 4.61 with the four large layers only, 4.67 with two)
+SEG_FORK_MIN_ROWS = int(os.environ.get("VP3D_SEG_FORK_MIN_ROWS", "0"))
 TAIL_MAX_ROWS = int(os.environ.get("VP3D_TAIL_MAX_ROWS", "3072"))     # B * T_out up to which a block runs in the persistent tail
 
 
@@ -473,7 +476,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     def group_done(on_side=True):
         # the bucket's all-reduce follows the stream that produced the group's last gradients
         if sink is not None:
-            if side is not None and on_side:
+            if side is not None and on_side and engine._segmenter is None:
                 with torch.cuda.stream(side):
                     sink.group_done(n_done[0])
             else:
@@ -488,7 +491,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
                L[0].bits is not None and L[0].bits.numel() * 32 < 2 ** 31 and
                L[0].x_t is not None and L[0].x_t.data.numel() * 4 < 2 ** 31)
     if L[0].one_col >= 0 and not fused_p:
-        if side is not None:
+        if side is not None and engine._segmenter is None:        # (a mid-backward join: not cut into graph pieces)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 gram_xx = S.gram(L[0].x_t)
@@ -500,10 +503,11 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
 
     o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
     if side is not None:          # nothing in backward reads the shrink gradients: off the dependent chain as well (-0.7 %)
-        side.wait_stream(main)
+        engine.fork_to_side(main, side, engine._fork_event(dev, -2))
         with torch.cuda.stream(side):
             d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
             d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
+        engine.fork_back()
         for t_ in (d_sb, d_sw):
             if t_ is not None:
                 t_.record_stream(main)
@@ -545,13 +549,13 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             if L[idx].wform == "gather":             # dilated / ragged windows / wide filters: build the operand now
                 x_t = S.gather_t(L[idx].x_rows, spec, L[idx].y.shape[1])
             return S.wgrad(dy_t, x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
-        if side is not None and on_side:
+        if side is not None and on_side and (engine._segmenter is None or m_rows >= SEG_FORK_MIN_ROWS):
             # nothing inside backward consumes dW: it runs beside the next layer's HBM-bound BatchNorm-backward kernels
-            ev = engine._fork_event(dev, idx)
-            ev.record(main)
-            side.wait_event(ev)
+            # (piecewise graph capture: only the large layers' hand-overs are worth a graph boundary)
+            engine.fork_to_side(main, side, engine._fork_event(dev, idx))
             with torch.cuda.stream(side):
                 dw = gemm()
+            engine.fork_back()
             if out is None:
                 dw.record_stream(main)
             keep.append((dy_t, L[idx].x_t, L[idx].x_rows, dw))
@@ -669,7 +673,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         # GEMM (still on the second stream) instead of queueing behind it (-0.4 %)
         wgrad(0, dy0_t, on_side=False)
     if side is not None:
-        main.wait_stream(side)
+        engine.join_side(main, side)
         keep.clear()
     group_done(on_side=False)
     return grads + [d_sw, d_sb], dx_in

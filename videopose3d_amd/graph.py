@@ -29,6 +29,7 @@ exchange runs after the replay (``sync.sync()``: one all-reduce of the flat buff
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
@@ -41,7 +42,7 @@ DEBUG_DOT_PATH = None      # tools/graph_branches.py: write hipGraphDebugDotPrin
 
 
 class _Entry:
-    __slots__ = ("graph", "x", "t", "loss", "keep", "guard", "grads")
+    __slots__ = ("graph", "x", "t", "loss", "keep", "guard", "grads", "segments", "fork_event")
 
 
 def _momentum_guard(m):
@@ -59,6 +60,66 @@ def _arm_device_momentum(m, dev):
     m._momentum_dev_ptr()                              # value in step with the modules BEFORE anything is captured
 
 
+class _Segments:
+    """Piecewise capture of a step whose backward hands work to the second stream: graph k on the main stream ends at a
+    hand-over, graph k' on the second stream holds the handed-over work, the next main graph follows (engine.fork_to_side /
+    fork_back call to_side / to_main).  ``replay`` launches them in capture order, each main -> side hand-over as an event
+    between two graph launches, and joins at the end: the two streams overlap as they do in the eager step, which ONE graph
+    with fork / join edges does not on this runtime (hipGraph replays its branches serially: DESIGN.md 4.8)."""
+
+    def __init__(self, pool, main, side):
+        self.pool, self.main, self.side = pool, main, side
+        self.graphs = []
+        self._cur = None
+
+    def _begin(self, kind):
+        ctx = torch.cuda.stream(self.main if kind == "main" else self.side)
+        ctx.__enter__()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self._cur = (kind, g, ctx)
+
+    def _end(self):
+        kind, g, ctx = self._cur
+        g.capture_end()
+        ctx.__exit__(None, None, None)
+        self.graphs.append((kind, g))
+        self._cur = None
+
+    def begin(self):
+        self._begin("main")
+
+    def end(self):
+        self._end()
+
+    def abort(self):
+        if self._cur is not None:
+            try:
+                self._end()
+            except Exception:  # noqa: BLE001
+                pass
+
+    def to_side(self):
+        self._end()
+        self._begin("side")
+
+    def to_main(self):
+        self._end()
+        self._begin("main")
+
+    def replay(self, fork_event):
+        main = torch.cuda.current_stream()
+        for kind, g in self.graphs:
+            if kind == "main":
+                g.replay()
+            else:
+                fork_event.record(main)
+                self.side.wait_event(fork_event)
+                with torch.cuda.stream(self.side):
+                    g.replay()
+        main.wait_stream(self.side)
+
+
 def _new_graph():
     g = torch.cuda.CUDAGraph()
     if DEBUG_DOT_PATH:
@@ -72,7 +133,10 @@ def _dump_dot(g):
 
 
 class GraphedTrainStep:
-    def __init__(self, model, sync: Optional[dp.FlatGradSync] = None):
+    def __init__(self, model, sync: Optional[dp.FlatGradSync] = None, piecewise: Optional[bool] = None):
+        # piecewise (default on, VP3D_GRAPH_PIECEWISE=0 / piecewise=False: one graph): capture the step as graph pieces per
+        # stream so that the replay keeps the eager backward's two-stream overlap
+        self.piecewise = (os.environ.get("VP3D_GRAPH_PIECEWISE", "1") != "0") if piecewise is None else bool(piecewise)
         self.model = model
         self.sync = sync if sync is not None else dp.FlatGradSync(model.parameters(), direct_module=model)
         if model.__dict__.get("_vp3d_grad_sink") is not self.sync:
@@ -150,15 +214,39 @@ class GraphedTrainStep:
         key = x.device.index
         cached = engine._side_streams.get(key)
         engine._side_streams[key] = torch.cuda.Stream(device=x.device)
-        e.graph = _new_graph()
+        e.segments, e.fork_event, e.graph = None, None, None
+        piecewise = (self.piecewise and DEBUG_DOT_PATH is None and engine.use_s16(m, x.shape[1], True, batch=x.shape[0]) and
+                     os.environ.get("VP3D_OVERLAP", "1") == "1")
         try:
-            with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):   # (an RCCL watchdog thread may be alive)
-                e.loss = self._step(e.x, e.t)
+            if piecewise:
+                # graph pieces per stream (see _Segments): the replay keeps the two-stream overlap of the eager backward
+                torch.cuda.synchronize()
+                cap_main = torch.cuda.Stream(device=x.device)
+                seg = _Segments(torch.cuda.graph_pool_handle(), cap_main, engine._side_streams[key])
+                cap_main.wait_stream(torch.cuda.current_stream())
+                engine._segmenter = seg
+                try:
+                    with torch.cuda.stream(cap_main):
+                        seg.begin()
+                        e.loss = self._step(e.x, e.t)
+                        seg.end()
+                except BaseException:
+                    seg.abort()
+                    raise
+                finally:
+                    engine._segmenter = None
+                torch.cuda.current_stream().wait_stream(cap_main)
+                e.segments, e.fork_event = seg, torch.cuda.Event()
+            else:
+                e.graph = _new_graph()
+                with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):   # (an RCCL watchdog thread may be alive)
+                    e.loss = self._step(e.x, e.t)
         finally:
             e.keep = engine._side_streams.pop(key)
             if cached is not None:
                 engine._side_streams[key] = cached
-        _dump_dot(e.graph)
+        if e.graph is not None:
+            _dump_dot(e.graph)
         m._drop_calls, m._stats_epoch = counters[0], counters[1]   # capture executes nothing: host-side counters as before
         return e
 
@@ -178,7 +266,10 @@ class GraphedTrainStep:
         e.x.copy_(inputs_2d.reshape(e.x.shape))
         e.t.copy_(inputs_3d.reshape(e.t.shape))
         self.model._stats_epoch += 1                  # the running statistics are about to change (eval-fold cache key)
-        e.graph.replay()
+        if e.segments is not None:
+            e.segments.replay(e.fork_event)
+        else:
+            e.graph.replay()
         if self.sync._reduce:
             self.sync.sync()
         return e.loss
