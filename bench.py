@@ -601,21 +601,6 @@ def main():
     dtype = ("f32 (products on split-fp16 MFMA: 22+ bit operands, exact fp16 products, fp32 accumulate)" if math == "f16x3"
              else "f32")
 
-    # the transposed-copy form of the C x C weight gradients (round 1's default; VP3D_WGRAD_ROWS=0), same step otherwise
-    rows_opt = None
-    if math == "f16x3" and os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and os.environ.get("VP3D_BENCH_AB", "0") == "1":
-        os.environ["VP3D_WGRAD_ROWS"] = "0"
-        try:                                  # informational: never lets the headline line fail
-            dt_r = time_steps(step, 3, args.steps)
-            rows_opt = {"what": "the same step with VP3D_WGRAD_ROWS=0 (weight gradients as NT GEMMs over transposed S16 copies "
-                                "written by the producers: round 1's default)",
-                        "ms_per_step": dt_r / args.steps * 1e3, "frames_per_s": world * B * args.steps / dt_r,
-                        "slowdown_vs_default": dt_r / dt}
-        except Exception as e:  # noqa: BLE001
-            rows_opt = {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            os.environ["VP3D_WGRAD_ROWS"] = "1"
-
     out = {
         "metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -707,8 +692,6 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- the same step on the exact-fp32 MFMA kernels (every rank: the step holds collectives) -------------
-    if rows_opt is not None:
-        out["wgrad_transposed_copies"] = rows_opt
     if math != "f32" and not args.no_f32:
         model, sync, step = build("f32")
         k32 = max(5, args.steps // 2)

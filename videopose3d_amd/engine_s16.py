@@ -171,17 +171,14 @@ def expand_kpad(spec: ConvSpec) -> int:
 def expand_shortcut_column(plan: StackPlan, sync) -> int:
     """Padding column of the expand conv's im2row rows that carries the constant 1 of the no-dy backward of the expand
     layer (expand_bwd below), or -1 when that backward is not used: no spare padding column, synchronised BatchNorm
-    (the formulas need the global sums between the two reductions), or VP3D_EXPAND_BWD=0."""
+    (the formulas need the global sums between the two reductions)."""
     spec = plan.convs[0]
     kpad, kv = expand_kpad(spec), spec.taps * spec.c_in
-    if os.environ.get("VP3D_EXPAND_BWD", "1") == "0" or sync is not None or not kpad or kv >= kpad or kpad > 128:
+    if sync is not None or not kpad or kv >= kpad or kpad > 128:
         return -1
     return kv
 
 
-# piecewise graph capture: hand-overs of layers below this many rows stay on the main stream (measured at B = 1024: every
-# hand-over kept is worth its graph boundary -- 4.55 ms with all of them, 4.61 with the four large layers only, 4.67 with two)
-SEG_FORK_MIN_ROWS = int(os.environ.get("VP3D_SEG_FORK_MIN_ROWS", "0"))
 TAIL_MAX_ROWS = int(os.environ.get("VP3D_TAIL_MAX_ROWS", "3072"))     # B * T_out up to which a block runs in the persistent tail
 
 
@@ -549,9 +546,10 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             if L[idx].wform == "gather":             # dilated / ragged windows / wide filters: build the operand now
                 x_t = S.gather_t(L[idx].x_rows, spec, L[idx].y.shape[1])
             return S.wgrad(dy_t, x_t, spec.c_out, spec.c_in, spec.taps, n_cols, out=out, flops_rows=m_rows)
-        if side is not None and on_side and (engine._segmenter is None or m_rows >= SEG_FORK_MIN_ROWS):
+        if side is not None and on_side:
             # nothing inside backward consumes dW: it runs beside the next layer's HBM-bound BatchNorm-backward kernels
-            # (piecewise graph capture: only the large layers' hand-overs are worth a graph boundary)
+            # (piecewise graph capture: every hand-over is worth its graph boundary -- 4.55 ms with all of them, 4.61 with the
+            # four large layers' only, 4.67 with two, B = 1024)
             engine.fork_to_side(main, side, engine._fork_event(dev, idx))
             with torch.cuda.stream(side):
                 dw = gemm()
@@ -595,7 +593,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         return dx
 
     # the trailing small-M blocks: one persistent launch (S.tail_bwd) instead of ~10 launches per block on two streams
-    tail0 = saved.get("tail0", 0) if os.environ.get("VP3D_TAIL_BWD", "1") != "0" else 0
+    tail0 = saved.get("tail0", 0)
     n_head = plan.n_blocks
     if tail0:
         n_head = (tail0 - 1) // 2

@@ -477,7 +477,6 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
     return S16(out, out_bound), (S16(tt, out_bound) if tt is not None else None)
 
 
-_FUSED_FINALIZE = os.environ.get("VP3D_FUSED_BN_BWD_FINALIZE", "1") != "0"
 _ticket_pool = {}
 
 
@@ -517,7 +516,7 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     else:
         dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
         dgam, dbet = dgb[0], dgb[1]
-    fused_fin = act_bits is not None and sync is None and _FUSED_FINALIZE
+    fused_fin = act_bits is not None and sync is None
     if fused_fin:
         # reduction + finalize + bound of dy in ONE launch (last-arriver blocks fold the partial rows): no [C]-sized kernel
         # that waits for a CU slot behind the second stream's weight-gradient GEMM
