@@ -456,3 +456,26 @@ def test_tail_structs_have_the_layout_of_the_header(tmp_path):
         got = [int(v) for v in line.split()[1:]]
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert got == want, (cname, got, want)
+
+
+def test_persistent_tail_selection_rules(monkeypatch):
+    """engine_s16.tail_from (which trailing blocks run in the persistent tail kernels when VP3D_TAIL=1): whole blocks of the
+    strided class whose windows tile, B * T_out <= 3072 rows, C % 64 == 0, one BatchNorm momentum, no synchronised BatchNorm;
+    off by default."""
+    from videopose3d_amd import engine_s16
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
+    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0                    # opt-in
+    monkeypatch.setenv("VP3D_TAIL", "1")
+    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 5                    # blocks 3 and 4: 3072 and 1024 rows
+    assert engine_s16.tail_from(m, m._plan, 243, 200, None, True) == 3                     # 200 * 27 rows are too many, 200 * 9 fit
+    assert engine_s16.tail_from(m, m._plan, 243, 64, None, True) == 1                      # 64 * 27 = 1728 rows: all four blocks = the 8 layers a tail may hold
+    assert engine_s16.tail_from(m, m._plan, 243, 8192, None, True) == 0                    # 8192 rows in the last block already
+    assert engine_s16.tail_from(m, m._plan, 243, 1024, object(), True) == 0                # synchronised BatchNorm
+    m.layers_bn[7].momentum = 0.5
+    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0                    # per-layer momenta
+    c = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], causal=True, channels=128)
+    assert engine_s16.tail_from(c, c._plan, 27, 16, None, True) == 1                       # every block, causal residual tap
+    d = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128)
+    assert engine_s16.tail_from(d, d._plan, 27, 16, None, True) == 0                       # dilated class: windows do not tile
+    n = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=96)
+    assert engine_s16.tail_from(n, n._plan, 27, 16, None, True) == 0                       # C % 64 != 0
