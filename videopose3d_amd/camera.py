@@ -6,12 +6,12 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return ops._stream()
 
 
 class _ProjectFn(torch.autograd.Function):

@@ -22,7 +22,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 from .dp import shard_bounds, shardable
 
@@ -96,7 +96,7 @@ class _Resident:
         g.out_3d = o3.data_ptr() if o3 is not None else None
         g.out_cam = oc.data_ptr() if oc is not None else None
         with torch.cuda.device(dev):
-            check(_lib.lib().vp3d_gather_chunks(torch.cuda.current_stream().cuda_stream, C.byref(g)),
+            check(_lib.lib().vp3d_gather_chunks(ops._stream(), C.byref(g)),
                   "vp3d_gather_chunks")
         return oc, o3, o2
 
@@ -346,6 +346,6 @@ def tta_average(predicted: torch.Tensor, joints_left=None, joints_right=None) ->
     perm = _perm_dev(j, joints_left, joints_right, p.device)
     out = torch.empty((1, t, j, d), dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
-        check(_lib.lib().vp3d_tta_fold(torch.cuda.current_stream().cuda_stream, t, j, d, p.data_ptr(),
+        check(_lib.lib().vp3d_tta_fold(ops._stream(), t, j, d, p.data_ptr(),
                                        perm.data_ptr() if perm is not None else None, out.data_ptr()), "vp3d_tta_fold")
     return out

@@ -14,7 +14,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 
@@ -143,7 +143,7 @@ class FlatAdam(torch.optim.Optimizer):
                       float(g["weight_decay"]), self._steps, 1 if g["amsgrad"] else 0)
         bufs = self._state_bufs
         with torch.cuda.device(self._flat_p.device):
-            check(_lib.lib().vp3d_adam_step(torch.cuda.current_stream().cuda_stream, self._n, self._flat_p.data_ptr(),
+            check(_lib.lib().vp3d_adam_step(ops._stream(), self._n, self._flat_p.data_ptr(),
                                             self._flat_g.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(),
                                             bufs[2].data_ptr() if len(bufs) > 2 else None, C.byref(h)),
                   "vp3d_adam_step")
