@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 105
+#define VP3D_VERSION 106
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -158,6 +158,36 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
  * of hi followed by 16 B of lo: an S16 row has the byte geometry of the fp32 row it replaces (ld* stay in 4-byte
  * units).  a*b is evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with fp32 accumulation.
  * ------------------------------------------------------------------------------------------------------------ */
+/* BatchNorm-backward column sums of the UPSTREAM activation inside the dgrad launch that produces its incoming gradient
+ * (training backward; autograd of model.py:134 / :193 drop(relu(bn(conv(x)))) for the layer whose output this dgrad's
+ * result is the gradient of).  The launch's result go (y, fp32, possibly with the residual gradient added) is still
+ * stored; while a tile of it sits in registers the epilogue reads the same tile of y_up and its activation bits and forms
+ *   g = bit ? go / (1 - p) : 0,   sum g,  sum g * (y_up - mean) * invstd      per column over the tile's rows,
+ * writes them as partial rows [m_tile][2][c_out], and the LAST workgroup of every column strip (one ticket per tile-wide
+ * strip of the c_up channels) folds the strip's rows (all taps of a strided dgrad, c_out = taps * c_up) in fp64 into
+ * dbeta / dgamma; the last strip then writes the bound of dy,
+ *   max_c |scale[c]| * (max|go| / (1 - p) + |dbeta[c]| / rows_up + sqrt(rows_up - 1) * |dgamma[c]| / rows_up),
+ * into dy_bound (32 zeroed slots) -- what vp3d_bn_bwd_reduce_fin_s16 produces from (go, y_up) in a pass of its own.
+ * Deterministic (fixed summation order).  Needs: amax_out (the bound of go), splits == 1, tile configuration 20 / 22 (operands
+ * below 2 GiB), fp32 output with y_bpitch % c_up == 0 and ldy % c_up == 0 (go addresses the upstream activation
+ * [rows_up][c_up] densely), c_up % 256 == 0, no bias / relu / statistics; an fp32 residual is fine.
+ *   partials : >= ceil(M / 128) * 2 * c_out floats;  tickets : c_up / 128 + 1 zeroed int32 (zero again on exit). */
+typedef struct vp3d_s16_red {
+  const float* y_up;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const uint8_t* act_bits;
+  int64_t rows_up;
+  int32_t c_up;
+  float p;
+  float* partials;
+  int64_t partials_floats;
+  int32_t* tickets;
+  float* dgamma;
+  float* dbeta;
+  float* dy_bound;
+} vp3d_s16_red;
 /* Extra arguments of the S16 GEMM.
  *   x_bound / w_bound : device "bounds" of max|.| of the two operand tensors.  A bound is VP3D_BOUND_SLOTS (32)
  *                       consecutive floats whose maximum is a guaranteed bound (measuring kernels spread their atomics
@@ -217,6 +247,8 @@ typedef struct vp3d_s16 {
    * order and runs the epilogue -- one launch, no finishing pass, bit-reproducible): ws / ws_floats is their workspace and
    * tickets the zeroed int32 counters (zero again on exit; keep one buffer per stream), sizes from vp3d_nt_s16_workspace. */
   int32_t* tickets;
+  /* fused BatchNorm-backward column sums of the upstream activation (dgrad launches of the training backward), or NULL */
+  const vp3d_s16_red* red;
 } vp3d_s16;
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
 /* The expand layer's forward, dedicated kernel (replaces model.py:74 / :127 / :176

@@ -29,7 +29,7 @@ def test_abi_exports_every_declared_symbol():
     h = _lib.lib()                                   # loads libvp3d.so; raises if any symbol is missing
     for name in declared:
         assert hasattr(h, name)
-    assert h.vp3d_version() == 105
+    assert h.vp3d_version() == 106
     assert h.vp3d_stat_slabs(129) == 3
 
 
@@ -439,7 +439,8 @@ def test_tail_structs_have_the_layout_of_the_header(tmp_path):
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = [("vp3d_tail_fwd_layer", _lib.TailFwdLayer), ("vp3d_tail_fwd", _lib.TailFwd), ("vp3d_tail_bwd_layer", _lib.TailBwdLayer),
-             ("vp3d_tail_bwd", _lib.TailBwd), ("vp3d_dropout", _lib.Dropout), ("vp3d_rowmap", _lib.RowMap)]
+             ("vp3d_tail_bwd", _lib.TailBwd), ("vp3d_dropout", _lib.Dropout), ("vp3d_rowmap", _lib.RowMap),
+             ("vp3d_s16", _lib.S16Opts), ("vp3d_s16_red", _lib.S16Red)]
     lines = ['#include "vp3d.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in pairs:
         lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))

@@ -45,7 +45,14 @@ class S16Opts(C.Structure):
                 ("res_s16", C.c_int32), ("res_bound", C.c_void_p), ("out_s16", C.c_int32), ("in_amax", C.c_void_p),
                 ("l1", C.c_void_p), ("res_amax", C.c_void_p), ("out_wbound", C.c_void_p), ("no_output", C.c_int32),
                 ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("act_drop", C.POINTER(Dropout)),
-                ("act_bound", C.c_void_p), ("act_bits", C.c_void_p), ("tickets", C.c_void_p)]
+                ("act_bound", C.c_void_p), ("act_bits", C.c_void_p), ("tickets", C.c_void_p), ("red", C.c_void_p)]
+
+
+class S16Red(C.Structure):                     # include/vp3d.h: vp3d_s16_red
+    _fields_ = [("y_up", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p),
+                ("act_bits", C.c_void_p), ("rows_up", C.c_int64), ("c_up", C.c_int32), ("p", C.c_float),
+                ("partials", C.c_void_p), ("partials_floats", C.c_int64), ("tickets", C.c_void_p), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p), ("dy_bound", C.c_void_p)]
 
 
 class Gather(C.Structure):
@@ -193,8 +200,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 105:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (105); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 106:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (106); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

@@ -48,6 +48,12 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->no_out = 0;
   e->act_scale = e->act_shift = e->act_bound = nullptr;
   e->act_bits = nullptr;
+  e->red = 0;
+  e->red_bits = nullptr;
+  e->red_m = e->red_row_b = e->red_row_t = 0;
+  e->red_inv_keep = e->red_inv_m = e->red_sqrt_m1 = 0.f;
+  e->red_cnt = nullptr;
+  e->red_dgamma = e->red_dbeta = e->red_dy_bound = nullptr;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -258,8 +264,46 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
     a.epi.act_bits = o->act_bits;
     a.epi.ab_drop = make_drop(o->act_drop);
   }
+  if (o->red != nullptr) {
+    const vp3d_s16_red* r = o->red;
+    VP3D_REQUIRE(!o->raw_partials && !o->out_s16 && !o->no_output && o->act_scale == nullptr && y && o->amax_out &&
+                     a.epi.bias == nullptr && !a.epi.relu && a.epi.stat_sum == nullptr && !a.epi.r_s16,
+                 "tconv_nt_s16: the fused BatchNorm-backward sums ride on a plain fp32 dgrad launch (amax_out set, no bias / "
+                 "relu / statistics / S16 output)");
+    VP3D_REQUIRE(r->y_up && r->mean && r->invstd && r->scale && r->act_bits && r->partials && r->tickets && r->dgamma && r->dbeta &&
+                     r->dy_bound && aligned16(r->y_up) && aligned16(r->mean) && aligned16(r->invstd) && aligned16(r->partials),
+                 "tconv_nt_s16: red has a null or unaligned pointer");
+    VP3D_REQUIRE(r->c_up > 0 && r->c_up % 256 == 0 && c_out % r->c_up == 0 && y_bpitch % r->c_up == 0 && ldy % r->c_up == 0 &&
+                     r->rows_up > 0 && r->rows_up < ((int64_t)1 << 31) && r->p >= 0.f && r->p < 1.f,
+                 "tconv_nt_s16: red needs c_up %% 256 == 0, c_out / y_bpitch / ldy multiples of c_up, rows_up < 2^31 (c_up=%d "
+                 "c_out=%d ldy=%d)", r->c_up, c_out, ldy);
+    VP3D_REQUIRE((int64_t)(map->batch - 1) * (y_bpitch / r->c_up) + (int64_t)(map->t_dst - 1) * (ldy / r->c_up) + c_out / r->c_up <=
+                     r->rows_up, "tconv_nt_s16: red: the output rows do not fit the upstream activation's %lld rows",
+                 (long long)r->rows_up);
+    VP3D_REQUIRE(r->partials_floats >= ((a.M + 127) / 128) * 2 * (int64_t)c_out,
+                 "tconv_nt_s16: red partials need ceil(M/128)*2*c_out floats");
+    VP3D_REQUIRE(r->rows_up * (r->c_up / 8) < ((int64_t)1 << 31), "tconv_nt_s16: red: more than 2 GiB of activation bits");
+    a.epi.red = 1;
+    a.epi.ab_y = r->y_up;
+    a.epi.ab_mean = r->mean;
+    a.epi.ab_invstd = r->invstd;
+    a.epi.ab_scale = r->scale;
+    a.epi.ab_part = r->partials;
+    a.epi.ab_c = r->c_up;
+    a.epi.red_bits = r->act_bits;
+    a.epi.red_m = (int32_t)r->rows_up;
+    a.epi.red_row_b = (int32_t)(y_bpitch / r->c_up);
+    a.epi.red_row_t = ldy / r->c_up;
+    a.epi.red_inv_keep = 1.0f / (1.0f - r->p);
+    a.epi.red_inv_m = 1.0f / (float)r->rows_up;
+    a.epi.red_sqrt_m1 = sqrtf((float)(r->rows_up > 1 ? r->rows_up - 1 : 1));
+    a.epi.red_cnt = r->tickets;
+    a.epi.red_dgamma = r->dgamma;
+    a.epi.red_dbeta = r->dbeta;
+    a.epi.red_dy_bound = r->dy_bound;
+  }
   set_splits(&a, nullptr, 0);
-  const bool single = o->out_s16 || o->res_s16 || o->no_output || o->act_scale != nullptr;
+  const bool single = o->out_s16 || o->res_s16 || o->no_output || o->act_scale != nullptr || o->red != nullptr;
   return launch_nt_s16((hipStream_t)stream, a, o->cfg, single ? 1 : o->splits, o->ws, o->ws_floats,
                        o->raw_partials != 0,    // the finishing pass of a split launch knows neither S16 residuals nor S16 output
                        o->tickets);

@@ -16,6 +16,8 @@
 //
 // All GEMM forms of the model are expressed as NT: forward (B = packed weight rows), dgrad (B = the transposed
 // pack [(tap,ci)][co]), wgrad (both operands pre-transposed by their producers).
+#include <type_traits>
+
 #include "vp3d_internal.h"
 #include "vp3d_s16.h"
 #include "vp3d_s16_mma.h"
@@ -68,7 +70,8 @@ __device__ __forceinline__ int sk_rank_of(int64_t x, int64_t U, int G) {       /
 
 // ACT: the instance that carries the fused BatchNorm + ReLU + dropout epilogue (Epi::act_scale) -- kept out of the
 // general instances so that its Philox temporaries do not enter their register allocation.
-template <class C, bool ACT = false, bool SK = false>
+// RED: the dgrad instance that also forms the BatchNorm-backward column sums of the upstream activation (Epi::red).
+template <class C, bool ACT = false, bool SK = false, bool RED = false>
 __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const RowsGemmArgs p) {
   constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE, PA = C::PA, PB = C::PB;
   constexpr int BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP, CPR = ROWB / 16;   // chunks per row
@@ -546,6 +549,193 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   if (!partial && e.bias != nullptr && vec && n < Nlim) bias = *reinterpret_cast<const f32x4*>(e.bias + n);
   const int rc = n - e.r_col0;
   const bool rcol_ok = !partial && e.R != nullptr && rc >= 0 && rc < e.r_cols;
+  if constexpr (RED) {
+    // ---- go = acc (+ residual gradient) stored as fp32 AND reduced: g = bit ? go / keep : 0, column sums of g and g * xhat
+    // of the upstream activation whose gradient this tile is.  The y_up / bit loads of 32-row block i + 1 are issued before
+    // block i's stores (a wave that mixes loads and stores only gets whole-counter waits: a load issued between the stores
+    // of a block would expose its full latency per pass).
+    constexpr int NPS = 32 / ERPP;
+    constexpr int LW = BN / 4, RG = C::NT / LW;       // strip fold: lanes per partial row (4 columns each), row groups
+    // The y_up rows and bits of a 32-row block are fetched in one batch at the top of the block (before its accumulators are
+    // staged) and nothing is loaded between the block's stores: the first pass waits for the whole batch (one exposed load
+    // latency per block), the other passes wait for nothing.  Prefetching block i + 1 during block i was built first: hipcc
+    // cannot count vmcnt through the row predicates' branches and falls back to "all but the newest operation", so every
+    // pass then waits for the previous pass's store (+35 us per 256x256 tile); the branch-free forms (buffer-descriptor
+    // predication, clamped addresses, one register slot refilled per pass) all spill 100-200 registers beside the 128
+    // accumulators of the 256x256 tiling.
+    const int tap_n = n / e.ab_c, ch = n - tap_n * e.ab_c;      // (N % BN == 0: every column of the tile exists)
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(e.ab_mean + ch);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(e.ab_invstd + ch);
+    const uint8_t* bp = e.red_bits + act_bits_index(ch, tap_n, e.red_m);
+    const float* yp = e.ab_y + n;
+    const int sh = ch & 4;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    // y_up rows: two register slots (block i + 1 is fetched while block i is stored); the bits: two slots where the
+    // accumulators leave room (128x128 tiling), one slot fetched at the top of its own block otherwise
+    constexpr int BSLOT = RB > 2 ? 1 : 2;
+    f32x4 yv[2][NPS];
+    uint32_t bb[BSLOT][NPS];
+    auto fetch_y = [&](const int i) {
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int lr = (wm * RB + i) * 32 + ps * ERPP + rr;       // (the row table is clamped to the launch's last row:
+        const int b = tab_b[lr], t = tab_t[lr];                   //  the address is valid, the row is masked below)
+        yv[i & 1][ps] = *reinterpret_cast<const f32x4*>(yp + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc);
+      }
+    };
+    auto fetch_bits = [&](const int i) {
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int lr = (wm * RB + i) * 32 + ps * ERPP + rr;
+        const int b = tab_b[lr], t = tab_t[lr];
+        bb[i % BSLOT][ps] = bp[((int64_t)b * e.red_row_b + (int64_t)t * e.red_row_t) * 8];
+      }
+    };
+    fetch_y(0);
+    if (BSLOT == 2) fetch_bits(0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if (BSLOT == 1) fetch_bits(i);
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
+        }
+      if (i + 1 < RB) {                                // (after the staging: this block's accumulator registers are free)
+        fetch_y(i + 1);
+        if (BSLOT == 2) fetch_bits(i + 1);
+      }
+      epi_stage_sync();
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int r = ps * ERPP + rr;
+        const int lr = (wm * RB + i) * 32 + r;
+        if (m0 + lr >= p.m_end) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
+        const int b = tab_b[lr], t = tab_t[lr];
+        const int tr = t * e.r_stride + e.r_off;
+        if (rcol_ok && (unsigned)tr < (unsigned)e.r_t)
+          v += *reinterpret_cast<const f32x4*>(e.R + (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0 + n);
+        *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        const uint32_t bits = bb[i % BSLOT][ps] >> sh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float g = ((bits >> c) & 1u) ? v[c] * e.red_inv_keep : 0.f;
+          sg[c] += g;
+          sgx[c] = fmaf(g, (yv[i & 1][ps][c] - mu[c]) * is[c], sgx[c]);
+        }
+      }
+      epi_stage_sync();
+    }
+    // ---- tile column sums: row lanes of the wave (shuffles), the WM waves of a column (LDS), one partial row per tile ----
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sg[c] += __shfl_xor(sg[c], o);
+        sgx[c] += __shfl_xor(sgx[c], o);
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    float* red2 = reinterpret_cast<float*>(smem);     // [WM][2][BN] column sums, then [NW] maxima
+    __syncthreads();                                   // every wave is done with its staging region
+    if (lane < LPR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        red2[(wm * 2 + 0) * BN + wn * WCOLS + c4 + c] = sg[c];
+        red2[(wm * 2 + 1) * BN + wn * WCOLS + c4 + c] = sgx[c];
+      }
+    }
+    if (lane == 0) red2[C::WM * 2 * BN + w] = amax;
+    __syncthreads();
+    static_assert(C::NT == 2 * BN, "one thread per (sum, column) of the tile");
+    {
+      const int q = tid / BN, col = tid - q * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::WM; ++k) t += red2[(k * 2 + q) * BN + col];
+      // (agent-scope store: straight past the L2.  A release fence here would write back the XCD's whole L2, which holds
+      //  this round's go tiles -- measured 25-35 us per tile)
+      if (n0 + col < Nlim)
+        __hip_atomic_store(e.ab_part + ((int64_t)tile_m * 2 + q) * p.N + n0 + col, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+      float m = red2[C::WM * 2 * BN];
+      for (int i = 1; i < C::NW; ++i) m = fmaxf(m, red2[C::WM * 2 * BN + i]);
+      s16_atomic_bound(e.amax_out, m);
+    }
+    // ---- the strip's last tile folds the strip's partial rows (all row tiles x taps) in fp64: dbeta / dgamma -------------
+    __shared__ int red_flag;
+    const int strips = e.ab_c / BN, taps_n = p.n_tiles / strips;
+    const int strip = tile_n % strips;
+    auto ticket_last = [&](int* counter, const int expected) {      // what this workgroup published went out as agent-scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stores: acknowledged = visible, no fence needed
+      __syncthreads();
+      if (tid == 0) {
+        const int tk = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == expected - 1 ? 1 : 0;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        red_flag = last;
+      }
+      __syncthreads();
+      return red_flag != 0;
+    };
+    if (!ticket_last(e.red_cnt + strip, p.m_tiles * taps_n)) return;
+    {
+      const int col4 = (tid % LW) * 4, rg = tid / LW;
+      const int R = p.m_tiles * taps_n;
+      double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int r = rg; r < R; r += RG) {
+        const int tm = r / taps_n, tp = r - tm * taps_n;
+        const float* pr = e.ab_part + ((int64_t)tm * 2) * p.N + tp * e.ab_c + strip * BN + col4;
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(pr);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(pr + p.N);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a0[c] += (double)u0[c];
+          a1[c] += (double)u1[c];
+        }
+      }
+      double* red3 = reinterpret_cast<double*>(smem);  // [RG][2][BN]
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        red3[(rg * 2 + 0) * BN + col4 + c] = a0[c];
+        red3[(rg * 2 + 1) * BN + col4 + c] = a1[c];
+      }
+      __syncthreads();
+      const int q = tid / BN, col = tid - q * BN;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < RG; ++k) t += red3[(k * 2 + q) * BN + col];
+      __hip_atomic_store((q == 0 ? e.red_dbeta : e.red_dgamma) + strip * BN + col, (float)t, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last strip: bound of dy from every channel's dbeta / dgamma and the launch's max|go| ---------------------------
+    if (!ticket_last(e.red_cnt + strips, strips)) return;
+    {
+      const float gmax = s16_load_bound_agent(e.amax_out) * e.red_inv_keep;
+      float bmax = 0.f;
+      for (int c = tid; c < e.ab_c; c += C::NT)
+        bmax = fmaxf(bmax, fabsf(e.ab_scale[c]) * (gmax + fabsf(e.red_dbeta[c]) * e.red_inv_m +
+                                                   e.red_sqrt_m1 * fabsf(e.red_dgamma[c]) * e.red_inv_m));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+      float* redm = reinterpret_cast<float*>(smem) + RG * 4 * BN;      // (behind red3, which late readers may still hold)
+      if (lane == 0) redm[w] = bmax;
+      __syncthreads();
+      if (tid == 0) {
+        float m = redm[0];
+        for (int i = 1; i < C::NW; ++i) m = fmaxf(m, redm[i]);
+        s16_atomic_bound(e.red_dy_bound, m);
+        for (int i = 0; i <= strips; ++i) e.red_cnt[i] = 0;            // every workgroup of the launch has drawn its tickets
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
 #pragma unroll
@@ -1055,6 +1245,18 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
       return check_launch("nt_s16(act)");
     } else {
       set_error("nt_s16: the fused activation epilogue exists for tile configurations 20 / 22 / 30 only");
+      return VP3D_E_INVALID;
+    }
+  }
+  if (a.epi.red) {
+    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && C::NT == 2 * C::BN) {
+      VP3D_REQUIRE(splits == 1 && a.epi.vec && a.N % C::BN == 0 && a.epi.ab_c % C::BN == 0 && a.m_begin == 0 && a.m_end == a.M,
+                   "nt_s16: the fused BatchNorm-backward sums need one K slice, 16-byte aligned fp32 output and c_out, c_up "
+                   "multiples of the %d-column tile", C::BN);
+      hipLaunchKernelGGL((k_nt_s16<C, false, false, true>), dim3(positions), dim3(C::NT), 0, s, a);
+      return check_launch("nt_s16(red)");
+    } else {
+      set_error("nt_s16: the fused BatchNorm-backward sums exist for tile configurations 20 / 22 only (operands below 2 GiB)");
       return VP3D_E_INVALID;
     }
   }

@@ -72,6 +72,16 @@ struct Epi {
   const float* act_shift;
   const float* act_bound;
   uint8_t* act_bits;
+  // fused BatchNorm-backward column sums of the upstream activation (vp3d_s16_red; red != 0): uses ab_y / ab_mean / ab_invstd /
+  // ab_scale / ab_part / ab_c from above; upstream row of output element (b, t, n) = b * red_row_b + t * red_row_t + n / ab_c
+  int32_t red;
+  const uint8_t* red_bits;
+  int32_t red_m, red_row_b, red_row_t;
+  float red_inv_keep, red_inv_m, red_sqrt_m1;
+  int32_t* red_cnt;
+  float* red_dgamma;
+  float* red_dbeta;
+  float* red_dy_bound;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";

@@ -89,4 +89,31 @@ __device__ __forceinline__ int64_t act_bits_index(int c, int64_t m, int M) {
   return ((int64_t)(c >> 6) * M + m) * 8 + ((c & 63) >> 3);
 }
 
+// Ticket of a block that has finished writing its contribution: true for the block that arrives last.  Publish / consume
+// follow the agent-scope release -> relaxed atomic -> acquire hand-off (all stores of the block drained and released
+// before the ticket; the last arriver acquires before any thread of it reads the other blocks' rows).
+__device__ __forceinline__ bool last_arriver(int* counter, int expected, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+// s16_load_bound of a bound whose slots other workgroups of the SAME launch have just atomicMax-ed (read behind a
+// last_arriver hand-over): agent-scope loads, so that no stale line of this XCD's L2 is consulted
+__device__ __forceinline__ float s16_load_bound_agent(const float* b) {
+  float m = __hip_atomic_load(b + (threadIdx.x & (kBoundSlots - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+
 }  // namespace vp3d

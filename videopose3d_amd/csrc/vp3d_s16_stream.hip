@@ -70,24 +70,6 @@ struct BwdFin {
   float inv_keep, inv_m, sqrt_m1;
 };
 
-// Ticket of a block that has finished writing its contribution: true for the block that arrives last.  Publish / consume
-// follow the agent-scope release -> relaxed atomic -> acquire hand-off (all stores of the block drained and released
-// before the ticket; the last arriver acquires before any thread of it reads the other blocks' rows).
-__device__ __forceinline__ bool last_arriver(int* counter, int expected, int* lds_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == expected - 1) ? 1 : 0;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *lds_flag = last;
-  }
-  __syncthreads();
-  return *lds_flag != 0;
-}
-
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce_bits(int M, int C, const float* __restrict__ go,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,

@@ -179,6 +179,12 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
     return kv
 
 
+# BatchNorm-backward column sums inside the dgrad launch that writes the activation's incoming gradient (vp3d_s16_red):
+# VP3D_FUSE_BN_RED=0 never, =1 wherever the launch supports it, default: where it pays -- activations of at least
+# FUSE_BN_RED_MIN_ROWS rows (below that the fused launch's finalize chain, ~14 us of dependent memory round trips at its tail,
+# costs what the 17-30 us reduction pass it replaces does: tools/red_bench.py)
+FUSE_BN_RED_DEFAULT = "auto"
+FUSE_BN_RED_MIN_ROWS = 8192
 TAIL_MAX_ROWS = int(os.environ.get("VP3D_TAIL_MAX_ROWS", "3072"))     # B * T_out up to which a block runs in the persistent tail
 
 
@@ -517,6 +523,29 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     S.amax(dh, out=bounds[last])
     group_done()                                     # shrink
 
+    # BatchNorm-backward column sums inside the dgrad launch that writes the activation's incoming gradient (vp3d_s16_red;
+    # VP3D_FUSE_BN_RED=0 keeps the separate reduction pass everywhere): presummed[idx] = (dgamma, dbeta) once done
+    fuse_mode = os.environ.get("VP3D_FUSE_BN_RED", FUSE_BN_RED_DEFAULT)
+    fuse_red = fuse_mode != "0" and mod.__dict__.get("_vp3d_sync_bn") is None
+    presummed = {}
+
+    def red_for(up, m, n, k, dy):
+        """vp3d_s16_red of layer `up` for the dgrad launch [m, n, k] that writes its incoming gradient, or None."""
+        s = L[up]
+        if (not fuse_red or up <= 0 or s.bits is None or
+                (fuse_mode != "1" and s.y.shape[0] * s.y.shape[1] < FUSE_BN_RED_MIN_ROWS) or
+                not S.red_supported(m, n, k, s.y.shape[2]) or
+                s.y.numel() * 4 >= 2 ** 31 or dy.data.numel() * 4 >= 2 ** 31 or n * k * 4 >= 2 ** 31):
+            return None
+        o_g, o_bt = view(bns[up].weight), view(bns[up].bias)
+        if o_g is None or o_bt is None:
+            dgb = torch.empty((2, s.y.shape[2]), dtype=torch.float32, device=dev)
+            o_g, o_bt = dgb[0], dgb[1]
+        r, hold = S.make_red(s.y, s.coef, s.bits, p if s.drop is not None else 0.0, m, n, o_g, o_bt, bounds[n_layers + up])
+        presummed[up] = (o_g, o_bt)
+        keep.append(hold)                            # (the partial rows: alive until the launch is enqueued)
+        return r
+
     def act_bwd(idx, go):
         s = L[idx]
         o_g, o_bt = view(bns[idx].weight), view(bns[idx].bias)
@@ -525,7 +554,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         dy, dy_t, dgam, dbet = S.bn_act_bwd(go, bounds[idx], s.y, s.coef, s.drop, p, bounds[n_layers + idx],
                                             out_dgamma=o_g, out_dbeta=o_bt, want_rows=idx > 0,   # expand: no dgrad
                                             sync=mod.__dict__.get("_vp3d_sync_bn"), act_bits=s.bits,
-                                            want_t=s.wform != "rows")
+                                            want_t=s.wform != "rows", presummed=presummed.get(idx))
         if s.wform == "rows":
             dy_t = dy                                # rows-form wgrad reads the rows
         grads[3 * idx + 1] = sunk(dgam, o_g)
@@ -561,10 +590,11 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             dw = gemm()
         grads[3 * idx] = sunk(dw, out)
 
-    def dgrad(idx, dy, residual, amax_out):
+    def dgrad(idx, dy, residual, amax_out, up=-1):
         """dx of conv idx.  Strided conv (stride == taps; also every 1x1 conv): windows do not overlap, dx viewed as
         [B*T_out, taps*C_in] = dy @ Wd is a plain GEMM (rows of a ragged tail stay zero).  Stride-1 conv of several taps
-        (the dilated class): gather form dx[b,s] = sum_k dy[b, s - k*dil] @ W_k^T over the [ci][k*C_out + co] pack."""
+        (the dilated class): gather form dx[b,s] = sum_k dy[b, s - k*dil] @ W_k^T over the [ci][k*C_out + co] pack.
+        up: the layer whose activation dx is the gradient of (its BatchNorm-backward sums may ride in the launch: red_for)."""
         spec: ConvSpec = plan.convs[idx]
         bb, t_o, c_out = dy.data.shape
         taps, c_in = spec.taps, spec.c_in
@@ -578,7 +608,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
                 assert rs.step == 1 and r.shape[0] == bb and r.shape[2] == c_in
                 e = ops._epi(residual=(r, 1, -rs.start, 0), n_cols=c_in)
             S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, c_in, dx, t_i * c_in, c_in, epi=e, amax_out=amax_out,
-                        family="tconv_dgrad")
+                        family="tconv_dgrad", red=red_for(up, bb * t_i, c_in, taps * c_out, dy))
             return dx
         assert spec.stride == taps and (spec.dil == 1 or taps == 1) and taps * t_o <= t_i      # (a 1-tap conv has no dilation to speak of)
         dx = (torch.empty if taps * t_o == t_i else torch.zeros)((bb, t_i, c_in), dtype=torch.float32, device=dev)
@@ -589,7 +619,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             assert rs.step == taps and r.shape == (bb, t_o, c_in)
             e = ops._epi(residual=(r, 1, 0, rs.start * c_in), n_cols=taps * c_in)
         S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, taps * c_in, dx, t_i * c_in, taps * c_in, epi=e, amax_out=amax_out,
-                    family="tconv_dgrad")
+                    family="tconv_dgrad", red=red_for(up, bb * t_o, taps * c_in, c_out, dy))
         return dx
 
     # the trailing small-M blocks: one persistent launch (S.tail_bwd) instead of ~10 launches per block on two streams
@@ -622,12 +652,12 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     for i in reversed(range(n_head)):
         i1, i2 = 1 + 2 * i, 2 + 2 * i
         dy2, dy2_t = act_bwd(i2, dh)
-        da1 = dgrad(i2, dy2, None, bounds[i1])
+        da1 = dgrad(i2, dy2, None, bounds[i1], up=i1)
         wgrad(i2, dy2_t)
         del dy2, dy2_t
         dy1, dy1_t = act_bwd(i1, da1)
         del da1
-        dh = dgrad(i1, dy1, (dh, plan.res[i]), bounds[2 * i])
+        dh = dgrad(i1, dy1, (dh, plan.res[i]), bounds[2 * i], up=2 * i)
         wgrad(i1, dy1_t)
         group_done()
         del dy1, dy1_t

@@ -197,12 +197,45 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
     return S16(out, out_bound)
 
 
+def red_supported(m: int, n: int, k: int, c_up: int) -> bool:
+    """Can a dgrad launch [m, n, k] carry the BatchNorm-backward column sums of its upstream activation (vp3d_s16_red)?
+    One K slice on the 128x128 / 256x256 buffer-descriptor tilings, whole column tiles."""
+    cfg, splits = plan(m, n, k)
+    bn = 256 if cfg == 22 else 128
+    return cfg in (20, 22) and splits == 1 and c_up % 256 == 0 and n % c_up == 0 and n % bn == 0
+
+
+RED_CALLS = {"n": 0}            # dgrad launches that carried the fused BatchNorm-backward sums (tests, tools)
+
+
+def make_red(y_up: torch.Tensor, coef: torch.Tensor, act_bits: torch.Tensor, p: float, m: int, n: int, dgamma: torch.Tensor,
+             dbeta: torch.Tensor, dy_bound: torch.Tensor):
+    """vp3d_s16_red for a dgrad launch [m rows, n columns] whose result is the gradient of dropout(relu(bn(y_up))): coef =
+    the upstream layer's (scale, shift, mean, invstd) rows; dgamma / dbeta / dy_bound (zeroed 32 slots) receive what
+    bn_act_bwd's reduction pass would.  Returns (struct, buffers to keep alive until the launch is enqueued)."""
+    bu, tu, cu = y_up.shape
+    ops._chk(y_up, "y_up")
+    assert act_bits.numel() * 8 == bu * tu * cu and act_bits.dtype == torch.uint8
+    parts = torch.empty(((m + 127) // 128) * 2 * n, dtype=torch.float32, device=y_up.device)
+    r = _lib.S16Red()
+    r.y_up, r.mean, r.invstd, r.scale = y_up.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[0].data_ptr()
+    r.act_bits, r.rows_up, r.c_up, r.p = act_bits.data_ptr(), bu * tu, cu, float(p)
+    r.partials, r.partials_floats = parts.data_ptr(), parts.numel()
+    r.tickets = _tickets(y_up.device, cu // 128 + 1).data_ptr()
+    r.dgamma, r.dbeta, r.dy_bound = dgamma.data_ptr(), dbeta.data_ptr(), dy_bound.data_ptr()
+    RED_CALLS["n"] += 1
+    return r, (parts,)
+
+
 def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: torch.Tensor, y_bpitch: int, ldy: int,
-              *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0):
-    """Raw form of conv_nt: out[b*y_bpitch + t*ldy + n] = sum_k x[gather] * wt[n][k] (+ epilogue)."""
+              *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0, red=None):
+    """Raw form of conv_nt: out[b*y_bpitch + t*ldy + n] = sum_k x[gather] * wt[n][k] (+ epilogue).  red: a make_red()
+    struct -- the launch also reduces the BatchNorm backward of the activation whose gradient it writes."""
     xd, wd = x.data, wt.data
     m, k = rm.batch * rm.t_dst, rm.taps * c_in
     o, ws = _opts(x, wt, m, n, k, xd.device, amax_out, cfg, splits)
+    if red is not None:
+        o.red = C.addressof(red)
     ops._timed_call(family, 2.0 * m * n * k, _lib.lib().vp3d_tconv_nt_s16,
                     ops._stream(), C.byref(rm), xd.data_ptr(), xd.shape[-1], c_src, wd.data_ptr(), wd.shape[-1], n,
                     out.data_ptr(), y_bpitch, ldy, C.byref(epi) if epi is not None else None,
@@ -498,10 +531,12 @@ def new_act_bits(m_rows: int, c: int, device) -> torch.Tensor:
 
 def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, drop, p: float,
                dy_bound: torch.Tensor, out_dgamma=None, out_dbeta=None, want_rows: bool = True, sync=None,
-               act_bits: Optional[torch.Tensor] = None, want_t: bool = True):
+               act_bits: Optional[torch.Tensor] = None, want_t: bool = True, presummed=None):
     """Backward of a = dropout(relu(bn(y))): returns (dy S16 rows [None unless want_rows: only dgrad reads them],
     dy S16 transposed, dgamma, dbeta); dy_bound (zeroed) receives the guaranteed bound of dy.  With the forward's
-    act_bits the two passes read the mask / ReLU predicate (1 bit per element) instead of regenerating them."""
+    act_bits the two passes read the mask / ReLU predicate (1 bit per element) instead of regenerating them.
+    presummed = (dgamma, dbeta): the dgrad launch that wrote go already reduced them and filled dy_bound (vp3d_s16_red):
+    only the apply pass runs."""
     ops._chk(go, "go")
     ops._chk(y, "y")
     b, t, c = y.shape
@@ -511,13 +546,18 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
     dref = C.byref(drop) if drop is not None else None
     nparts = C.c_int32(0)
     sc, sh, mu, inv = (coef[i].data_ptr() for i in range(4))
-    if out_dgamma is not None and out_dbeta is not None:
+    if presummed is not None:
+        assert sync is None and act_bits is not None
+        dgam, dbet = presummed
+    elif out_dgamma is not None and out_dbeta is not None:
         dgam, dbet = out_dgamma, out_dbeta
     else:
         dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
         dgam, dbet = dgb[0], dgb[1]
     fused_fin = act_bits is not None and sync is None
-    if fused_fin:
+    if presummed is not None:
+        pass
+    elif fused_fin:
         # reduction + finalize + bound of dy in ONE launch (last-arriver blocks fold the partial rows): no [C]-sized kernel
         # that waits for a CU slot behind the second stream's weight-gradient GEMM
         assert act_bits.numel() * 8 == m * c and act_bits.dtype == torch.uint8
@@ -547,7 +587,7 @@ def bn_act_bwd(go: torch.Tensor, go_bound: torch.Tensor, y: torch.Tensor, coef: 
         parts = torch.empty((nparts.value, 2, c), dtype=torch.float32, device=y.device)
         check(L.vp3d_bn_bwd_reduce(ops._stream(), m, c, go.data_ptr(), y.data_ptr(), sc, sh, mu, inv, dref, parts.data_ptr(),
                                    C.byref(nparts)), "vp3d_bn_bwd_reduce")
-    if not fused_fin:
+    if not fused_fin and presummed is None:
         check(L.vp3d_bn_bwd_finalize_s16(ops._stream(), c, m, parts.data_ptr(), nparts.value, dgam.data_ptr(), dbet.data_ptr(), sc,
                                          go_bound.data_ptr(), float(p), dy_bound.data_ptr()), "vp3d_bn_bwd_finalize_s16")
     a_g, a_b = dgam, dbet
