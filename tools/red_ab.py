@@ -68,10 +68,15 @@ def timed(n=30):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-res = {"0": [], "1": []}
-for rep in range(4):
-    for v in ("0", "1"):
-        os.environ["VP3D_FUSE_BN_RED"] = v
+from videopose3d_amd import engine_s16  # noqa: E402
+MODES = ("0", "auto", "auto@16384", "auto@4096", "1")      # (auto@rows: the automatic rule with another row threshold)
+res = {v: [] for v in MODES}
+rows_default = engine_s16.FUSE_BN_RED_MIN_ROWS
+for rep in range(6):
+    for v in MODES:
+        os.environ["VP3D_FUSE_BN_RED"] = v.split("@")[0]
+        engine_s16.FUSE_BN_RED_MIN_ROWS = int(v.split("@")[1]) if "@" in v else rows_default
         res[v].append(timed())
-print("whole step  VP3D_FUSE_BN_RED=0: %s   =1: %s   (min %.3f vs %.3f ms)" % (
-    " ".join("%.3f" % t for t in res["0"]), " ".join("%.3f" % t for t in res["1"]), min(res["0"]), min(res["1"])), flush=True)
+for v in MODES:
+    print("whole step  VP3D_FUSE_BN_RED=%-10s: %s   (min %.3f, median %.3f ms)" % (
+        v, " ".join("%.3f" % t for t in res[v]), min(res[v]), sorted(res[v])[len(res[v]) // 2]), flush=True)

@@ -240,7 +240,8 @@ def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: t
                     ops._stream(), C.byref(rm), xd.data_ptr(), xd.shape[-1], c_src, wd.data_ptr(), wd.shape[-1], n,
                     out.data_ptr(), y_bpitch, ldy, C.byref(epi) if epi is not None else None,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
-                    nbytes=4.0 * (xd.numel() + wd.numel() + m * n), shape=(m, n, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
+                    nbytes=4.0 * (xd.numel() + wd.numel() + m * n) + (4.125 * m * n if red is not None else 0.0),
+                    shape=(m, n, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
     return out
 
 
