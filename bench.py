@@ -377,6 +377,9 @@ def instrumented(step, ops, n_prof, math):
         # GEMM form -- one template serves forward and dgrad launches alike
         names = {22: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>> (256x256 tile, 8 waves of 128x64; forward + dgrad launches)",
                  20: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>> (128x128 tile, 4 waves, 2 workgroups per CU)",
+                 1022: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>, RED> (256x256 tile dgrad + the BatchNorm-backward column sums of the "
+                       "upstream activation: reads that activation's conv output and bits in the epilogue, vp3d_s16_red)",
+                 1020: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>, RED> (128x128 tile dgrad + BatchNorm-backward column sums)",
                  "tn": "k_tn_s16<2> (rows-form weight gradient, 256x256 tile, transpose reads)",
                  "ex": "k_expand_fwd_s16 (expand layer forward: statistics + activation pass)",
                  "exb": "k_expand_bwd_p_s16 (expand layer backward: P = G^T X from go + bits)"}

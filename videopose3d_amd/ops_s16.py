@@ -205,6 +205,7 @@ def red_supported(m: int, n: int, k: int, c_up: int) -> bool:
     return cfg in (20, 22) and splits == 1 and c_up % 256 == 0 and n % c_up == 0 and n % bn == 0
 
 
+RED_CFG_KEY = 1000              # profiler rows: tile configuration + 1000 = the instance that carries the fused sums
 RED_CALLS = {"n": 0}            # dgrad launches that carried the fused BatchNorm-backward sums (tests, tools)
 
 
@@ -241,7 +242,7 @@ def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: t
                     out.data_ptr(), y_bpitch, ldy, C.byref(epi) if epi is not None else None,
                     ops.zeros_page(xd.device).data_ptr(), C.byref(o),
                     nbytes=4.0 * (xd.numel() + wd.numel() + m * n) + (4.125 * m * n if red is not None else 0.0),
-                    shape=(m, n, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
+                    shape=(m, n, k, o.cfg + (RED_CFG_KEY if red is not None else 0), o.splits, 2 if o.cfg == 30 else 1))
     return out
 
 
