@@ -165,13 +165,15 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
  *   g = bit ? go / (1 - p) : 0,   sum g,  sum g * (y_up - mean) * invstd      per column over the tile's rows,
  * writes them as partial rows [m_tile][2][c_out], and the LAST workgroup of every column strip (one ticket per tile-wide
  * strip of the c_up channels) folds the strip's rows (all taps of a strided dgrad, c_out = taps * c_up) in fp64 into
- * dbeta / dgamma; the last strip then writes the bound of dy,
- *   max_c |scale[c]| * (max|go| / (1 - p) + |dbeta[c]| / rows_up + sqrt(rows_up - 1) * |dgamma[c]| / rows_up),
- * into dy_bound (32 zeroed slots) -- what vp3d_bn_bwd_reduce_fin_s16 produces from (go, y_up) in a pass of its own.
+ * dbeta / dgamma and max-es the strip's share of the bound of dy,
+ *   max_{c in strip} |scale[c]| * (max|go over the strip's columns| / (1 - p) + |dbeta[c]| / rows_up
+ *                                  + sqrt(rows_up - 1) * |dgamma[c]| / rows_up),
+ * into dy_bound (32 zeroed slots): dbeta / dgamma are those of vp3d_bn_bwd_reduce_fin_s16's pass over (go, y_up), the bound
+ * is a (tighter or equal) guaranteed bound of the same dy -- g of a channel is bounded by max|go| over that channel's column.
  * Deterministic (fixed summation order).  Needs: amax_out (the bound of go), splits == 1, tile configuration 20 / 22 (operands
  * below 2 GiB), fp32 output with y_bpitch % c_up == 0 and ldy % c_up == 0 (go addresses the upstream activation
  * [rows_up][c_up] densely), c_up % 256 == 0, no bias / relu / statistics; an fp32 residual is fine.
- *   partials : >= ceil(M / 128) * 2 * c_out floats;  tickets : c_up / 128 + 1 zeroed int32 (zero again on exit). */
+ *   partials : >= ceil(M / 128) * 2 * c_out floats;  tickets : 2 * (c_up / 128) zeroed int32 (zero again on exit). */
 typedef struct vp3d_s16_red {
   const float* y_up;
   const float* mean;

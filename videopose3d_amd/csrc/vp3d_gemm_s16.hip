@@ -662,28 +662,29 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       if (n0 + col < Nlim)
         __hip_atomic_store(e.ab_part + ((int64_t)tile_m * 2 + q) * p.N + n0 + col, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    const int strips = e.ab_c / BN, taps_n = p.n_tiles / strips;
+    const int strip = tile_n % strips;
     if (tid == 0) {
       float m = red2[C::WM * 2 * BN];
       for (int i = 1; i < C::NW; ++i) m = fmaxf(m, red2[C::WM * 2 * BN + i]);
       s16_atomic_bound(e.amax_out, m);
+      // max|go| over the STRIP's columns (what bounds g for its channels): non-negative floats order as integers
+      __hip_atomic_fetch_max(e.red_cnt + strips + strip, __float_as_int(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- the strip's last tile folds the strip's partial rows (all row tiles x taps) in fp64: dbeta / dgamma -------------
+    // ---- the strip's last tile folds the strip's partial rows (all row tiles x taps) in fp64: dbeta / dgamma, and the strip's
+    // share of the bound of dy.  One hand-over: what this workgroup published went out as agent-scope stores / atomics,
+    // acknowledged = visible, so the ticket needs no release fence; the last arriver acquires.
     __shared__ int red_flag;
-    const int strips = e.ab_c / BN, taps_n = p.n_tiles / strips;
-    const int strip = tile_n % strips;
-    auto ticket_last = [&](int* counter, const int expected) {      // what this workgroup published went out as agent-scope
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stores: acknowledged = visible, no fence needed
-      __syncthreads();
-      if (tid == 0) {
-        const int tk = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = tk == expected - 1 ? 1 : 0;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        red_flag = last;
-      }
-      __syncthreads();
-      return red_flag != 0;
-    };
-    if (!ticket_last(e.red_cnt + strip, p.m_tiles * taps_n)) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int tk = __hip_atomic_fetch_add(e.red_cnt + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = tk == p.m_tiles * taps_n - 1 ? 1 : 0;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      red_flag = last;
+    }
+    __syncthreads();
+    if (!red_flag) return;
     {
       const int col4 = (tid % LW) * 4, rg = tid / LW;
       const int R = p.m_tiles * taps_n;
@@ -711,27 +712,25 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < RG; ++k) t += red3[(k * 2 + q) * BN + col];
-      __hip_atomic_store((q == 0 ? e.red_dbeta : e.red_dgamma) + strip * BN + col, (float)t, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- the last strip: bound of dy from every channel's dbeta / dgamma and the launch's max|go| ---------------------------
-    if (!ticket_last(e.red_cnt + strips, strips)) return;
-    {
-      const float gmax = s16_load_bound_agent(e.amax_out) * e.red_inv_keep;
+      (q == 0 ? e.red_dbeta : e.red_dgamma)[strip * BN + col] = (float)t;
+      float* fin = reinterpret_cast<float*>(smem) + RG * 4 * BN;      // [2][BN] behind red3, then [NW] maxima
+      fin[q * BN + col] = fabsf((float)t);
+      __syncthreads();
+      const float gmax = __int_as_float(__hip_atomic_load(e.red_cnt + strips + strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) *
+                         e.red_inv_keep;
       float bmax = 0.f;
-      for (int c = tid; c < e.ab_c; c += C::NT)
-        bmax = fmaxf(bmax, fabsf(e.ab_scale[c]) * (gmax + fabsf(e.red_dbeta[c]) * e.red_inv_m +
-                                                   e.red_sqrt_m1 * fabsf(e.red_dgamma[c]) * e.red_inv_m));
+      if (tid < BN)
+        bmax = fabsf(e.ab_scale[strip * BN + tid]) * (gmax + fin[tid] * e.red_inv_m + e.red_sqrt_m1 * fin[BN + tid] * e.red_inv_m);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
-      float* redm = reinterpret_cast<float*>(smem) + RG * 4 * BN;      // (behind red3, which late readers may still hold)
-      if (lane == 0) redm[w] = bmax;
+      if (lane == 0) fin[2 * BN + w] = bmax;
       __syncthreads();
       if (tid == 0) {
-        float m = redm[0];
-        for (int i = 1; i < C::NW; ++i) m = fmaxf(m, redm[i]);
+        float m = fin[2 * BN];
+        for (int i = 1; i < C::NW; ++i) m = fmaxf(m, fin[2 * BN + i]);
         s16_atomic_bound(e.red_dy_bound, m);
-        for (int i = 0; i <= strips; ++i) e.red_cnt[i] = 0;            // every workgroup of the launch has drawn its tickets
+        e.red_cnt[strip] = 0;                          // every tile of the strip has drawn its ticket: zero for the next launch
+        e.red_cnt[strips + strip] = 0;
       }
     }
     return;

@@ -222,7 +222,7 @@ def make_red(y_up: torch.Tensor, coef: torch.Tensor, act_bits: torch.Tensor, p: 
     r.y_up, r.mean, r.invstd, r.scale = y_up.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[0].data_ptr()
     r.act_bits, r.rows_up, r.c_up, r.p = act_bits.data_ptr(), bu * tu, cu, float(p)
     r.partials, r.partials_floats = parts.data_ptr(), parts.numel()
-    r.tickets = _tickets(y_up.device, cu // 128 + 1).data_ptr()
+    r.tickets = _tickets(y_up.device, 2 * (cu // 128)).data_ptr()
     r.dgamma, r.dbeta, r.dy_bound = dgamma.data_ptr(), dbeta.data_ptr(), dy_bound.data_ptr()
     RED_CALLS["n"] += 1
     return r, (parts,)
