@@ -459,6 +459,18 @@ def test_tail_structs_have_the_layout_of_the_header(tmp_path):
         assert got == want, (cname, got, want)
 
 
+def test_fused_bn_backward_sums_selection_rules():
+    """ops_s16.red_supported (which dgrad launches may carry the BatchNorm-backward column sums, vp3d_s16_red): one K slice on
+    the 128x128 / 256x256 tilings, whole column tiles, 256-channel strips; engine_s16 adds the row threshold."""
+    from videopose3d_amd import engine_s16, ops_s16 as S
+    assert S.red_supported(27648, 1024, 1024, 1024)            # block 1's 1x1 dgrad: writes the gradient of a 27,648-row activation
+    assert S.red_supported(9216, 3072, 1024, 1024)             # block 2's strided dgrad: three taps fold into one strip
+    assert not S.red_supported(1024, 1024, 1024, 1024)         # the planner slices K: the finishing pass owns the epilogue
+    assert not S.red_supported(27648, 1024, 1024, 128)         # strips are 256 channels wide
+    assert not S.red_supported(27648, 1000, 1024, 1000)
+    assert engine_s16.FUSE_BN_RED_DEFAULT == "auto" and engine_s16.FUSE_BN_RED_MIN_ROWS == 8192
+
+
 def test_persistent_tail_selection_rules(monkeypatch):
     """engine_s16.tail_from (which trailing blocks run in the persistent tail kernels when VP3D_TAIL=1): whole blocks of the
     strided class whose windows tile, B * T_out <= 3072 rows, C % 64 == 0, one BatchNorm momentum, no synchronised BatchNorm;

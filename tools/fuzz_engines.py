@@ -24,10 +24,11 @@ for case in range(n_cases):
     fw = rnd.choice([[3], [3, 3], [3, 3, 3], [3, 5], [5, 3], [3, 3, 3, 3], [1, 3], [3, 1, 3]])
     causal = rnd.random() < 0.3
     dense = (not strided) and rnd.random() < 0.2
-    c = rnd.choice([64, 128, 192, 256])
+    big = os.environ.get("VP3D_FUZZ_BIG", "0") == "1"      # larger shapes: reach the launches that carry the fused sums
+    c = rnd.choice([256, 512] if big else [64, 128, 192, 256])
     j_in, j_out = rnd.choice([17, 15, 10, 5, 16]), rnd.choice([17, 1, 15])
     p = rnd.choice([0.0, 0.25, 0.5])
-    b = rnd.choice([2, 3, 16, 33, 128])
+    b = rnd.choice([130, 300, 512, 1000] if big else [2, 3, 16, 33, 128])
     rf = 1
     for f in fw:
         rf *= f
@@ -87,6 +88,7 @@ for case in range(n_cases):
         bad += 1
         print("EXC  %-86s %s" % (tag, repr(e)[:300]), flush=True)
 from videopose3d_amd import ops_s16 as _S  # noqa: E402
-print("tail launches: %d forward, %d backward" % (_S.TAIL_CALLS["fwd"], _S.TAIL_CALLS["bwd"]))
+print("tail launches: %d forward, %d backward; dgrad launches with the fused BatchNorm-backward sums: %d" % (
+    _S.TAIL_CALLS["fwd"], _S.TAIL_CALLS["bwd"], _S.RED_CALLS["n"]))
 print("%d / %d cases failed" % (bad, n_cases))
 sys.exit(1 if bad else 0)
