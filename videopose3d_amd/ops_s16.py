@@ -390,11 +390,18 @@ def wgrad_rows_supported(c_out: int, c_in: int) -> bool:
     return c_out % 256 == 0 and (c_in % 256 == 0 or c_in == 128)
 
 
+# Slice counts the rows-form weight gradient may be cut into.  5 / 10 / 15 / 20 matter for the 48 tiles of a 1024 x 3072 weight
+# gradient: 48 x 5 = 240 workgroups are one (94 % full) round of the 256 CUs, where 4 slices leave a quarter of the chip idle and
+# 16 slices (three exact rounds) write 201 MB of partial matrices instead of 63 (tools/wgrad_splits.py: M 27,648: 479 -> 444 us,
+# M 9,216: 174 -> 162 us, GEMM + reduce)
+WGRAD_SPLIT_CANDIDATES = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24, 32)
+
+
 def _wgrad_rows_splits(m_rows: int, c_out: int, n_cols: int) -> int:
     """K-slices of the 256x256 rows-form wgrad GEMM: the S16 planner's 256x256 cost terms (plan_nt_s16)."""
     tiles, nkt = (c_out // 256) * max(1, n_cols // 256), (m_rows + 31) // 32
     best, best_s = None, 1
-    for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+    for s in WGRAD_SPLIT_CANDIDATES:
         if s > 1 and nkt // s < 6:
             break
         wgs = tiles * s
