@@ -194,16 +194,17 @@ def test_s16_planner_returns_launchable_plans_and_keeps_the_tuned_picks():
 
 
 def test_rows_form_wgrad_split_choice_is_launchable():
-    """ops_s16._wgrad_rows_splits (host side of vp3d_wgrad_rows_s16): a measured slice count, at least 6 K-tiles of 32 rows
-    per slice when sliced, and the step's two big shapes fill whole rounds of 256 workgroups."""
+    """ops_s16._wgrad_rows_splits (host side of vp3d_wgrad_rows_s16): a candidate slice count, at least 6 K-tiles of 32 rows
+    per slice when sliced, and the step's big shapes fill one (nearly) whole round of the 256 CUs."""
     from videopose3d_amd import ops_s16 as S
     for m in (1, 31, 65, 1000, 1024, 3072, 9216, 27648, 82944):
         for c_out, n_cols in ((256, 256), (256, 768), (1024, 1024), (1024, 3072), (512, 1536)):
             s = S._wgrad_rows_splits(m, c_out, n_cols)
             nkt = (m + 31) // 32
-            assert s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) and 1 <= s <= max(1, nkt)
+            assert s in S.WGRAD_SPLIT_CANDIDATES and 1 <= s <= max(1, nkt)
             assert s == 1 or nkt // s >= 6
-    assert S._wgrad_rows_splits(27648, 1024, 3072) == 16        # 48 tiles x 16 slices = 3 rounds (measured best)
+    assert S._wgrad_rows_splits(27648, 1024, 3072) == 5         # 48 tiles x 5 slices = 240 workgroups: one round, 63 MB of
+    assert S._wgrad_rows_splits(9216, 1024, 3072) == 5          # partials (16 slices: three rounds, 201 MB; tools/wgrad_splits.py)
     assert S._wgrad_rows_splits(27648, 1024, 1024) == 16        # 16 tiles x 16 slices = 1 round
     assert S.wgrad_rows_supported(1024, 1024) and S.wgrad_rows_supported(1024, 128) and not S.wgrad_rows_supported(1024, 96)
     assert not S.wgrad_rows_supported(128, 128) and not S.expand_rows_form(1024, 96)
