@@ -197,12 +197,19 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
     return S16(out, out_bound)
 
 
+_red_ok = {}
+
+
 def red_supported(m: int, n: int, k: int, c_up: int) -> bool:
     """Can a dgrad launch [m, n, k] carry the BatchNorm-backward column sums of its upstream activation (vp3d_s16_red)?
-    One K slice on the 128x128 / 256x256 buffer-descriptor tilings, whole column tiles."""
-    cfg, splits = plan(m, n, k)
-    bn = 256 if cfg == 22 else 128
-    return cfg in (20, 22) and splits == 1 and c_up % 256 == 0 and n % c_up == 0 and n % bn == 0
+    One K slice on the 128x128 / 256x256 buffer-descriptor tilings, whole column tiles.  (Cached: asked per launch.)"""
+    key = (m, n, k, c_up)
+    ok = _red_ok.get(key)
+    if ok is None:
+        cfg, splits = plan(m, n, k)
+        bn = 256 if cfg == 22 else 128
+        ok = _red_ok[key] = bool(cfg in (20, 22) and splits == 1 and c_up > 0 and c_up % 256 == 0 and n % c_up == 0 and n % bn == 0)
+    return ok
 
 
 RED_CFG_KEY = 1000              # profiler rows: tile configuration + 1000 = the instance that carries the fused sums
