@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 106
+#define VP3D_VERSION 107
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -683,6 +683,20 @@ typedef struct vp3d_adam {
 } vp3d_adam;
 int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* grad, float* exp_avg,
                    float* exp_avg_sq, float* max_exp_avg_sq, const vp3d_adam* h);
+
+/* Guard of the split-fp16 arithmetic (videopose3d_amd/range_guard.py).  The S16 operand format keeps one exponent per
+ * tensor, while the reference's BatchNorm affine and conv weights are unconstrained (common/model.py:32,102,113-119): this
+ * measures, on the device and without a host synchronisation, how far the parameters are from the regime in which a hot
+ * channel pushes the others down the format's range.  "spread" of per-group magnitudes g_i := E(max g) - E(median of the
+ * non-zero g), E = binary exponent.  atomicMax-ed into out (int32[2], zeroed by the caller for a fresh measurement):
+ *   out[0]  BatchNorm layers l < n_layers (host pointer tables): groups = channels, g_c = |gamma_l[c]| * kfac[l] + |beta_l[c]|
+ *           (kfac = sqrt(M_l - 1) in training: the activation bound of vp3d_act_bounds_multi per channel; ~4 in eval);
+ *   out[1]  tensors i < n_tensors: groups = rows of row_len[i] contiguous floats (Conv1d.weight [C_out][C_in*taps]: output rows).
+ * ws: sum(rows) ints of workspace.  At most vp3d_range_max_tensors() layers / tensors. */
+int vp3d_range_max_tensors(void);
+int vp3d_range_stats(vp3d_stream_t stream, int32_t n_layers, int32_t C, const float* const* gamma, const float* const* beta,
+                     const float* kfac, int32_t n_tensors, const float* const* w, const int64_t* rows, const int64_t* row_len,
+                     int32_t* ws, int64_t ws_ints, int32_t* out);
 
 #ifdef __cplusplus
 }

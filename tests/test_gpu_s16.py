@@ -689,3 +689,155 @@ def test_fused_prologue_is_bit_identical(joints, c, arc, monkeypatch):
             assert torch.equal(res[0][2][k], res[1][2][k]), k
     finally:
         engine.S16_MIN_FORWARD_FLOPS.update(keep)
+
+
+# ---- the block-exponent format at its edges: adversarial intra-tensor dynamic range (reference: nn.BatchNorm1d's affine and
+# the conv weights are unconstrained, common/model.py:32,102,113-119) -- against the float64 oracle, with the exact-fp32 engine
+# beside it as the yardstick of what ANY fp32 evaluation of the same step loses (tools/range_edges.py prints the full table) ---
+RANGE_EDGE_CASES = [(128, c, s, None) for c in ("gamma", "beta", "w_row", "w_col") for s in (8, 14, 20)] + \
+    [(128, "w_row", 12, None), (128, "none", 0, 1e4),
+     (1024, "gamma", 20, None), (1024, "beta", 20, None), (1024, "w_row", 12, None), (1024, "w_row", 20, None),
+     (1024, "w_col", 20, None), (1024, "none", 0, 1e4)]
+
+
+def _range_models(channels, sd):
+    from videopose3d_amd import engine
+    out = []
+    for math in ("f32", "f16x3"):
+        m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.0, channels=channels).to(DEV).train()
+        m.math = math
+        m.load_state_dict(sd)
+        out.append(m)
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("channels,case,s,joint", RANGE_EDGE_CASES)
+def test_dynamic_range_edges_raw_format_vs_fp64_oracle(channels, case, s, joint, monkeypatch):
+    """ONE hot channel (a BatchNorm gamma_c / beta_c, a conv-weight output row, a conv-weight input column = hot dy) up to
+    2^20 x the rest, or one input joint 1e4 x the others, with the guard OFF: the raw split-fp16 format stays on the
+    exact-fp32 engine's own error -- output MPJPE <= 4 x the fp32 engine's + 2e-6 (and <= 1e-4 absolute wherever the fp32
+    engine itself is within 2e-5 of the float64 oracle: a beta_c of 1e5 is ill-conditioned for ANY fp32 evaluation, 3e-3
+    on the fp32 engine), every gradient tensor in max-norm <= 4 x the fp32 engine's + 5e-6.  (A hot channel dominates every
+    contraction it enters in EITHER arithmetic: the 2^-40 * bound absolute error of the small elements stays below fp32's
+    own rounding of those sums; vp3d_s16.h.)"""
+    from tests import util as U
+    from videopose3d_amd import engine, range_guard
+    monkeypatch.setenv("VP3D_RANGE_GUARD", "0")
+    sd = U.range_edge_state(channels, case, s)
+    x, tgt = U.range_edge_batch(64, joint)
+    yo, go = U.range_edge_oracle(sd, x, tgt)
+    m32, m16 = _range_models(channels, sd)
+    n16 = engine.ENGINE_CALLS["s16_train"]
+    r32 = U.range_edge_errors(m32, x, tgt, yo, go)
+    assert engine.ENGINE_CALLS["s16_train"] == n16
+    r16 = U.range_edge_errors(m16, x, tgt, yo, go)
+    assert engine.ENGINE_CALLS["s16_train"] == n16 + 1 and not range_guard.tripped(m16)      # the raw format was measured
+    assert r16["finite"] and r32["finite"]
+    assert r16["mpjpe"] <= 4 * r32["mpjpe"] + 2e-6, (r16, r32)
+    assert r32["mpjpe"] > 2e-5 or r16["mpjpe"] <= 1e-4, (r16, r32)
+    assert r16["grad_maxnorm"] <= 4 * r32["grad_maxnorm"] + 5e-6, (r16, r32)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("channels", [128, 1024])
+@pytest.mark.parametrize("case,s", [("gamma", 14), ("gamma", 20), ("gamma_all_layers", 14), ("gamma_all_layers", 20),
+                                    ("beta", 20), ("w_row", 20)])
+def test_range_guard_routes_adversarial_parameters_to_the_fp32_engine(channels, case, s):
+    """As shipped (guard on): parameters whose per-channel spread is outside the format's lossless window (activation
+    bounds 2^12, weight rows 2^16) are measured on the device when they are loaded and the model's calls run on the
+    exact-fp32 engine -- bit for bit what math='f32' gives; re-loading benign parameters puts it back on split-fp16."""
+    import warnings
+    from tests import util as U
+    from videopose3d_amd import engine, range_guard
+    sd = U.range_edge_state(channels, case, s)
+    x, tgt = U.range_edge_batch(32)
+    m32, m16 = _range_models(channels, sd)
+    outs = []
+    n16, n32 = engine.ENGINE_CALLS["s16_train"], engine.ENGINE_CALLS["f32_train"]
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        for m in (m32, m16):
+            y = m(x.to(DEV))
+            torch.mean(torch.norm(y - tgt.to(DEV), dim=3)).backward()
+            outs.append(y.detach())
+    st = range_guard.status(m16)
+    assert st["tripped"] and st["sync_checks"] == 1 and (st["last"][0] > 12 or st["last"][1] > 16), st
+    assert st["last"][0 if case != "w_row" else 1] >= s - 1, st             # the statistic sees the planted factor
+    assert any("exact-fp32 engine" in str(w.message) for w in wlist)
+    assert engine.ENGINE_CALLS["s16_train"] == n16 and engine.ENGINE_CALLS["f32_train"] == n32 + 2
+    assert torch.equal(outs[0], outs[1])
+    for (k, a), (_, b) in zip(m16.named_parameters(), m32.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    # benign parameters again: measured at the load, back on the split-fp16 engine
+    m16.load_state_dict(U.range_edge_state(channels, "none", 0))
+    m16(x.to(DEV))
+    st = range_guard.status(m16)
+    assert not st["tripped"] and st["sync_checks"] == 2 and st["last"][0] <= 3 and st["last"][1] <= 3, st
+    assert engine.ENGINE_CALLS["s16_train"] == n16 + 1
+
+
+def test_range_guard_steady_state_has_no_host_synchronisation_and_catches_inplace_edits(monkeypatch):
+    """Steady state: one synchronous measurement at the first call, then an asynchronous one every CHECK_EVERY calls whose
+    result a LATER call reads from pinned memory.  An in-place edit that by-passes load_state_dict is caught that way."""
+    from tests import util as U
+    from videopose3d_amd import engine, range_guard
+    monkeypatch.setattr(range_guard, "CHECK_EVERY", 4)
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.0, channels=128).to(DEV).train()
+    m.math = "f16x3"
+    m.load_state_dict(U.range_edge_state(128, "none", 0))
+    x = U.range_edge_batch(16)[0].to(DEV)
+    for _ in range(9):
+        m(x)
+    st = range_guard.status(m)
+    assert st["sync_checks"] == 1 and st["checks"] >= 3 and not st["tripped"], st
+    with torch.no_grad():
+        m.layers_bn[1].weight[7] *= 2.0 ** 15          # (no load_state_dict: nothing tells the guard)
+    n32 = engine.ENGINE_CALLS["f32_train"]
+    for i in range(12):
+        m(x)
+        torch.cuda.synchronize()                       # (lets the asynchronous copy's event complete between calls)
+    st = range_guard.status(m)
+    assert st["tripped"] and st["sync_checks"] == 1 and st["last"][0] >= 14, st
+    assert engine.ENGINE_CALLS["f32_train"] > n32
+
+
+def test_range_stats_kernel_matches_numpy():
+    """vp3d_range_stats: E(max) - E(lower median of the non-zero groups) of |gamma_c| k + |beta_c| per BatchNorm layer and of
+    the per-row maxima per weight tensor, maximum over layers / tensors."""
+    import ctypes as C
+    import numpy as np
+    from videopose3d_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    c = 192
+    gam = [torch.randn(c, generator=g) for _ in range(3)]
+    bet = [torch.randn(c, generator=g) * 0.1 for _ in range(3)]
+    gam[1][17] = 3.0e5
+    gam[2][:40] = 0.0
+    bet[2][:40] = 0.0                                   # dead channels: left out of the median
+    kf = [31.0, 5.0, 100.0]
+    ws = [torch.randn(c, 96, generator=g) * 0.05, torch.randn(64, 301, generator=g)]
+    ws[0][3] *= 7.0e4
+    ws[1][5] = 0.0
+
+    def spread(v):
+        v = np.asarray(v, np.float64)
+        e = np.sort(np.frexp(v[v > 0])[1])
+        return int(e[-1] - e[(len(e) + 1) // 2 - 1])
+    want_a = max(spread(gm.abs().numpy() * k + bt.abs().numpy()) for gm, bt, k in zip(gam, bet, kf))
+    want_w = max(spread(w.abs().amax(dim=1).numpy()) for w in ws)
+    gd, bd, wd = [t.to(DEV) for t in gam], [t.to(DEV) for t in bet], [t.to(DEV).contiguous() for t in ws]
+    out = torch.zeros(2, dtype=torch.int32, device=DEV)
+    wsp = torch.empty(sum(w.shape[0] for w in ws), dtype=torch.int32, device=DEV)
+
+    def ptrs(ts):
+        arr = (C.c_void_p * len(ts))()
+        for i, t in enumerate(ts):
+            arr[i] = t.data_ptr()
+        return arr
+    _lib.check(_lib.lib().vp3d_range_stats(ops._stream(), 3, c, ptrs(gd), ptrs(bd), (C.c_float * 3)(*kf), 2, ptrs(wd),
+                                           (C.c_int64 * 2)(*[w.shape[0] for w in ws]), (C.c_int64 * 2)(*[w.shape[1] for w in ws]),
+                                           wsp.data_ptr(), wsp.numel(), out.data_ptr()), "vp3d_range_stats")
+    got = out.cpu().tolist()
+    assert got == [want_a, want_w], (got, want_a, want_w)
+    assert want_a >= 17 and want_w >= 15

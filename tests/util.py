@@ -218,3 +218,91 @@ def load_kat_matrix():
         name, key = k.split("|", 1)
         out.setdefault(name, {})[key] = z[k]
     return out
+
+
+# ---- adversarial intra-tensor dynamic range (tests/test_gpu_s16.py, tools/range_edges.py) --------------------------------
+RANGE_FW = [3, 3, 3]
+RANGE_CASES = ("none", "gamma", "gamma_all_layers", "beta", "w_row", "w_col")
+
+
+def range_edge_state(channels, case, s, ch=5, seed=0):
+    """state_dict (CPU tensors) of a strided arc-3,3,3 model with a trained-looking BatchNorm affine and ONE adversarial
+    edit of factor 2^s: `gamma` / `beta`: channel `ch` of the first C x C block's BatchNorm; `gamma_all_layers`: the same
+    channel hot in every BatchNorm (compounds along the residual chain); `w_row`: output row `ch` of the first 3-tap C x C
+    conv; `w_col`: input column `ch` of the 1x1 conv (makes that channel's incoming gradient, hence dy, hot)."""
+    import torch
+    import videopose3d_amd as V
+    torch.manual_seed(seed)
+    m = V.TemporalModelOptimized1f(17, 2, 17, RANGE_FW, dropout=0.0, channels=channels)
+    f = float(2.0 ** s)
+    with torch.no_grad():
+        for bn in [m.expand_bn] + list(m.layers_bn):
+            bn.weight.copy_(1.0 + 0.2 * torch.randn_like(bn.weight))
+            bn.bias.copy_(0.1 * torch.randn_like(bn.bias))
+        if case == "gamma":
+            m.layers_bn[0].weight[ch] *= f
+        elif case == "gamma_all_layers":
+            for bn in [m.expand_bn] + list(m.layers_bn):
+                bn.weight[ch] *= f
+        elif case == "beta":
+            m.layers_bn[0].bias[ch] = 0.1 * f
+        elif case == "w_row":
+            m.layers_conv[0].weight[ch] *= f
+        elif case == "w_col":
+            m.layers_conv[1].weight[:, ch] *= f
+        elif case != "none":
+            raise ValueError(case)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def range_edge_batch(batch=64, joint_scale=None):
+    import torch
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.randn(batch, 27, 17, 2, generator=g) * 0.5).clamp(-1, 1)
+    if joint_scale is not None:
+        x[:, :, 3, :] *= joint_scale                    # one joint far outside the screen-normalised range of the others
+    tgt = torch.randn(batch, 1, 17, 3, generator=g) * 0.3
+    return x, tgt
+
+
+def range_edge_oracle(sd, x, tgt):
+    """float64 oracle: (output, {name: gradient}) of one mpjpe training step (dropout 0)."""
+    from oracle import temporal_oracle as O
+    sdn = {k: v.numpy() for k, v in sd.items()}
+    yo, cache, _ = O.forward(sdn, x.numpy(), RANGE_FW, kind="strided", training=True, dtype=np.float64)
+    return yo, O.backward(cache, O.mpjpe_grad(yo, tgt.numpy().astype(np.float64)))
+
+
+def range_edge_errors(model, x, tgt, yo, go):
+    """One step of `model` (on the GPU) against the oracle's (yo, go): dict(mpjpe, grad_maxnorm [worst tensor, |d| / max|ref|],
+    grad_rowrel [worst output row / input column relative to ITS OWN reference maximum], finite, names)."""
+    import torch
+    dev = next(model.parameters()).device
+    model.zero_grad(set_to_none=True)
+    y = model(x.to(dev))
+    torch.mean(torch.norm(y - tgt.to(dev), dim=3)).backward()
+    torch.cuda.synchronize()
+    yv = y.detach().cpu().numpy().astype(np.float64)
+    r = dict(mpjpe=float(np.mean(np.sqrt(((yv - yo) ** 2).sum(-1)))), finite=bool(np.isfinite(yv).all()))
+    worst_t, worst_r, wt_name, wr_name = 0.0, 0.0, "", ""
+    for k, p in model.named_parameters():
+        a = p.grad.detach().cpu().numpy().astype(np.float64)
+        ref = go[k].astype(np.float64)
+        r["finite"] = r["finite"] and bool(np.isfinite(a).all())
+        d = np.abs(a - ref)
+        et = float(d.max() / (np.abs(ref).max() + 1e-300))
+        d2, r2 = d.reshape(d.shape[0], -1), np.abs(ref).reshape(ref.shape[0], -1)
+        rmax = r2.max(axis=1)
+        ok = rmax > 0
+        er = float((d2.max(axis=1)[ok] / rmax[ok]).max()) if ok.any() else 0.0
+        if a.ndim == 3 and a.shape[1] > 1:               # conv weights: also per INPUT channel
+            d3 = d.transpose(1, 0, 2).reshape(a.shape[1], -1)
+            cmax = np.abs(ref).transpose(1, 0, 2).reshape(a.shape[1], -1).max(axis=1)
+            okc = cmax > 0
+            er = max(er, float((d3.max(axis=1)[okc] / cmax[okc]).max()))
+        if et > worst_t:
+            worst_t, wt_name = et, k
+        if er > worst_r:
+            worst_r, wr_name = er, k
+    r.update(grad_maxnorm=worst_t, grad_maxnorm_at=wt_name, grad_rowrel=worst_r, grad_rowrel_at=wr_name)
+    return r

@@ -175,6 +175,8 @@ SIGNATURES = {
     "vp3d_mpjpe_ws_bytes": (_i64, [_i64]),
     "vp3d_mpjpe": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_adam_step": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _P(Adam)]),
+    "vp3d_range_max_tensors": (C.c_int, []),
+    "vp3d_range_stats": (C.c_int, [_vp, _i32, _i32, _P(_vp), _P(_vp), _P(_f32), _i32, _P(_vp), _P(_i64), _P(_i64), _vp, _i64, _vp]),
 }
 
 _lib = None
@@ -200,8 +202,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 106:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (106); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 107:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (107); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

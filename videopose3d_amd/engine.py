@@ -18,7 +18,7 @@ from typing import List, Optional
 
 import torch
 
-from . import ops
+from . import ops, range_guard
 from .plan import ConvSpec, StackPlan
 
 
@@ -364,6 +364,8 @@ def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Option
     if getattr(mod, "math", "f32") != "f16x3":
         return False
     from . import engine_s16
+    if range_guard.tripped(mod):                     # intra-tensor dynamic range outside the S16 format's lossless window
+        return False
     if not engine_s16.supported(mod, t_in, training, need_dx, batch=batch or 0):
         return False
     return batch is None or mod._plan.forward_flops(batch, t_in) >= S16_MIN_FORWARD_FLOPS[bool(training)]
@@ -375,6 +377,7 @@ ENGINE_CALLS = collections.Counter()
 
 
 def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
+    range_guard.tick(mod, False, x3)
     if use_s16(mod, x3.shape[1], False, batch=x3.shape[0]):
         from . import engine_s16
         ENGINE_CALLS["s16_eval"] += 1
@@ -385,6 +388,7 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 
 def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     """Returns (out3, saved); saved is None unless `save` (it records which arithmetic produced it)."""
+    range_guard.tick(mod, True, x3)
     if use_s16(mod, x3.shape[1], True, need_dx, batch=x3.shape[0]):
         from . import engine_s16
         ENGINE_CALLS["s16_train"] += 1

@@ -209,9 +209,10 @@ class ChunkedGenerator:
         while True:
             first, order = self.next_pairs()
             table = self._device_table(order)
-            if first == 0 and self.shard is not None and all(self._batch_rows(b_i, len(order)) is None
-                                                              for b_i in range(self.num_batches)):
-                # (an endless generator would otherwise spin here forever without ever yielding)
+            if self.endless and first == 0 and self.shard is not None and all(
+                    self._batch_rows(b_i, len(order)) is None for b_i in range(self.num_batches)):
+                # (an endless generator would otherwise spin here forever without ever yielding; a one-epoch generator
+                # just yields its empty epoch, as a tiny sharded validation set always did)
                 raise ValueError("sharded ChunkedGenerator: no batch of this epoch can be split over %d ranks "
                                  "(%d chunks, batch size %d: every rank needs at least 2 samples per batch)"
                                  % (self.shard[1], len(order), self.batch_size))

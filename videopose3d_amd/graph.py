@@ -34,7 +34,7 @@ from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
 
-from . import dp, engine, loss as vloss
+from . import dp, engine, loss as vloss, range_guard
 from ._lib import Vp3dError
 
 
@@ -81,10 +81,12 @@ class _Segments:
 
     def _end(self):
         kind, g, ctx = self._cur
-        g.capture_end()
-        ctx.__exit__(None, None, None)
-        self.graphs.append((kind, g))
         self._cur = None
+        try:
+            g.capture_end()
+        finally:
+            ctx.__exit__(None, None, None)            # also when capture_end raises (abort): never leave the stream entered
+        self.graphs.append((kind, g))
 
     def begin(self):
         self._begin("main")
@@ -254,6 +256,9 @@ class GraphedTrainStep:
         """One training step on the batch; returns the mpjpe loss (a 0-dim device tensor that the next call overwrites)."""
         if not inputs_2d.is_cuda:
             raise Vp3dError("GraphedTrainStep runs on the GPU only")
+        # the split-fp16 engine's dynamic-range guard ticks per replay (the captured forward is never re-executed by Python);
+        # a trip changes use_s16 and with it the key: the step is re-captured on the exact-fp32 kernels
+        range_guard.tick(self.model, True, inputs_2d)
         key = self._key(inputs_2d, inputs_3d)
         e = self._cache.get(key)
         if e is not None and e.guard != self._guard():

@@ -119,10 +119,33 @@ class TemporalModelBase(nn.Module):
             self._bn_momentum_host = mom
         return t.data_ptr()
 
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .cpu(): the device-side step counter and momentum are plain attributes (not state_dict entries),
+        so they follow the parameters here -- a launch on cuda:1 must never be handed a cuda:0 address."""
+        out = super()._apply(fn, *args, **kwargs)
+        from . import range_guard
+        range_guard.invalidate(self)                 # (the dynamic-range guard measures again before the next call)
+        dev = self.shrink.weight.device
+        for name in ("_drop_counter", "_bn_momentum_dev"):
+            t = getattr(self, name, None)
+            if t is not None and t.device != dev:
+                setattr(self, name, t.to(dev) if dev.type == "cuda" else None)
+        return out
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """nn.Module.load_state_dict (run.py:209-210,219,303-304,426,429); the split-fp16 engine's dynamic-range guard measures
+        the new parameters before the next call chooses an arithmetic (range_guard.py)."""
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        from . import range_guard
+        range_guard.invalidate(self)
+        return out
+
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
+            if k == "_range_state":                  # (device buffers + an event of the guard: the copy builds its own)
+                continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         # a copy is a model of its own: its own dropout mask stream (the seed mixes the ordinal) and device-side counters
         TemporalModelBase._n_models += 1
