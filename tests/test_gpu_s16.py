@@ -648,6 +648,9 @@ def test_engines_agree_on_random_configurations_through_the_persistent_tail():
     import os
     import subprocess
     import sys
+    from videopose3d_amd import _lib
+    if not _lib.lib().vp3d_has_experiments():
+        pytest.skip("library built without VP3D_BUILD_EXPERIMENTS: no persistent tail")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "40", "11"], capture_output=True, text=True,
                        cwd=root, timeout=600, env=dict(os.environ, VP3D_TAIL="1"))
@@ -763,7 +766,8 @@ def test_range_guard_routes_adversarial_parameters_to_the_fp32_engine(channels, 
             outs.append(y.detach())
     st = range_guard.status(m16)
     assert st["tripped"] and st["sync_checks"] == 1 and (st["last"][0] > 12 or st["last"][1] > 16), st
-    assert st["last"][0 if case != "w_row" else 1] >= s - 1, st             # the statistic sees the planted factor
+    if case != "beta":                               # (a hot beta_c is measured against gamma_c * sqrt(M - 1), not against 1)
+        assert st["last"][0 if case != "w_row" else 1] >= s - 1, st         # the statistic sees the planted factor
     assert any("exact-fp32 engine" in str(w.message) for w in wlist)
     assert engine.ENGINE_CALLS["s16_train"] == n16 and engine.ENGINE_CALLS["f32_train"] == n32 + 2
     assert torch.equal(outs[0], outs[1])

@@ -476,10 +476,15 @@ def test_persistent_tail_selection_rules(monkeypatch):
     """engine_s16.tail_from (which trailing blocks run in the persistent tail kernels when VP3D_TAIL=1): whole blocks of the
     strided class whose windows tile, B * T_out <= 3072 rows, C % 64 == 0, one BatchNorm momentum, no synchronised BatchNorm;
     off by default."""
-    from videopose3d_amd import engine_s16
+    from videopose3d_amd import engine_s16, ops_s16
     m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
     assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0                    # opt-in
     monkeypatch.setenv("VP3D_TAIL", "1")
+    if not _lib.lib().vp3d_has_experiments():
+        # the default library is built without the persistent tail (an experiment since round 4): nothing is ever selected
+        assert ops_s16.tail_max_layers() == 0
+        assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0
+        monkeypatch.setattr(ops_s16, "tail_max_layers", lambda: 8)     # the selection rules of an experiments build
     assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 5                    # blocks 3 and 4: 3072 and 1024 rows
     assert engine_s16.tail_from(m, m._plan, 243, 200, None, True) == 3                     # 200 * 27 rows are too many, 200 * 9 fit
     assert engine_s16.tail_from(m, m._plan, 243, 64, None, True) == 1                      # 64 * 27 = 1728 rows: all four blocks = the 8 layers a tail may hold

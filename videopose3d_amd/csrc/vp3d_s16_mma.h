@@ -113,15 +113,16 @@ __device__ __forceinline__ void mma_frags(const Frags<RB, CB, STEPS>& f, f32x16 
 }
 
 // One K-tile of this wave's sub-tile: STEPS MFMA k-steps (16 elements each) x 3 products.
-template <int RB, int CB, int STEPS, int ROWB>
+// RBW <= RB: the wave only owns the first RBW row blocks of its accumulator array (the 224-row tiling: wave row 1 has 3 of 4).
+template <int RB, int CB, int STEPS, int ROWB, int RBW = RB>
 __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const char* __restrict__ sB,
                                              f32x16 (&acc)[RB][CB], int off0, int off1) {
-  f16x8 ah[STEPS][RB], al[STEPS][RB], bh[STEPS][CB], bl[STEPS][CB];
+  f16x8 ah[STEPS][RBW], al[STEPS][RBW], bh[STEPS][CB], bl[STEPS][CB];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int off = s == 0 ? off0 : off1;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
+    for (int i = 0; i < RBW; ++i) {
       ah[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + off);
       al[s][i] = *reinterpret_cast<const f16x8*>(sA + i * (32 * ROWB) + (off ^ 16));
     }
@@ -134,17 +135,17 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int i = 0; i < RBW; ++i)
 #pragma unroll
       for (int j = 0; j < CB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int i = 0; i < RBW; ++i)
 #pragma unroll
       for (int j = 0; j < CB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int i = 0; i < RBW; ++i)
 #pragma unroll
       for (int j = 0; j < CB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
@@ -152,7 +153,7 @@ __device__ __forceinline__ void compute_tile(const char* __restrict__ sA, const 
   // Pin the interleave (hipcc otherwise sinks every ds_read to just before its first use: read -> wait -> 2 MFMA -> read
   // ..., exposing the LDS latency a dozen times per K-tile): all fragment reads of k-step 0 up front, the reads of k-step
   // 1 one at a time behind the first MFMAs of step 0.  Masks: 0x008 MFMA, 0x100 DS read.
-  constexpr int R = 2 * (RB + CB), MQ = 3 * RB * CB;       // fragment reads / MFMAs per k-step
+  constexpr int R = 2 * (RBW + CB), MQ = 3 * RBW * CB;       // fragment reads / MFMAs per k-step
   __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
   if constexpr (STEPS == 2) {
     constexpr int NI = R < MQ ? R : MQ;

@@ -131,6 +131,17 @@ __global__ void k_xcc_probe(int* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf);
 }
 
+// The probe certifies the mapping for ITS launch; every persistent launch re-checks its own placement (one s_getreg per
+// workgroup): a workgroup of the grouped flavour that finds itself on another XCD than b % 8 (partition mode changed, a
+// dispatcher that places this grid differently) raises the error flag -- the host reports the launch as invalid
+// (ops_s16._tail_watch) instead of consuming lines that a foreign XCD's write-back never covered.
+__device__ __forceinline__ void check_xcc_placement(const GridSync& g) {
+  if (g.grouped && threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;
+    if (xcc != (blockIdx.x % kXcds)) __hip_atomic_store(g.base, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // items of a phase: workgroup b runs on XCD b % 8 and takes a CONTIGUOUS eighth of the item order, so that the tiles an XCD
 // works on at a time are neighbours (shared operand panels in its L2); returns false past the end
 __device__ __forceinline__ bool next_item(int k, int items, int& L) {
@@ -384,6 +395,7 @@ __device__ __forceinline__ void fwd_stats_strip(const TailFwdArgs& a, const FwdL
 __global__ void __launch_bounds__(T_NT, 2) k_tail_fwd(const TailFwdArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[T_SMEM];
   GridSync gs{a.sync, gridDim.x, 0u, a.grouped, a.trace, 0};
+  check_xcc_placement(gs);
   stamp(gs);
   const int C = a.C;
   for (int l = 0; l < a.n_layers; ++l) {
@@ -580,6 +592,7 @@ __global__ void __launch_bounds__(T_NT, 2) k_tail_bwd(const TailBwdArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[T_SMEM];
   __shared__ float bred[4];
   GridSync gs{a.sync, gridDim.x, 0u, a.grouped, a.trace, 0};
+  check_xcc_placement(gs);
   stamp(gs);
   const int C = a.C;
   constexpr int kUnpackBlocks = 128;                 // virtual blocks of a weight-gradient un-pack riding in a reduce phase

@@ -193,10 +193,11 @@ def tail_from(mod, plan: StackPlan, t_in0: int, batch: int, sync, save: bool) ->
     convs produce at most TAIL_MAX_ROWS rows run as ONE launch per direction), or 0 when there is none.  The tail takes whole
     blocks of the strided class whose windows tile (reshape GEMMs), 3-tap or 1-tap convs, C % 64 == 0, per-replica BatchNorm
     with one momentum for all layers; at most vp3d_tail_max_layers() layers.
-    OPT-IN (VP3D_TAIL=1): measured on MI355X at the benchmark shapes the persistent kernels are correct and ~0.35 ms per step
-    SLOWER than the per-layer launches they replace (the hardware queue already pipelines those ~90 small
-    kernels; 25 grid barriers of ~8 us and cold L2s after each cost more than the launches they remove)."""
-    if os.environ.get("VP3D_TAIL", "0") != "1" or sync is not None or plan.n_blocks < 1:
+    AN EXPERIMENT since round 4 (library built with VP3D_BUILD_EXPERIMENTS=1, then VP3D_TAIL=1): measured on MI355X at the
+    benchmark shapes the persistent kernels are correct and ~0.35 ms per step SLOWER than the per-layer launches they replace
+    (the hardware queue already pipelines those ~90 small kernels; 25 grid barriers of ~8 us and cold L2s after
+    each cost more than the launches they remove); the default library refuses the entry points (tail_max_layers() == 0)."""
+    if os.environ.get("VP3D_TAIL", "0") != "1" or sync is not None or plan.n_blocks < 1 or S.tail_max_layers() == 0:
         return 0
     bns = engine._bns(mod)
     t_len = plan.lengths(t_in0)
