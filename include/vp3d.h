@@ -251,8 +251,26 @@ typedef struct vp3d_s16 {
   int32_t* tickets;
   /* fused BatchNorm-backward column sums of the upstream activation (dgrad launches of the training backward), or NULL */
   const vp3d_s16_red* red;
+  /* Rows per BatchNorm statistics slab that epi->stat_sum / stat_m2 were sized for: 0 or 64 = vp3d_stat_slabs(M) rows of 64
+   * (every configuration but 28); 32 = (M + 31) / 32 rows -- what tile configuration 28 writes (its 224-row tiles are not
+   * multiples of 64 rows) and vp3d_bn_finalize_slab merges.  A launch whose configuration writes another slab size than the
+   * caller announced is refused, never silently mis-indexed. */
+  int32_t stat_slab_rows;
 } vp3d_s16;
-int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits);
+/* Configuration 28: 224 x 256 tiles (the 8 waves of configuration 22; wave row 0 owns 4 row blocks of 32, wave row 1 owns 3):
+ * B * T_out = 27,648 rows of the benchmark step are 124 x 4 = 496 such tiles = 1.94 rounds of the 256 CUs, where the 432
+ * tiles of 256 x 256 = 1.69 rounds cost 2.  One K slice, fp32 or S16 output, bias / ReLU / residual / statistics (32-row
+ * slabs) / amax epilogues; no fused activation, no fused BatchNorm-backward sums, operands below 2 GiB.
+ * vp3d_nt_s16_plan flags: bit 0 = raw partial output (weight gradients), bit 1 = configuration 28 may be chosen (the caller
+ * sizes its statistics for vp3d_nt_s16_stat_slab_rows(cfg) and does not attach act / red epilogues). */
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t flags, int32_t* cfg, int32_t* splits);
+int vp3d_nt_s16_stat_slab_rows(int32_t cfg);
+/* vp3d_bn_finalize / vp3d_bn_finalize_dm for statistics in slabs of slab_rows (32 or 64) rows: momentum_dev != NULL is read
+ * at execution time instead of `momentum`. */
+int vp3d_bn_finalize_slab(vp3d_stream_t stream, int32_t C, int64_t M, int32_t slab_rows, const float* stat_sum, const float* stat_m2,
+                          const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                          float* save_mean, float* save_invstd);
 /* The expand layer's forward, dedicated kernel (replaces model.py:74 / :127 / :176
  *   x = self.drop(self.relu(self.expand_bn(self.expand_conv(x))))
  * in training mode without ever storing the conv output): x = S16 im2row rows [M][kpad] (kpad = 32..128, e.g. 3 taps x 34

@@ -62,6 +62,10 @@ CASES = [  # (B, T, spec, cfg, splits)
     (11, 67, ConvSpec(64, 1344, 1), 20, 1),             # 11 column tiles: a full block of 8 + a ragged block of 3 (tile order)
     (11, 67, ConvSpec(64, 2368, 1), 22, 1),             # 10 column tiles of 256 (8 + 2), 3 row tiles: 30 tiles over 8 XCDs
     (11, 67, ConvSpec(192, 2368, 1), 22, 2),            # ... with split-K (positions of a split are a multiple of 8)
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 28, 1),        # 224 x 256 tiles (wave rows of 4 + 3 row blocks): one ragged tile
+    (31, 81, ConvSpec(64, 512, 3, 1, 3), 28, 1),        # ... M = 837 = 3 full tiles + 165 rows (5 blocks + 5 rows), strided
+    (11, 67, ConvSpec(64, 2368, 1), 28, 1),             # ... ragged N (10 column tiles of 256, the last one 64 wide)
+    (7, 40, ConvSpec(128, 256, 3, 9, 1), 28, 1),        # ... dilated taps
 ]
 
 
@@ -78,17 +82,27 @@ def test_nt_gemm_vs_fp64(case):
     ref = torch.relu(ref)
     xs, ws = S.split(x), S.split(ops.pack_weight(w))
     m = b * spec.t_out(t)
-    stats = ops.stat_buffers(m, spec.c_out, DEV)
+    slab = S.stat_slab_rows(cfg)                        # 64 rows; the 224-row tiling writes 32-row slabs
+    stats = ops.stat_buffers(m, spec.c_out, DEV, slab)
     am = S.new_bound(DEV)
-    y = S.conv_nt(xs, ws, spec, bias=bias, relu=True, stats=stats, amax_out=am, cfg=cfg, splits=splits)
+    y = S.conv_nt(xs, ws, spec, bias=bias, relu=True, stats=stats, amax_out=am, cfg=cfg, splits=splits, stat_slab=slab)
     assert float(((y.double() - ref).abs() / den).max()) < GEMM_TOL
     assert float(am.max()) == float(y.abs().max())
     # slab statistics are those of the raw conv output (before bias / ReLU)
     raw = (_ref_conv(x, w, spec)[0]).reshape(m, spec.c_out)
-    for s0 in range(0, m, 64):
-        blk = raw[s0:s0 + 64]
-        assert torch.allclose(stats[0][s0 // 64].double(), blk.sum(0), rtol=1e-4, atol=1e-4)
-        assert torch.allclose(stats[1][s0 // 64].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
+    assert stats[0].shape[0] == (m + slab - 1) // slab
+    for s0 in range(0, m, slab):
+        blk = raw[s0:s0 + slab]
+        assert torch.allclose(stats[0][s0 // slab].double(), blk.sum(0), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(stats[1][s0 // slab].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
+    if cfg == 28:
+        # the same K order per element as the 256-row tiling: bit-identical output; a statistics buffer sized for the
+        # other slab size is refused, not overrun
+        y22 = S.conv_nt(xs, ws, spec, bias=bias, relu=True, cfg=22, splits=1)
+        assert torch.equal(y, y22)
+        from videopose3d_amd._lib import Vp3dError
+        with pytest.raises(Vp3dError, match="slabs"):
+            S.conv_nt(xs, ws, spec, stats=ops.stat_buffers(m, spec.c_out, DEV), cfg=28, splits=1)
 
 
 def test_nt_gemm_exponents_and_residual():
@@ -845,3 +859,36 @@ def test_range_stats_kernel_matches_numpy():
     got = out.cpu().tolist()
     assert got == [want_a, want_w], (got, want_a, want_w)
     assert want_a >= 17 and want_w >= 15
+
+
+def test_tile_224_planned_for_the_benchmark_rows_and_finalize_agrees():
+    """The planner picks the 224 x 256 tiling (configuration 28) where the 256-row tiling strands most of a round -- the
+    27,648-row layers of the benchmark step -- when the caller allows it, never for raw (weight-gradient) launches; the
+    BatchNorm coefficients finalised from 32-row slabs agree with those from 64-row slabs to fp32 rounding."""
+    assert S.plan(27648, 1024, 3072, mix=True) == (28, 1) and S.plan(27648, 1024, 1024, mix=True) == (28, 1)
+    assert S.plan(27648, 3072, 1024, mix=True) == (28, 1)
+    assert S.plan(27648, 1024, 3072)[0] == 22 and S.plan(27648, 1024, 3072, raw=True, mix=True)[0] != 28
+    assert S.plan(1024, 1024, 3072, mix=True)[0] == 20          # the T_out = 1 tail stays on split 128 x 128 tiles
+    g = torch.Generator().manual_seed(21)
+    b, t, c = 40, 27, 256
+    spec = ConvSpec(c, c, 3, 1, 3)
+    x = torch.relu(torch.randn(b, t, c, generator=g)).to(DEV)
+    w = ((torch.rand(c, c, 3, generator=g) * 2 - 1) * 0.05).to(DEV)
+    xs, ws = S.split(x), S.split(ops.pack_weight(w))
+    m = b * spec.t_out(t)
+    bn = torch.nn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    coefs, stats_run = [], []
+    for cfg in (22, 28):
+        slab = S.stat_slab_rows(cfg)
+        st = ops.stat_buffers(m, c, DEV, slab)
+        S.conv_nt(xs, ws, spec, stats=st, cfg=cfg, splits=1, stat_slab=slab)
+        bn.running_mean.zero_()
+        bn.running_var.fill_(1.0)
+        coefs.append(ops.bn_finalize(bn, m, st, slab_rows=slab).clone())
+        stats_run.append((bn.running_mean.clone(), bn.running_var.clone()))
+    assert float((coefs[0] - coefs[1]).abs().max() / coefs[0].abs().max()) < 1e-6
+    assert torch.allclose(stats_run[0][0], stats_run[1][0], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(stats_run[0][1], stats_run[1][1], rtol=1e-5, atol=1e-7)

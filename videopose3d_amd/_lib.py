@@ -45,7 +45,8 @@ class S16Opts(C.Structure):
                 ("res_s16", C.c_int32), ("res_bound", C.c_void_p), ("out_s16", C.c_int32), ("in_amax", C.c_void_p),
                 ("l1", C.c_void_p), ("res_amax", C.c_void_p), ("out_wbound", C.c_void_p), ("no_output", C.c_int32),
                 ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("act_drop", C.POINTER(Dropout)),
-                ("act_bound", C.c_void_p), ("act_bits", C.c_void_p), ("tickets", C.c_void_p), ("red", C.c_void_p)]
+                ("act_bound", C.c_void_p), ("act_bits", C.c_void_p), ("tickets", C.c_void_p), ("red", C.c_void_p),
+                ("stat_slab_rows", C.c_int32)]
 
 
 class S16Red(C.Structure):                     # include/vp3d.h: vp3d_s16_red
@@ -110,6 +111,8 @@ SIGNATURES = {
     "vp3d_tconv_fwd": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,
                                  _vp, _i64]),
     "vp3d_nt_s16_plan": (C.c_int, [_i64, _i32, _i32, _i32, _P(_i32), _P(_i32)]),
+    "vp3d_nt_s16_stat_slab_rows": (C.c_int, [_i32]),
+    "vp3d_bn_finalize_slab": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_im2row_split_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64]),
     "vp3d_amax_floor": (C.c_int, [_vp, _i64, _vp, _f32, _vp]),
     "vp3d_expand_fwd_s16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _P(Dropout), _vp, _vp, _vp]),

@@ -179,10 +179,12 @@ int vp3d_tconv_fwd(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x,
   return launch_rows_gemm((hipStream_t)stream, a, /*b_kcontig=*/true);
 }
 
-int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t raw_partials, int32_t* cfg, int32_t* splits) {
-  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && cfg && splits, "nt_s16_plan: bad argument");
+int vp3d_nt_s16_stat_slab_rows(int32_t cfg) { return nt_s16_stat_slab_rows(cfg); }
+
+int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t flags, int32_t* cfg, int32_t* splits) {
+  VP3D_REQUIRE(M > 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0 && cfg && splits && (flags & ~3) == 0, "nt_s16_plan: bad argument");
   int c, sp;
-  plan_nt_s16((int)M, N, K, 1, raw_partials, &c, &sp);
+  plan_nt_s16((int)M, N, K, 1, flags & 1, &c, &sp, (flags >> 1) & 1);
   *cfg = c;
   *splits = sp;
   return VP3D_OK;
@@ -229,6 +231,9 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
   a.epi.bound_a = o->x_bound;
   a.epi.bound_b = o->w_bound;
   a.epi.amax_out = o->amax_out;
+  VP3D_REQUIRE(o->stat_slab_rows == 0 || o->stat_slab_rows == 32 || o->stat_slab_rows == 64, "tconv_nt_s16: stat_slab_rows=%d",
+               o->stat_slab_rows);
+  a.stat_slab_rows = o->stat_slab_rows ? o->stat_slab_rows : 64;
   if (o->res_s16) {
     VP3D_REQUIRE(a.epi.R != nullptr && o->res_bound != nullptr && a.epi.r_ld % 8 == 0 && a.epi.r_col0 % 8 == 0 && c_out % 8 == 0,
                  "tconv_nt_s16: an S16 residual needs its bound and 8-element aligned rows");

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FIN_CH = 16, FIN_GROUPS = 64;
 
 __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
-    int C, int64_t M, int nslab, const float* __restrict__ psum, const float* __restrict__ pm2,
+    int C, int64_t M, int nslab, int slab_rows, const float* __restrict__ psum, const float* __restrict__ pm2,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum_arg,
     const float* __restrict__ momentum_dev, float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
     float* save_mean, float* save_invstd) {
@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
   if (c < C) {
 #pragma unroll 4
     for (int s = g; s < nslab; s += FIN_GROUPS) {
-      const int64_t left = M - (int64_t)s * 64;
-      const double cnt = (double)(left < 64 ? left : 64);
+      const int64_t left = M - (int64_t)s * slab_rows;
+      const double cnt = (double)(left < slab_rows ? left : slab_rows);
       const double sum = (double)psum[(int64_t)s * C + c];
       a1 += sum;
       a2 += (double)pm2[(int64_t)s * C + c] + sum * sum / cnt;
@@ -513,7 +513,7 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd,
                "bn_finalize: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, 64, stat_sum,
                      stat_m2, gamma, beta, eps, momentum, (const float*)nullptr, running_mean, running_var, num_batches_tracked,
                      scale, shift, save_mean, save_invstd);
   return check_launch("bn_finalize");
@@ -527,10 +527,24 @@ int vp3d_bn_finalize_dm(vp3d_stream_t stream, int32_t C, int64_t M, const float*
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd && momentum_dev,
                "bn_finalize_dm: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, stat_sum,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, 64, stat_sum,
                      stat_m2, gamma, beta, eps, 0.f, momentum_dev, running_mean, running_var, num_batches_tracked, scale, shift,
                      save_mean, save_invstd);
   return check_launch("bn_finalize_dm");
+}
+
+int vp3d_bn_finalize_slab(vp3d_stream_t stream, int32_t C, int64_t M, int32_t slab_rows, const float* stat_sum, const float* stat_m2,
+                          const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                          float* save_mean, float* save_invstd) {
+  VP3D_REQUIRE(C > 0 && M > 0 && (slab_rows == 32 || slab_rows == 64), "bn_finalize_slab: C=%d M=%lld slab_rows=%d", C, (long long)M,
+               slab_rows);
+  VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize_slab: null pointer");
+  const int nslab = (int)((M + slab_rows - 1) / slab_rows);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab,
+                     slab_rows, stat_sum, stat_m2, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var,
+                     num_batches_tracked, scale, shift, save_mean, save_invstd);
+  return check_launch("bn_finalize_slab");
 }
 
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,

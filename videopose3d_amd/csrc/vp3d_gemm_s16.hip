@@ -124,9 +124,11 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const float* b_ptr[PB];
   int b_inc[PB];
   const int zoff = (lane & (CPR - 1)) * 4;
+  const int pa_cnt = C::pa_count(w), pa_first = C::pa_first(w);   // (uniform configurations: PA and w * PA)
+  const int rbw = C::rb_of(wm);                                   // row blocks of this wave (MIX: the last wave row has fewer)
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int r = (w * PA + i) * RPP + lane / CPR;
+    const int r = (i < pa_cnt ? pa_first + i : 0) * RPP + lane / CPR;
     const int chunk = (lane & (CPR - 1)) ^ C::swz(r);
     const int b = tab_b[r], t = tab_t[r];
     a_t[i] = t * p.t_stride + p.t_off + tap0 * p.tap_step;
@@ -162,7 +164,8 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     if (C::BUF) {
       if (live) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) blds16(rsA, a_cur[i], sA + (w * PA + i) * 1024);
+        for (int i = 0; i < PA; ++i)
+          if (!C::MIX || i < pa_cnt) blds16(rsA, a_cur[i], sA + (pa_first + i) * 1024);
 #pragma unroll
         for (int i = 0; i < PB; ++i) blds16(rsB, b_cur[i], sB + (w * PB + i) * 1024);
       } else {
@@ -227,17 +230,23 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     // tiles stay in flight across the barrier), then refills the stage everyone left at the end of iteration it-1
 #pragma unroll
     for (int ps = 0; ps < NSTAGE - 1; ++ps) issue(ps, ps < nkt);
-    int st_c = 0, st_i = NSTAGE - 1;                 // stage computed / issued this iteration
-    for (int it = 0; it < nkt; ++it) {
-      wait_vmcnt<(PA + PB) * (NSTAGE - 2)>();
-      if (NSTAGE == 2) __syncthreads();
-      else __builtin_amdgcn_s_barrier();
-      issue(st_i, it + NSTAGE - 1 < nkt);
-      const char* sA = smem + st_c * C::STAGE_B;
-      compute_tile<RB, CB, BK / 16, ROWB>(sA + a_row, sA + C::A_B + b_row, acc, off0, off1);
-      st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
-      st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
-    }
+    // (MIX: one specialised loop per wave row -- both pass the same barriers; a branch INSIDE the loop made hipcc spill)
+    auto main_loop = [&](auto rbw_c) {
+      constexpr int RBW = decltype(rbw_c)::value;
+      int st_c = 0, st_i = NSTAGE - 1;               // stage computed / issued this iteration
+      for (int it = 0; it < nkt; ++it) {
+        wait_vmcnt<(PA + PB) * (NSTAGE - 2)>();
+        if (NSTAGE == 2) __syncthreads();
+        else __builtin_amdgcn_s_barrier();
+        issue(st_i, it + NSTAGE - 1 < nkt);
+        const char* sA = smem + st_c * C::STAGE_B;
+        compute_tile<RB, CB, BK / 16, ROWB, RBW>(sA + a_row, sA + C::A_B + b_row, acc, off0, off1);
+        st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+        st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+      }
+    };
+    if (!C::MIX || wm != C::WM - 1) main_loop(std::integral_constant<int, RB>());
+    else main_loop(std::integral_constant<int, C::RBL>());
   }
   if (nkt > 0 && C::PIPE) {
     // Register double-buffered variant: the fragments of tile it+1 are read from LDS while the MFMAs of tile `it`
@@ -350,7 +359,41 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
   }
   if (!partial) {
-    if (e.stat_sum != nullptr) {                     // BatchNorm slab statistics of the raw conv output
+    if (C::MIX && e.stat_sum != nullptr) {           // ... per 32-row slab (a 64-row slab would straddle two 224-row tiles)
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if (i >= rbw) break;
+        const int row0 = m0 + (wm * RB + i) * 32;
+        const int cnt = min(32, p.m_end - row0);     // wave-uniform
+        if (cnt > 0) {
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            const int n = n0 + (wn * CB + j) * 32 + cl;
+            float s = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              s += (r < cnt) ? acc[i][j][reg] : 0.f;
+            }
+            s += __shfl_xor(s, 32);
+            const float mean = s / (float)cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              const float d = acc[i][j][reg] - mean;
+              q += (r < cnt) ? d * d : 0.f;
+            }
+            q += __shfl_xor(q, 32);
+            if (h == 0 && n < p.N) {
+              e.stat_sum[(int64_t)(row0 >> 5) * p.N + n] = s;
+              e.stat_m2[(int64_t)(row0 >> 5) * p.N + n] = q;
+            }
+          }
+        }
+      }
+    }
+    if (!C::MIX && e.stat_sum != nullptr) {          // BatchNorm slab statistics of the raw conv output
 #pragma unroll
       for (int sb = 0; sb < RB / 2; ++sb) {
         const int row0 = m0 + (wm * RB + sb * 2) * 32;
@@ -417,6 +460,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
+      if (C::MIX && i >= rbw) break;
 #pragma unroll
       for (int j = 0; j < CB; ++j)
 #pragma unroll
@@ -478,7 +522,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     // (8 times per tile with the loads inside the row loop: ~22 us per round of 256x256 tiles).  The K loop's
     // operand registers are dead here: 2 x NPS x 8 VGPRs hold the prefetched S16 groups.
     constexpr int NPS = 32 / ERPP8;
-    constexpr bool PRE = !SK && NPS <= 4 && RB % 2 == 0;      // (the stream-K instances have no registers to spare)
+    constexpr bool PRE = !SK && NPS <= 4 && RB % 2 == 0 && !C::MIX;      // (the stream-K instances have no registers to spare)
     f16x8 rh[PRE ? 2 * NPS : 1], rl[PRE ? 2 * NPS : 1];
     auto fetch_res = [&](int i0) {
 #pragma unroll
@@ -497,6 +541,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     };
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
+      if (C::MIX && i >= rbw) break;
       if constexpr (PRE) {
         if (i % 2 == 0 && e.R != nullptr) fetch_res(i);
       }
@@ -737,6 +782,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   }
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
+    if (C::MIX && i >= rbw) break;
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
@@ -1239,7 +1285,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   a.splits = splits;
   a.kt_per_split = (nkt + splits - 1) / splits;
   if (a.epi.act_scale != nullptr) {
-    if constexpr (C::BUF && !C::PIPE && C::BKE == 32) {          // (instantiated for the planner's configurations only)
+    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && !C::MIX) {          // (instantiated for the planner's configurations only)
       hipLaunchKernelGGL((k_nt_s16<C, true>), dim3(positions * splits), dim3(C::NT), 0, s, a);
       return check_launch("nt_s16(act)");
     } else {
@@ -1248,7 +1294,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
     }
   }
   if (a.epi.red) {
-    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && C::NT == 2 * C::BN) {
+    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && C::NT == 2 * C::BN && !C::MIX) {
       VP3D_REQUIRE(splits == 1 && a.epi.vec && a.N % C::BN == 0 && a.epi.ab_c % C::BN == 0 && a.m_begin == 0 && a.m_end == a.M,
                    "nt_s16: the fused BatchNorm-backward sums need one K slice, 16-byte aligned fp32 output and c_out, c_up "
                    "multiples of the %d-column tile", C::BN);
@@ -1378,7 +1424,17 @@ static int hybrid_split_rows(int M, int N) {
   return (int)((full_rounds * 256 / n256) * 256);
 }
 
-void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out) {
+// one K-tile of a 224-row tile against a 256-row one: tools/ubench/kloop.hip, 2.18 vs 2.44 us per K-tile and round
+static double cost_224(int64_t wgs, double nk) {
+  const int64_t per_cu = (wgs + 255) / 256;
+  const double fill = wgs < 256 ? (double)wgs / 256.0 : 1.0;
+  return (double)per_cu * (nk * 0.893 * (per_cu >= 2 ? 2.22 : 1.68 + 0.54 * fill) + 7.6);
+}
+
+// rows per BatchNorm statistics slab that configuration cfg writes
+int nt_s16_stat_slab_rows(int cfg) { return cfg == 28 ? 32 : 64; }
+
+void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out, int allow_mix) {
   const int nkt = K / 32;
   double best = 1e30;
   int best_cfg = 0, best_s = 1;
@@ -1417,6 +1473,15 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
       if (hybrid < best * 0.93) best_cfg = 30;
     }
   }
+  // Configuration 28 (224 x 256 tiles, one K slice): where the 256-row tiling leaves most of its last round idle
+  if (allow_mix && !raw && N % 256 == 0 && M >= 224 * 8) {
+    const int64_t tiles = (int64_t)((M + 223) / 224) * (N / 256);
+    const double cost = kLaunchUs + cost_224(tiles, (double)nkt);
+    if (cost < best * 0.97) {
+      best_cfg = 28;
+      best_s = 1;
+    }
+  }
   *cfg_out = best_cfg;
   *splits_out = best_s;
 }
@@ -1434,7 +1499,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
                "nt_s16: the split-fp16 GEMM needs channel counts %% 32 == 0 and 16-byte aligned S16 rows");
   if (cfg < 0) {
     int pc, ps;
-    plan_nt_s16(a.M, a.N, a.K, ws != nullptr, raw_partials ? 1 : 0, &pc, &ps);
+    plan_nt_s16(a.M, a.N, a.K, ws != nullptr, raw_partials ? 1 : 0, &pc, &ps, 0);
     cfg = pc;
     if (splits <= 0) splits = ps;
   }
@@ -1456,7 +1521,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   a.a_bytes = (uint32_t)a_bytes;
   a.b_bytes = (uint32_t)b_bytes;
 #ifndef VP3D_BUILD_EXPERIMENTS
-  VP3D_REQUIRE(cfg == 0 || cfg == 4 || cfg == 20 || cfg == 22,
+  VP3D_REQUIRE(cfg == 0 || cfg == 4 || cfg == 20 || cfg == 22 || cfg == 28,
                "nt_s16: tile configuration %d is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)", cfg);
   (void)tickets;
   if ((cfg == 20 || cfg == 22) && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31)))
@@ -1490,6 +1555,15 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     }
   }
 #endif  // VP3D_BUILD_EXPERIMENTS
+  if (cfg == 28) {
+    VP3D_REQUIRE(splits == 1 && !raw_partials && a.epi.act_scale == nullptr && !a.epi.red && a_bytes < ((int64_t)1 << 31) &&
+                     b_bytes < ((int64_t)1 << 31),
+                 "nt_s16: tile configuration 28 (224 x 256) takes one K slice, no fused activation / BatchNorm-backward sums and "
+                 "operands below 2 GiB");
+  }
+  VP3D_REQUIRE(a.epi.stat_sum == nullptr || splits > 1 || a.stat_slab_rows == nt_s16_stat_slab_rows(cfg),
+               "nt_s16: the statistics buffers were sized for %d-row slabs, tile configuration %d writes %d-row slabs",
+               a.stat_slab_rows, cfg, nt_s16_stat_slab_rows(cfg));
   int rc;
   switch (cfg) {
     // flat-address LDS-DMA (operands of any size)
@@ -1502,6 +1576,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     // buffer-descriptor LDS-DMA (operands < 2 GiB): what plan_nt_s16 picks
     case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break;
     case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break;
+    case 28: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1, 3>>(s, a, splits); break;  // 224x256: wave rows of 4 + 3 row blocks
 #ifdef VP3D_BUILD_EXPERIMENTS
     case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break;   // measured alternatives
     case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break;

@@ -98,6 +98,7 @@ struct RowsGemmArgs {
   // K-sliced tail (set by launch_rows_gemm from plan_rows_gemm): tile positions >= pos_full are cut into `splits`
   // slices whose raw partial tiles go to `part` ([split][tail position][128][128]); k_splitk_finish sums them
   int32_t pos_full, tail_pos, splits, kt_per_split;
+  int32_t stat_slab_rows = 64;   // rows per statistics slab the caller sized epi.stat_sum / stat_m2 for (S16 GEMM: vp3d_s16.stat_slab_rows)
   float* part;
   int64_t part_floats;
   uint32_t a_bytes, b_bytes;   // S16 kernel, buffer-descriptor DMA: byte extents of the two operands (set by the launcher)
@@ -136,7 +137,8 @@ int red_gemm_splits(int Mred, int Mo, int N);
 int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a, bool b_kcontig);
 int launch_red_gemm(hipStream_t s, const RedGemmArgs& a);
 // split-fp16 NT GEMM (vp3d_gemm_s16.hip); cfg selects the tile configuration
-void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out);
+void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out, int allow_mix = 0);
+int nt_s16_stat_slab_rows(int cfg);
 int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, float* ws, int64_t ws_floats,
                   bool raw_partials, int32_t* tickets = nullptr);
 void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets);

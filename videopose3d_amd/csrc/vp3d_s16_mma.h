@@ -19,22 +19,37 @@ constexpr int KQ = 32;   // K and channels-per-tap are multiples of this many el
 // With 16-element tiles a 4-deep ring fits twice in a CU's LDS (2 workgroups x 4 x 16 KiB for 128x128), keeping three
 // tiles in flight per workgroup: the MFMA time of a K-tile (768 pipe cycles for a 64x64 sub-tile) is far below the
 // LDS-DMA latency under load (~1.5 us), so the depth of the ring, not its width, is what feeds the matrix pipe.
-template <int WM_, int WN_, int RB_, int CB_, int NSTAGE_, int BKE_ = 32, int PIPE_ = 0, int BUF_ = 0>
+// RBL_: row blocks of the LAST wave row (default: RB_ like the others).  RBL_ < RB_ gives tile heights that are not multiples
+// of WM * 64 rows -- the 224 x 256 tile (Cfg<2, 4, 4, 2, 2, 32, 0, 1, 3>: wave row 0 owns rows 0..127, wave row 1 rows
+// 128..223): 27,648 rows are 124 x 4 = 496 such tiles = 1.94 rounds of 256 CUs where 432 tiles of 256 x 256 = 1.69 rounds cost
+// 2.  Wave w runs on SIMD w % 4 and WN == 4, so every SIMD hosts one wave of each row: the matrix pipes stay balanced.  Such a
+// configuration ("MIX") writes its BatchNorm statistics per 32-row slab (a 64-row slab would straddle two tiles).
+template <int WM_, int WN_, int RB_, int CB_, int NSTAGE_, int BKE_ = 32, int PIPE_ = 0, int BUF_ = 0, int RBL_ = RB_>
 struct Cfg {
-  static constexpr int WM = WM_, WN = WN_, RB = RB_, CB = CB_, NSTAGE = NSTAGE_, BKE = BKE_, PIPE = PIPE_, BUF = BUF_;
+  static constexpr int WM = WM_, WN = WN_, RB = RB_, CB = CB_, NSTAGE = NSTAGE_, BKE = BKE_, PIPE = PIPE_, BUF = BUF_, RBL = RBL_;
+  static constexpr bool MIX = RBL_ != RB_;
   static constexpr int NW = WM * WN, NT = NW * 64;
-  static constexpr int BM = WM * RB * 32, BN = WN * CB * 32;
+  static constexpr int BM = ((WM - 1) * RB + RBL) * 32, BN = WN * CB * 32;
+  static constexpr int SLAB = MIX ? 32 : 64;                 // rows per BatchNorm statistics slab of the epilogue
   static constexpr int ROWB = BKE * 4;                       // bytes per row per K-tile
   static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB LDS-DMA piece (8 or 16)
-  static constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;   // pieces per wave per K-tile
+  static constexpr int PA_ALL = BM / RPP;                    // A pieces per K-tile
+  static constexpr int PA = (PA_ALL + NW - 1) / NW, PB = BN / RPP / NW;   // (most) pieces per wave per K-tile
+  // A pieces of wave w: the first PA_BIG waves issue PA pieces each, the others PA - 1 (uniform configurations: all PA)
+  static constexpr int PA_BIG = PA_ALL - NW * (PA - 1);
+  __device__ static __forceinline__ int pa_count(int w) { return (!MIX || w < PA_BIG) ? PA : PA - 1; }
+  __device__ static __forceinline__ int pa_first(int w) { return (!MIX || w < PA_BIG) ? w * PA : PA_BIG * PA + (w - PA_BIG) * (PA - 1); }
+  // row blocks of wave row wm
+  __device__ static __forceinline__ int rb_of(int wm) { return (MIX && wm == WM - 1) ? RBL : RB; }
   static constexpr int A_B = BM * ROWB, B_B = BN * ROWB, STAGE_B = A_B + B_B;
   static constexpr int TAB_OFF = NSTAGE * STAGE_B;
   static constexpr int SMEM_B = TAB_OFF + 2 * BM * 4;
   static constexpr int OCC = (SMEM_B * 2 <= 160 * 1024 && NT * 2 <= 1024) ? 2 : 1;   // workgroups per CU aimed at
   static_assert(BKE == 16 || BKE == 32, "K-tile of 16 or 32 elements");
-  static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "DMA pieces must divide evenly over the waves");
+  static_assert(BM % RPP == 0 && (MIX || BM % (RPP * NW) == 0) && BN % (RPP * NW) == 0, "DMA pieces must divide evenly over the waves");
   static_assert(NW * 32 * CB * 32 * 4 <= NSTAGE * STAGE_B, "epilogue staging must fit in the operand ring");
-  static_assert(RB % 2 == 0, "64-row statistic slabs need an even number of 32-row blocks per wave");
+  static_assert(MIX || RB % 2 == 0, "64-row statistic slabs need an even number of 32-row blocks per wave");
+  static_assert(!MIX || (RBL < RB && RBL >= 1 && NSTAGE == 2 && !PIPE && BUF), "MIX: 2-stage buffer-descriptor ring only");
   // 16-B chunk c of tile row r sits at chunk position c ^ swz(r): conflict-free ds_read_b128 for both row widths
   __device__ static __forceinline__ int swz(int r) { return BKE == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 };

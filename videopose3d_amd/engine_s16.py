@@ -354,15 +354,20 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         t_cur = a.data.shape[1]
         m_rows = b * spec.t_out(t_cur)
         assert m_rows == m_all[idx]
-        stats = ops.stat_buffers(m_rows, spec.c_out, dev)
+        # 224 x 256 tiles (tile configuration 28) where the 256-row tiling strands most of its last round: their statistics
+        # come in 32-row slabs; not for the launches that carry a fused activation, nor under synchronised BatchNorm
+        mix = idx > 0 and sync is None
+        slab = S.stat_slab_rows(S.plan(m_rows, spec.c_out, spec.taps * spec.c_in, mix=True)[0]) if mix else 64
+        stats = ops.stat_buffers(m_rows, spec.c_out, dev, slab)
         # expand layer, fused: its GEMM (K = 128) is cheap enough to run twice -- pass 1 only produces the BatchNorm
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
         # the conv output never goes to HBM (its backward, expand_bwd, needs no y either)
         fused0 = idx == 0 and fuse_expand and n_layers > 1
         dedicated0 = (fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
                       m_rows * kpad * 4 < 2 ** 31)                                     # vp3d_expand_fwd_s16 (32-bit byte offsets)
-        y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr())
+        y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
+                                                                          stat_slab=slab)
+        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr(), slab_rows=slab)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:
@@ -609,7 +614,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
                 assert rs.step == 1 and r.shape[0] == bb and r.shape[2] == c_in
                 e = ops._epi(residual=(r, 1, -rs.start, 0), n_cols=c_in)
             S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, c_in, dx, t_i * c_in, c_in, epi=e, amax_out=amax_out,
-                        family="tconv_dgrad", red=red_for(up, bb * t_i, c_in, taps * c_out, dy))
+                        family="tconv_dgrad", red=red_for(up, bb * t_i, c_in, taps * c_out, dy), mix=True)
             return dx
         assert spec.stride == taps and (spec.dil == 1 or taps == 1) and taps * t_o <= t_i      # (a 1-tap conv has no dilation to speak of)
         dx = (torch.empty if taps * t_o == t_i else torch.zeros)((bb, t_i, c_in), dtype=torch.float32, device=dev)
@@ -620,7 +625,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             assert rs.step == taps and r.shape == (bb, t_o, c_in)
             e = ops._epi(residual=(r, 1, 0, rs.start * c_in), n_cols=taps * c_in)
         S.gemm_rows(dy, L[idx].wd, rm, c_out, c_out, taps * c_in, dx, t_i * c_in, taps * c_in, epi=e, amax_out=amax_out,
-                    family="tconv_dgrad", red=red_for(up, bb * t_o, taps * c_in, c_out, dy))
+                    family="tconv_dgrad", red=red_for(up, bb * t_o, taps * c_in, c_out, dy), mix=True)
         return dx
 
     # the trailing small-M blocks: one persistent launch (S.tail_bwd) instead of ~10 launches per block on two streams

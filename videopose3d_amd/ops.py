@@ -113,8 +113,10 @@ def _epi(bias=None, relu=False, residual=None, stats=None, n_cols=0) -> Optional
     return e
 
 
-def stat_buffers(m_rows: int, c: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    slabs = (m_rows + 63) // 64
+def stat_buffers(m_rows: int, c: int, device, slab_rows: int = 64) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(sum, M2) partial rows of the GEMM epilogue's BatchNorm statistics: one row per slab of slab_rows rows (64; 32 for the
+    split-fp16 GEMM's 224-row tiling, ops_s16.stat_slab_rows)."""
+    slabs = (m_rows + slab_rows - 1) // slab_rows
     buf = torch.empty((2, slabs, c), dtype=torch.float32, device=device)
     return buf[0], buf[1]
 
@@ -428,11 +430,14 @@ def _bn_finalize_sync(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync) -> tor
     return buf
 
 
-def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None, momentum_dev: Optional[int] = None) -> torch.Tensor:
+def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None, momentum_dev: Optional[int] = None,
+                slab_rows: int = 64) -> torch.Tensor:
     """Returns a [4, C] tensor: scale, shift, mean, invstd.  Updates the running buffers in place.
     sync: a dp.SyncBatchNorm -> statistics over the global batch.  momentum_dev: device address of a float the kernel reads
-    the momentum from at execution time (hipGraph replays follow set_bn_momentum), instead of bn.momentum as an argument."""
+    the momentum from at execution time (hipGraph replays follow set_bn_momentum), instead of bn.momentum as an argument.
+    slab_rows: rows per statistics slab of `stats` (stat_buffers)."""
     if sync is not None:
+        assert slab_rows == 64, "synchronised BatchNorm merges 64-row slabs"
         return _bn_finalize_sync(bn, m_rows, stats, sync)
     c = bn.num_features
     if m_rows <= 1:
@@ -447,6 +452,11 @@ def bn_finalize(bn: torch.nn.BatchNorm1d, m_rows: int, stats, sync=None, momentu
             bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
             buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr())
     head = (_stream(), c, m_rows, stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps))
+    if slab_rows != 64:
+        use_dev = momentum_dev is not None and track and bn.momentum is not None
+        check(_lib.lib().vp3d_bn_finalize_slab(head[0], c, m_rows, slab_rows, *head[3:], 0.0 if use_dev else momentum,
+                                               momentum_dev if use_dev else None, *tail), "vp3d_bn_finalize_slab")
+        return buf
     if momentum_dev is not None and track and bn.momentum is not None:
         check(_lib.lib().vp3d_bn_finalize_dm(*head, momentum_dev, *tail), "vp3d_bn_finalize_dm")
     else:

@@ -67,19 +67,36 @@ def split(t: torch.Tensor, bound: Optional[torch.Tensor] = None, measure: bool =
     return S16(out, bound)
 
 
-def plan(m: int, n: int, k: int, raw: bool = False) -> Tuple[int, int]:
-    cfg, splits = C.c_int32(0), C.c_int32(1)
-    check(_lib.lib().vp3d_nt_s16_plan(m, n, k, 1 if raw else 0, C.byref(cfg), C.byref(splits)), "vp3d_nt_s16_plan")
-    return cfg.value, splits.value
+_plan_cache = {}
+# VP3D_TILE_224=0: the planner never picks the 224 x 256 tiling (read per call: tools/env_ab.py interleaves both)
 
 
-def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=False):
+def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False) -> Tuple[int, int]:
+    """(tile configuration, K slices) of an [m, n, k] split-fp16 GEMM.  mix: configuration 28 (224 x 256 tiles: statistics in
+    32-row slabs, no fused activation / BatchNorm-backward sums) may be chosen."""
+    mix = bool(mix and os.environ.get("VP3D_TILE_224", "1") != "0")
+    key = (m, n, k, raw, mix)
+    hit = _plan_cache.get(key)
+    if hit is None:
+        cfg, splits = C.c_int32(0), C.c_int32(1)
+        check(_lib.lib().vp3d_nt_s16_plan(m, n, k, (1 if raw else 0) | (2 if mix else 0), C.byref(cfg), C.byref(splits)),
+              "vp3d_nt_s16_plan")
+        hit = _plan_cache[key] = (cfg.value, splits.value)
+    return hit
+
+
+def stat_slab_rows(cfg: int) -> int:
+    """Rows per BatchNorm statistics slab that tile configuration cfg writes (64; 32 for the 224-row tiling)."""
+    return 32 if cfg == 28 else 64
+
+
+def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=False, mix=False):
     o = S16Opts()
     o.x_bound = x.bound_ptr()
     o.w_bound = w.bound_ptr()
     o.amax_out = None if amax_out is None else amax_out.data_ptr()
     if cfg < 0 or splits <= 0:
-        pc, ps = plan(m, n, k, raw)
+        pc, ps = plan(m, n, k, raw, mix)
         cfg = pc if cfg < 0 else cfg
         splits = ps if splits <= 0 else splits
     o.cfg, o.splits = cfg, splits
@@ -100,12 +117,14 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
 
 def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=None, stats=None, amax_out=None,
             cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None, s16_out=None, no_output: bool = False,
-            act=None):
+            act=None, mix: bool = False, stat_slab: int = 64):
     """y = conv(x) with the fused epilogue of ops.conv_fwd; x [B,T_in,C_in] and wt [C_out, taps*C_in] in S16.
 
     residual = (tensor, ResSpec): fp32 tensor or S16 (decoded with its own bound).
     s16_out = None: y is fp32 (returned).  s16_out = (in_amax, l1, res_amax or None): y is written as S16 whose bound
     l1[0]*max(in_amax) + l1[1] + max(res_amax) is evaluated on the device; returns S16(y, that bound).
+    mix: the planner may pick the 224 x 256 tiling (configuration 28); stat_slab: slab size `stats` was sized for
+    (plan(..., mix=True) + stat_slab_rows(cfg) tell before the buffers are made; a mismatch is refused by the library).
     no_output: only the BatchNorm slab statistics (`stats`) are produced (returns None).
     act = (coef, drop, out_bound, act_bits or None): fused BatchNorm + ReLU + dropout epilogue -- returns the S16 rows of
     dropout(relu(y*coef[0] + coef[1])) under out_bound (and fills act_bits) without ever storing y."""
@@ -138,7 +157,8 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
     m, k = b * t_out, spec.taps * c_in
     if s16_out is not None or res_s16 is not None or no_output or act is not None:
         splits = 1
-    o, ws = _opts(x, wt, m, spec.c_out, k, xd.device, amax_out, cfg, splits)
+    o, ws = _opts(x, wt, m, spec.c_out, k, xd.device, amax_out, cfg, splits, mix=mix and act is None)
+    o.stat_slab_rows = stat_slab
     keep = None
     if no_output:
         o.no_output = 1
@@ -236,12 +256,12 @@ def make_red(y_up: torch.Tensor, coef: torch.Tensor, act_bits: torch.Tensor, p: 
 
 
 def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: torch.Tensor, y_bpitch: int, ldy: int,
-              *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0, red=None):
+              *, epi=None, amax_out=None, family="tconv_fwd", cfg: int = -1, splits: int = 0, red=None, mix: bool = False):
     """Raw form of conv_nt: out[b*y_bpitch + t*ldy + n] = sum_k x[gather] * wt[n][k] (+ epilogue).  red: a make_red()
     struct -- the launch also reduces the BatchNorm backward of the activation whose gradient it writes."""
     xd, wd = x.data, wt.data
     m, k = rm.batch * rm.t_dst, rm.taps * c_in
-    o, ws = _opts(x, wt, m, n, k, xd.device, amax_out, cfg, splits)
+    o, ws = _opts(x, wt, m, n, k, xd.device, amax_out, cfg, splits, mix=mix and red is None)
     if red is not None:
         o.red = C.addressof(red)
     ops._timed_call(family, 2.0 * m * n * k, _lib.lib().vp3d_tconv_nt_s16,
