@@ -60,19 +60,19 @@ def mpjpe(pred, target):                                                        
     return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))
 
 
-PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r03f32_pmc_traffic.json"),
-            "f16x3": os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")}
+PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r04f32_pmc_traffic.json"),
+            "f16x3": os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")}
 FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"},
                   # one kernel serves all three GEMM forms of the split-fp16 path (all are "NT")
                   "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
-STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r03_step_table.json"),
-                   "f32": os.path.join(ROOT, "profiles", "r03f32_step_table.json")}
+STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r04_step_table.json"),
+                   "f32": os.path.join(ROOT, "profiles", "r04f32_step_table.json")}
 
 
 def pmc_traffic(family, math):
-    """Per-launch table first (profiles/r03_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
+    """Per-launch table first (profiles/r04_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
     WRITE_SIZE): the family's traffic is the mean over ITS launches, comparable with `algorithmic_bytes`; else the
     per-kernel-template means of the older profile."""
     path = STEP_TABLE_JSON.get(math)
@@ -90,8 +90,10 @@ def pmc_traffic(family, math):
     return _pmc_traffic_templates(family, math)
 
 
-def pmc_traffic_of_cfg(cfg, math):
-    """The same per-launch table, the launches served by one kernel (tile configuration `cfg`)."""
+def pmc_traffic_of_cfg(cfg, math, live=None):
+    """The same per-launch table, the launches served by one kernel (tile configuration `cfg`).  live: this run's launches of
+    that kernel as (M, N, K, k_slices) -- the committed table is only quoted when it holds EXACTLY those launches (a planner or
+    kernel change since the profile was collected would otherwise put another kernel's bytes beside this run's time)."""
     path = STEP_TABLE_JSON.get(math)
     try:
         with open(path) as f:
@@ -99,16 +101,23 @@ def pmc_traffic_of_cfg(cfg, math):
     except (OSError, ValueError, KeyError, TypeError):
         return None, None
     if not rows:
-        return None, None
+        return None, ("the committed per-launch table %s has no launches of tile configuration %s: collected before this "
+                      "kernel served them (tools/profile_round.sh re-collects)" % (os.path.relpath(path, ROOT), cfg))
+    if live is not None:
+        have = sorted((r["M"], r["N"], r["K"], r["k_slices"]) for r in rows)
+        if have != sorted(live):
+            return None, ("the committed per-launch table %s is stale for tile configuration %s: it holds launches %s, this run "
+                          "issued %s (tools/profile_round.sh re-collects)" % (os.path.relpath(path, ROOT), cfg, have, sorted(live)))
     return (sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows),
             "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included), mean over the %d launches of "
-            "this kernel in one step, %s (algorithmic mean of the same launches: %.1f MB)"
+            "this kernel in one step, %s (algorithmic mean of the same launches: %.1f MB; the table's launch list was checked "
+            "against this run's)"
             % (len(rows), os.path.relpath(path, ROOT), sum(r["algorithmic_bytes"] for r in rows) / len(rows) / 1e6))
 
 
 def _pmc_traffic_templates(family, math):
     """HBM-side bytes per launch of a GEMM family from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r03*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
+    (profiles/r04*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the
     gfx950 correction of MI355X_MICROARCH.md; tools/pmc_traffic.py).  PMC counters cannot be read from inside the
     timed process, so the value is the committed measurement, averaged over the family's launches like `achieved`."""
     path = PMC_JSON[math]
@@ -376,6 +385,8 @@ def instrumented(step, ops, n_prof, math):
         # The DOMINANT KERNEL of the step: the launches grouped by the kernel that served them (tile configuration), not by
         # GEMM form -- one template serves forward and dgrad launches alike
         names = {22: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>> (256x256 tile, 8 waves of 128x64; forward + dgrad launches)",
+                 28: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>> (224x256 tile, 8 waves: wave rows of 4 + 3 row blocks; the forward and "
+                     "plain-dgrad launches of the 27,648-row layers: 496 / 1488 tiles = 1.94 / 5.81 rounds of 256 CUs)",
                  20: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>> (128x128 tile, 4 waves, 2 workgroups per CU)",
                  1022: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>, RED> (256x256 tile dgrad + the BatchNorm-backward column sums of the "
                        "upstream activation: reads that activation's conv output and bits in the epilogue, vp3d_s16_red)",
@@ -397,9 +408,9 @@ def instrumented(step, ops, n_prof, math):
         kdom = max(grp, key=lambda k: grp[k]["us"])
         kname = str(names.get(kdom, kdom))
         alg = grp[kdom]["flops"] / grp[kdom]["us"]
-        kt = pmc_traffic_of_cfg(kdom, math)
-        if kt[0] is not None:
-            traffic, traffic_note = kt
+        live = [(r["M"], r["N"], r["K"], r["k_slices"]) for r in per_launch if r.get("cfg") == kdom
+                for _ in range(int(round(r["calls_per_step"])))]
+        traffic, traffic_note = pmc_traffic_of_cfg(kdom, math, live)          # None + the reason when the table is stale
         kernels[dom] = dict(kernels[dom])
         dom_launch = dict(calls_per_step=grp[kdom]["n"], avg_launch_ms=grp[kdom]["us"] / grp[kdom]["n"] / 1e3,
                           algorithmic_bytes_per_launch=grp[kdom]["mb"] / grp[kdom]["n"] * 1e6)
@@ -429,7 +440,7 @@ def instrumented(step, ops, n_prof, math):
     roof.update(extra)
     if by_kernel is not None:
         roof["by_kernel"] = by_kernel            # every GEMM kernel of the step: time, algorithmic TFLOP/s, fraction of the roofline
-    roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r03_step_table.txt shows
+    roof["per_launch"] = per_launch          # one row per distinct GEMM launch of the step (what profiles/r04_step_table.txt shows
     roof["streaming"] = streaming[:6]        # from rocprofv3); the two big HBM-bound producers against the achievable HBM rate
     return roof, kernels
 
@@ -532,6 +543,9 @@ def relaunch_under_torchrun(n_gpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks of one node
     env.setdefault("OMP_NUM_THREADS", "1")                  # N python ranks share the host's cores: no oneDNN/OpenMP pools
+    from videopose3d_amd import dp
+    for k, v in dp.RCCL_ENV_DEFAULTS.items():               # RCCL's channel budget beside the backward GEMMs (dp.py; also set by
+        env.setdefault(k, v)                                # dp.init_from_env under an external launcher: the driver's torchrun)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -542,8 +556,14 @@ def dry_run(args):
     the barrier / max-over-ranks timing contract): rendezvous (gloo), W + K empty steps between barriers, rank 0 prints
     the JSON skeleton with value null."""
     from videopose3d_amd import dp
-    rank, world, _ = dp.init_from_env("gloo")
+    rank, world, local = dp.init_from_env("gloo")
     assert world == args.gpus, (world, args.gpus)
+    cores = dp.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if world > 1:
+        allc = [None] * world
+        dist.all_gather_object(allc, cores)
+    else:
+        allc = [cores]
     for _ in range(args.warmup):
         pass
     if world > 1:
@@ -564,7 +584,9 @@ def dry_run(args):
         print(json.dumps({"metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
-                          "barrier_to_barrier_s": dt}), flush=True)
+                          "barrier_to_barrier_s": dt,
+                          "launcher": {"rccl_env": {k: os.environ.get(k) for k in dp.RCCL_ENV_DEFAULTS} if world > 1 else None,
+                                       "cores_per_rank": allc}}), flush=True)
 
 
 def main():
@@ -594,6 +616,7 @@ def main():
     rank, world, local = dp.init_from_env(os.environ.get("VP3D_DIST_BACKEND", "nccl"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch one rank per GPU" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    pinned = dp.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     local = int(os.environ.get("VP3D_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -728,6 +751,23 @@ def main():
             del gstep
         except Exception as e:  # noqa: BLE001  (informational: never lets the headline line fail)
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # N > 1: the host side counts (N Python ranks enqueue ~2 ms of launches per 4.4 ms step each on the node's cores): both forms of
+    # the SAME step were timed above -- eager and hipGraph pieces -- and `value` is the faster one; `value_path` says which, the
+    # other stays in `eager` / `graph_replay`.  One GPU: `value` is always the eager module call (the drop-in for run.py).
+    out["value_path"] = "eager"
+    out["launcher"] = {"rccl_env": {k: os.environ.get(k) for k in dp.RCCL_ENV_DEFAULTS} if world > 1 else None,
+                       "cores_of_rank0": pinned}
+    gr = out.get("graph_replay", {})
+    if world > 1 and gr.get("ms_per_step") and gr["ms_per_step"] < ms_per_step:
+        out["eager"] = {"value": value, "ms_per_step": ms_per_step}
+        out["value_path"] = "graph_replay"
+        value, ms_per_step = gr["frames_per_s"], gr["ms_per_step"]
+        out["value"], out["ms_per_step"] = value, ms_per_step
+        out["step_tflops"] = FLOP_TRAIN_PER_FRAME * value / 1e12
+        out["step_frac_of_fp32_mfma_peak"] = out["step_tflops"] / (PEAK_F32_MFMA_TFLOPS * world)
+        out["step_frac_of_roofline"] = out["step_tflops"] / world / (PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3 if math == "f16x3"
+                                                                     else PEAK_F32_MFMA_TFLOPS)
 
     # Everything below that runs training steps is executed by EVERY rank: a step contains collectives (the bucketed
     # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.

@@ -27,11 +27,17 @@ def test_bench_gpus2_launches_itself_dry_run():
     out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry_run"] is True
     assert out["metric"].startswith("frames/sec") and out["scaling"] == "weak"
+    # the launcher's environment: RCCL's channel budget (dp.RCCL_ENV_DEFAULTS: measured with tools/cu_hog_ab.py) and one slice
+    # of the host's cores per rank (disjoint when there are at least two cores)
+    assert out["launcher"]["rccl_env"] == {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "4"}
+    c0, c1 = out["launcher"]["cores_per_rank"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert c0 and c1 and not set(c0) & set(c1)
 
 
 def test_bench_single_process_dry_run():
     out = _run(["--steps", "2", "--warmup", "0", "--dry-run"])
-    assert out["n_gpus"] == 1
+    assert out["n_gpus"] == 1 and out["launcher"]["rccl_env"] is None
 
 
 @pytest.mark.gpu
@@ -44,3 +50,6 @@ def test_bench_gpus2_self_launch_real_step_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["config"]["grad_allreduce_bytes"] > 6e7
     assert out["roofline"]["frac"] > 0
+    assert out["value_path"] in ("eager", "graph_replay") and out["launcher"]["rccl_env"]["NCCL_MAX_NCHANNELS"] == "8"
+    if out["value_path"] == "graph_replay":
+        assert out["eager"]["ms_per_step"] >= out["ms_per_step"]

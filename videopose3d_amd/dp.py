@@ -18,9 +18,42 @@ import torch
 import torch.distributed as dist
 
 
+# RCCL channel budget of the overlapped bucket all-reduce.  Every RCCL channel is one workgroup that stays RESIDENT on a CU for
+# the whole collective, and the 256 x 256 / 224 x 256 GEMM workgroups of the backward need a CU's entire register file: a CU
+# that hosts a channel is lost to them, and kernels laid out for exactly 256 CUs (the expand layer's persistent kernels, whole
+# rounds of tiles) pay a whole extra round.  Measured on one MI355X with N resident stand-in workgroups on a third queue
+# (tools/cu_hog_ab.py, profiles/r04_cu_hog_interference.txt): 8 -> +14.5 % step time while they are resident, 16 -> +36 %,
+# 32 -> +133 %.  Eight channels move a 17 MB bucket in ~0.15 ms (ring over xGMI, ~30 GB/s per channel workgroup), i.e. the four
+# buckets are resident for ~0.6 ms of the 2.6 ms backward: ~+0.09 ms per step, against ~0.45 ms for an exchange that is not
+# overlapped at all and ~+0.3 ms for RCCL's default of 32+ channels.  The user's own NCCL_* settings win (setdefault).
+RCCL_ENV_DEFAULTS = {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "4"}
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int):
+    """Give every rank of a node its own slice of the cores this process may run on (the step's host side is one Python
+    thread enqueueing ~2 ms of launches per 4.4 ms step: N unpinned ranks migrate over each other's cores and caches).
+    Returns the sorted core list the rank is pinned to, or None when there is nothing to split (fewer cores than ranks, no
+    sched_setaffinity)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if local_world <= 1 or len(cores) < local_world:
+        return None
+    per = len(cores) // local_world
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(per, 4)))
+    return mine
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank).  A single process without those variables is world 1 (no group)."""
+    Returns (rank, world, local_rank).  A single process without those variables is world 1 (no group).  For world > 1 the
+    RCCL channel budget (RCCL_ENV_DEFAULTS) is put into the environment before the communicator is created."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,6 +61,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in RCCL_ENV_DEFAULTS.items():
+            os.environ.setdefault(k, v)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
