@@ -1,7 +1,7 @@
 """GPU tests of the BatchNorm-backward column sums fused into the dgrad launches of the split-fp16 training backward
 (vp3d_s16_red, csrc/vp3d_gemm_s16.hip k_nt_s16<.., RED>; autograd of reference common/model.py:134 / :193
 drop(relu(bn(conv(x))))) against the separate reduction pass it replaces (VP3D_FUSE_BN_RED=0) and against the oracle.  The
-model-level parity suite runs through the fused launches wherever engine_s16 selects them (activations of >= 8192 rows)."""
+model-level parity suite runs through the fused launches wherever engine_s16 selects them (activations of >= 16,384 rows)."""
 import numpy as np
 import pytest
 import torch

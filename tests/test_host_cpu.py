@@ -469,7 +469,7 @@ def test_fused_bn_backward_sums_selection_rules():
     assert not S.red_supported(1024, 1024, 1024, 1024)         # the planner slices K: the finishing pass owns the epilogue
     assert not S.red_supported(27648, 1024, 1024, 128)         # strips are 256 channels wide
     assert not S.red_supported(27648, 1000, 1024, 1000)
-    assert engine_s16.FUSE_BN_RED_DEFAULT == "auto" and engine_s16.FUSE_BN_RED_MIN_ROWS == 8192
+    assert engine_s16.FUSE_BN_RED_DEFAULT == "auto" and engine_s16.FUSE_BN_RED_MIN_ROWS == 16384
 
 
 def test_persistent_tail_selection_rules(monkeypatch):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of the benchmark training step under an environment knob that the package / the HIP library reads at call
-time:   python tools/env_ab.py VP3D_SOME_KNOB 0 1 [reps] [steps]      (interleaved runs: box-to-box spread does not enter)."""
+time:   python tools/env_ab.py VP3D_SOME_KNOB 0 1 [reps] [steps]      (interleaved runs: box-to-box spread does not enter);
+more than two values: python tools/env_ab.py VP3D_SOME_KNOB 0,1,2,3 - [reps] [steps]."""
 import os
 import sys
 import time
@@ -11,7 +12,7 @@ import torch  # noqa: E402
 import videopose3d_amd as V  # noqa: E402
 from videopose3d_amd import dp, loss as vloss  # noqa: E402
 
-var, values = sys.argv[1], sys.argv[2:4]
+var, values = sys.argv[1], (sys.argv[2].split(",") if sys.argv[3] == "-" else sys.argv[2:4])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 25
 dev = "cuda:0"
@@ -39,10 +40,16 @@ def timed(n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+import random  # noqa: E402
+random.seed(int(os.environ.get("ENV_AB_SEED", "0")))
 res = {v: [] for v in values}
 for rep in range(reps):
-    for v in values:
+    order = list(values)
+    if len(order) > 2:
+        random.shuffle(order)                        # (no value always runs behind the same neighbour)
+    for v in order:
         os.environ[var] = v
         res[v].append(timed(steps))
 for v in values:
-    print("%s=%s: %s  -> min %.3f ms / step" % (var, v, " ".join("%.3f" % t for t in res[v]), min(res[v])), flush=True)
+    print("%s=%s: %s  -> min %.3f median %.3f ms / step" % (var, v, " ".join("%.3f" % t for t in res[v]), min(res[v]),
+                                                           sorted(res[v])[len(res[v]) // 2]), flush=True)

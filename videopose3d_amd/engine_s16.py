@@ -181,10 +181,13 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
 
 # BatchNorm-backward column sums inside the dgrad launch that writes the activation's incoming gradient (vp3d_s16_red):
 # VP3D_FUSE_BN_RED=0 never, =1 wherever the launch supports it, default: where it pays -- activations of at least
-# FUSE_BN_RED_MIN_ROWS rows (below that the fused launch's finalize chain, ~14 us of dependent memory round trips at its tail,
-# costs what the 17-30 us reduction pass it replaces does: tools/red_bench.py)
+# FUSE_BN_RED_MIN_ROWS rows.  Round 4, interleaved in RANDOMISED order on one box (tools/red_ab.py, profiles/r04_bn_red_ab.txt):
+# never 4.364 ms, >= 16,384 rows 4.291, >= 8,192 rows 4.301, >= 4,096 rows 4.302, everywhere 4.304 -- the 27,648-row activation
+# pays (-1.7 %), the 9,216-row ones cost 10 us more inside their dgrad launch than their reduction pass did beside the
+# second stream's weight-gradient GEMM, and below that the fused launch's hand-over (~14 us of dependent memory round trips at
+# its tail) costs what the 17-30 us pass it replaces does (tools/red_bench.py)
 FUSE_BN_RED_DEFAULT = "auto"
-FUSE_BN_RED_MIN_ROWS = 8192
+FUSE_BN_RED_MIN_ROWS = 16384
 TAIL_MAX_ROWS = int(os.environ.get("VP3D_TAIL_MAX_ROWS", "3072"))     # B * T_out up to which a block runs in the persistent tail
 
 

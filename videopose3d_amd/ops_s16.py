@@ -74,7 +74,8 @@ _plan_cache = {}
 def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False) -> Tuple[int, int]:
     """(tile configuration, K slices) of an [m, n, k] split-fp16 GEMM.  mix: configuration 28 (224 x 256 tiles: statistics in
     32-row slabs, no fused activation / BatchNorm-backward sums) may be chosen."""
-    mix = bool(mix and os.environ.get("VP3D_TILE_224", "1") != "0")
+    mode = os.environ.get("VP3D_TILE_224", "1")       # (2 / 3: only launches of at most / more than 16,384 rows -- A/B runs)
+    mix = bool(mix and mode != "0" and not (mode == "2" and m > 16384) and not (mode == "3" and m <= 16384))
     key = (m, n, k, raw, mix)
     hit = _plan_cache.get(key)
     if hit is None:
