@@ -512,7 +512,7 @@ def test_gather_transposed_operand_vs_torch():
 
 
 @pytest.mark.parametrize("kc", [(128, 256), (96, 64), (64, 1024)])
-@pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1), (0.25, 26)])
+@pytest.mark.parametrize("p_drop,cfg", [(0.0, 20), (0.25, 22), (0.25, -1), (0.25, 26), (0.1, -1), (0.5, -1)])
 def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg, kc):
     """The expand layer's fused forward: pass 1 (no_output) writes only the BatchNorm slab statistics, pass 2 applies
     BatchNorm + ReLU + dropout in the GEMM epilogue and writes S16 rows + activation bits -- bit for bit what
@@ -551,7 +551,8 @@ def test_fused_conv_bn_relu_dropout_epilogue_equals_unfused(p_drop, cfg, kc):
     assert torch.equal(a_d.data.view(torch.int32), a_ref.data.view(torch.int32))
     assert torch.equal(bits_d, bits_ref)
     if p_drop > 0:
-        assert 0.6 < float((S.join(a_f) != 0).float().mean() / (S.join(S.bn_act_fwd(y, coef, None, None, bound)[0]) != 0).float().mean()) < 0.9
+        kept = float((S.join(a_f) != 0).float().mean() / (S.join(S.bn_act_fwd(y, coef, None, None, bound)[0]) != 0).float().mean())
+        assert abs(kept - (1.0 - p_drop)) < 0.03, kept
 
 
 @pytest.mark.parametrize("cfg", [120, 122])
@@ -892,3 +893,25 @@ def test_tile_224_planned_for_the_benchmark_rows_and_finalize_agrees():
     assert float((coefs[0] - coefs[1]).abs().max() / coefs[0].abs().max()) < 1e-6
     assert torch.allclose(stats_run[0][0], stats_run[1][0], rtol=1e-5, atol=1e-7)
     assert torch.allclose(stats_run[0][1], stats_run[1][1], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("p_drop", [0.25, 0.5, 0.75, 0.1])
+def test_dropout_mask_two_bit_mode_statistics(p_drop):
+    """p = 0.25 / 0.5 / 0.75: 2 random bits per element decide exactly and ONE Philox block serves 64 elements (vp3d_dropout.h
+    "two" mode; the expand layer's kernel shares the block across its lanes); any other p keeps 16 bits per element.  Either way:
+    the keep rate, no correlation between neighbours inside a block (the 2-bit fields of one word), none between the 8-element
+    groups of a block, none between blocks, and another (seed, offset, layer) gives another mask."""
+    n = 1 << 22
+    d = ops.make_dropout(p_drop, 4321, 5, 2)
+    mk = (ops.dropout_mask(n, d, DEV) > 0).float()
+    keep = 1.0 - p_drop
+    assert abs(float(mk.mean()) - keep) < 2e-3
+    var = keep * (1 - keep)
+    for lag in (1, 2, 7, 8, 9, 63, 64, 65, 4096):
+        cov = float((mk[:-lag] * mk[lag:]).mean()) - keep * keep
+        assert abs(cov) < 4e-3 * var / 0.1875 + 1e-3, (lag, cov)
+    per_pos = mk.view(-1, 64).mean(dim=0)                 # every position of a 64-element block keeps at the same rate
+    assert float((per_pos - keep).abs().max()) < 8e-3
+    other = (ops.dropout_mask(n, ops.make_dropout(p_drop, 4321, 6, 2), DEV) > 0).float()
+    assert abs(float((mk * other).mean()) - keep * keep) < 2e-3
+    assert float(ops.dropout_mask(n, d, DEV).max()) == pytest.approx(1.0 / keep, rel=1e-6)

@@ -231,6 +231,20 @@ __global__ void __launch_bounds__(EX_NT, 3) k_expand_fwd_s16(const ExpandArgs p)
       }
     } else {
       // ---- BatchNorm + ReLU + dropout -> S16 rows + activation bits, one 32-row block at a time through the wave's region --
+      // "two" mode of the mask (vp3d_dropout.h: 2 random bits per element, one Philox block per 64 elements): the wave's 32
+      // columns are half of ONE block per row, so lane L evaluates the block of tile row L once per tile and keeps the two words
+      // of this wave's half; the four passes below fetch their 16 bits with shuffles -- 1 Philox evaluation per lane and tile
+      // instead of 4 (the pass is VALU-bound and the block's 20 multiplies were ~40 % of it)
+      uint32_t pw0 = 0u, pw1 = 0u;
+      const bool shared_mask = d.on && d.two && (p.N & 63) == 0;
+      if (shared_mask) {
+        const uint64_t q64 = (uint64_t)(row0 + lane) * (uint64_t)(p.N >> 6) + (uint64_t)((n8 - q4 * 8) >> 6);
+        uint32_t r4[4];
+        philox4((uint32_t)q64, (uint32_t)(q64 >> 32), d.layer, d.off_lo, d.k0, d.k1, r4);
+        const bool upper = (((n8 - q4 * 8) >> 5) & 1) != 0;          // this wave's strip = columns 32..63 of the 64-column block
+        pw0 = upper ? r4[2] : r4[0];
+        pw1 = upper ? r4[3] : r4[1];
+      }
 #pragma unroll 1
       for (int blk = 0; blk < 2; ++blk) {
         compute(blk);
@@ -244,13 +258,18 @@ __global__ void __launch_bounds__(EX_NT, 3) k_expand_fwd_s16(const ExpandArgs p)
         for (int ps = 0; ps < 2; ++ps) {
           const int r = ps * 16 + rsub;
           const int m = row0 + blk * 32 + r;
+          // (before the row predicate: every lane takes part in the shuffles)
+          const uint32_t sw0 = __shfl(pw0, blk * 32 + r), sw1 = __shfl(pw1, blk * 32 + r);
           if (m >= p.M || n8 >= p.N) continue;
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(wreg + r * EX_EPI_PITCH + q4 * 8);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(wreg + r * EX_EPI_PITCH + q4 * 8 + 4);
           const float y8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           const int64_t e0 = (int64_t)m * p.N + n8;   // element index in the [M][N] activation (the mask's counter)
           float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-          if (d.on) {
+          if (shared_mask) {
+            const uint32_t wsel = (q4 & 2) ? sw1 : sw0;
+            drop8_from_bits16(d, (q4 & 1) ? (wsel >> 16) : (wsel & 0xffffu), mk);
+          } else if (d.on) {
             drop8(d, (uint64_t)(e0 >> 3), mk);
           }
           float v[8];
