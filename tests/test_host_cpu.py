@@ -498,3 +498,58 @@ def test_persistent_tail_selection_rules(monkeypatch):
     assert engine_s16.tail_from(d, d._plan, 27, 16, None, True) == 0                       # dilated class: windows do not tile
     n = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=96)
     assert engine_s16.tail_from(n, n._plan, 27, 16, None, True) == 0                       # C % 64 != 0
+
+
+def test_build_is_gated_by_a_content_hash_not_by_mtimes(tmp_path, monkeypatch):
+    """__graft_entry__.build() compiles unless libvp3d.so was built from EXACTLY the sources in the tree: the stamp holds a sha256
+    of every source / header + the flags (a fresh clone has no stamp -> compiles; touching a file without changing it does not)."""
+    import importlib
+    g = importlib.import_module("__graft_entry__")
+    assert os.path.exists(g.LIB) and not g._stale(), "the shipped library must match the tree's sources"
+    h0 = g._source_hash()
+    src = os.path.join(g.CSRC, g.SOURCES[0])
+    os.utime(src, None)                                  # newer mtime, same content
+    assert g._source_hash() == h0 and not g._stale()
+    monkeypatch.setattr(g, "STAMP", str(tmp_path / "missing.srchash"))
+    assert g._stale()                                    # no stamp: a library of unknown origin is rebuilt
+    stamp = tmp_path / "other.srchash"
+    stamp.write_text("0" * 64 + "\n")
+    monkeypatch.setattr(g, "STAMP", str(stamp))
+    assert g._stale()                                    # built from other sources
+    monkeypatch.setattr(g, "FLAGS", g.FLAGS + ["-DSOMETHING"])
+    assert g._source_hash() != h0                        # the flags are part of the identity
+
+
+def test_range_guard_host_logic_without_gpu():
+    """The guard never touches a CPU model, parameter loads / .to() ask for a fresh measurement, deep copies build their own state,
+    and dp's launcher helpers behave (RCCL channel budget as defaults, core slices disjoint)."""
+    import copy
+    from videopose3d_amd import dp, engine, range_guard
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=128)
+    m.math = "f16x3"
+    e0 = m.__dict__.get("_range_epoch", 0)
+    range_guard.tick(m, True, torch.zeros(4, 27, 34))     # CPU tensor: nothing happens, no state
+    assert m.__dict__.get("_range_state") is None and not range_guard.tripped(m)
+    assert range_guard.status(m) == dict(tripped=False, last=None, checks=0, sync_checks=0)
+    m.load_state_dict(m.state_dict())
+    assert m.__dict__["_range_epoch"] == e0 + 1
+    m.float()                                              # nn.Module._apply
+    assert m.__dict__["_range_epoch"] == e0 + 2
+    m.__dict__["_range_state"] = object()                  # (stands in for device buffers + an event)
+    c = copy.deepcopy(m)
+    assert "_range_state" not in c.__dict__
+    del m.__dict__["_range_state"]
+    assert engine.use_s16(m, 27, True)                     # an untripped model is not held back
+    assert dp.RCCL_ENV_DEFAULTS["NCCL_MAX_NCHANNELS"] == "8"
+    cores = sorted(os.sched_getaffinity(0))
+    try:
+        if len(cores) >= 2:
+            a = dp.pin_rank_to_cores(0, 2)
+            os.sched_setaffinity(0, cores)
+            b = dp.pin_rank_to_cores(1, 2)
+            assert a and b and not set(a) & set(b) and set(a) | set(b) <= set(cores)
+        os.sched_setaffinity(0, cores)
+        assert dp.pin_rank_to_cores(0, 1) is None
+    finally:
+        os.sched_setaffinity(0, cores)
+        torch.set_num_threads(max(1, min(len(cores), 8)))

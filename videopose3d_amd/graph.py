@@ -68,7 +68,11 @@ class _Segments:
     with fork / join edges does not on this runtime (hipGraph replays its branches serially: DESIGN.md 4.8)."""
 
     def __init__(self, pool, main, side):
-        self.pool, self.main, self.side = pool, main, side
+        # Two memory pools: the pieces of the main stream share one, the pieces of the second stream the other.  torch only
+        # documents a shared pool as safe for graphs that replay in capture order and never concurrently; the side pieces replay
+        # BESIDE the main ones, so a block that a main piece frees must never be handed to a side piece that is still running
+        # (ADVICE r3: that safety was implicit in the engine's `keep` list; now it does not depend on it).
+        self.pool, self.side_pool, self.main, self.side = pool, torch.cuda.graph_pool_handle(), main, side
         self.graphs = []
         self._cur = None
 
@@ -76,7 +80,7 @@ class _Segments:
         ctx = torch.cuda.stream(self.main if kind == "main" else self.side)
         ctx.__enter__()
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        g.capture_begin(pool=self.pool if kind == "main" else self.side_pool, capture_error_mode="thread_local")
         self._cur = (kind, g, ctx)
 
     def _end(self):
