@@ -702,6 +702,20 @@ typedef struct vp3d_adam {
 int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* grad, float* exp_avg,
                    float* exp_avg_sq, float* max_exp_avg_sq, const vp3d_adam* h);
 
+/* BatchNorm coefficients of the expand layer (model.py:32,74 / :127 / :188: expand_bn(expand_conv(x)) in training mode) WITHOUT a pass
+ * over the conv output: y = X W^T with only kpad <= 128 input columns, so mean_n = W[n] . mean(x) and var_n = W[n]^T Cov(x) W[n].
+ * One MFMA pass over the transposed S16 copy of the im2row rows (xt [kpad][ld_t], the copy the no-dy backward reads) forms the
+ * second-moment matrix of X CENTRED at its first row (no E[x^2] - E[x]^2 cancellation; the constant-1 column `one_col` of the
+ * rows is not shifted and yields the column sums), `part` = vp3d_expand_stats_gram_groups(M) partial [kpad][kpad] matrices, `gram`
+ * = their sum as kpad * kpad doubles; then C quadratic forms in fp64 give exactly vp3d_bn_finalize's outputs (momentum_dev != NULL
+ * is read at execution time instead of `momentum`).  w_packed: the fp32 weight rows [C][kpad] (columns >= kv are padding). */
+int vp3d_expand_stats_gram_groups(int64_t M);
+int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kpad, int32_t kv, int32_t one_col, const void* xt,
+                               int64_t ld_t, const float* x_bound, const float* w_packed, float* part, double* gram,
+                               const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                               float* save_mean, float* save_invstd);
+
 /* Guard of the split-fp16 arithmetic (videopose3d_amd/range_guard.py).  The S16 operand format keeps one exponent per
  * tensor, while the reference's BatchNorm affine and conv weights are unconstrained (common/model.py:32,102,113-119): this
  * measures, on the device and without a host synchronisation, how far the parameters are from the regime in which a hot

@@ -916,3 +916,61 @@ def test_dropout_mask_two_bit_mode_statistics(p_drop):
     other = (ops.dropout_mask(n, ops.make_dropout(p_drop, 4321, 6, 2), DEV) > 0).float()
     assert abs(float((mk * other).mean()) - keep * keep) < 2e-3
     assert float(ops.dropout_mask(n, d, DEV).max()) == pytest.approx(1.0 / keep, rel=1e-6)
+
+
+@pytest.mark.parametrize("joints,b,shift,scale", [(17, 96, 0.0, 0.5), (17, 37, 300.0, 1.0), (15, 64, -40.0, 3e-3), (5, 50, 0.0, 1.0)])
+def test_expand_statistics_from_the_centred_gram_matrix(joints, b, shift, scale):
+    """vp3d_expand_stats_gram_s16 (the expand layer's training-mode BatchNorm coefficients from the centred second-moment matrix
+    of its <= 128-column input, no pass over the conv output) against the statistics pass + vp3d_bn_finalize it replaces and
+    against float64 -- including inputs whose mean is 300 standard deviations away from zero (the shift by the first row is what
+    keeps E[x^2] - E[x]^2 out of it) and a ragged last slab."""
+    from videopose3d_amd import engine_s16
+    g = torch.Generator().manual_seed(31)
+    c, t = 256, 27
+    c_in = joints * 2
+    spec = ConvSpec(c_in, c, 3, 1, 3)
+    kpad = engine_s16.expand_kpad(spec)
+    kv = 3 * c_in
+    one_col = kv
+    assert kv < kpad
+    x = (torch.randn(b, t, c_in, generator=g) * scale + shift).to(DEV)
+    w = ((torch.rand(c, c_in, 3, generator=g) * 2 - 1) * 0.1).to(DEV)
+    xb = S.amax(x, floor=1.0)
+    x_rows, x_t = S.im2row_split(x, spec, kpad, one_col, xb, want_t=True)
+    w_packed = ops.pack_weight(w, ld_out=kpad)
+    ws_ = S.split(w_packed)
+    m = b * spec.t_out(t)
+    bn_a, bn_b = torch.nn.BatchNorm1d(c).to(DEV), torch.nn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-1, 1, c))
+    st = ops.stat_buffers(m, c, DEV)
+    assert S.expand_fwd(x_rows, ws_, stats=st) is None
+    coef_a = ops.bn_finalize(bn_a, m, st)
+    coef_b = S.expand_stats_gram(x_t, w_packed, bn_b, m, kv, one_col)
+    # float64 reference of the conv output's statistics from the S16-rounded operands' exact values
+    xr = S.join(x_rows).double().reshape(m, kpad)[:, :kv]
+    y = xr @ w_packed.double()[:, :kv].t()
+    den = (xr.abs() @ w_packed.double()[:, :kv].abs().t()).mean(0)          # sum |w||x| per channel: what fp32 rounding of y scales with
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    for name, coef, noise in (("statistics pass", coef_a, 1e-6), ("centred Gram", coef_b, 2e-7)):
+        # (the pass over the conv output inherits the fp32 accumulation noise of y itself, ~1e-6 sum|w||x|; the Gram path forms its
+        #  sums in fp64 from the exact S16 values)
+        err_m = (coef[2].double() - mean).abs()
+        assert bool((err_m <= 2e-5 * (mean.abs() + var.sqrt()) + noise * den).all()), (name, float(err_m.max()))
+        # (std(y) ~ 3e-3 next to |y| ~ 20 in the third case: the fp32 noise of y is 3e-4 of its standard deviation, and the
+        #  pass over y carries it into the variance; the Gram path does not)
+        if name == "centred Gram" or scale >= 0.1:
+            assert float((coef[3].double() / invstd - 1).abs().max()) < 2e-5, name
+    if scale >= 0.1:
+        assert float((coef_a[0] / coef_b[0] - 1).abs().max()) < 2e-5
+        assert float((coef_a[1] - coef_b[1]).abs().max() / coef_a[1].abs().max()) < 2e-5
+        assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=2e-5, atol=1e-7)
+    else:
+        assert torch.allclose(bn_b.running_mean.double(), 0.1 * mean, rtol=1e-5, atol=1e-6)
+        unb = var * m / (m - 1)
+        assert torch.allclose(bn_b.running_var.double(), 0.9 + 0.1 * unb, rtol=1e-5, atol=1e-7)
+    assert int(bn_b.num_batches_tracked) == 1

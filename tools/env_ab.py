@@ -45,8 +45,7 @@ random.seed(int(os.environ.get("ENV_AB_SEED", "0")))
 res = {v: [] for v in values}
 for rep in range(reps):
     order = list(values)
-    if len(order) > 2:
-        random.shuffle(order)                        # (no value always runs behind the same neighbour)
+    random.shuffle(order)                            # (no value always runs behind the same neighbour)
     for v in order:
         os.environ[var] = v
         res[v].append(timed(steps))

@@ -44,8 +44,12 @@ def timed(fn, n=30):
 
 for name, fn in (("forward only", fwd), ("whole step", step)):
     res = {v: [] for v in values}
+    import random
+    random.seed(0)
     for rep in range(reps):
-        for v in values:
+        order = list(values)
+        random.shuffle(order)                        # (fixed-order interleaving has position effects: DESIGN.md 4.9)
+        for v in order:
             os.environ[var] = v
             res[v].append(timed(fn))
     for v in values:

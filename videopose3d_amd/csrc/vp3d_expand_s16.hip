@@ -491,6 +491,155 @@ __global__ void __launch_bounds__(EB_NT, 2) k_expand_bwd_p_s16(const ExpandBwdAr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// BatchNorm statistics of the expand layer WITHOUT a pass over its conv output (round 4): y = X W^T with only kpad <= 128 input
+// columns, so   mean_n = W[n] . mean(x),   var_n = W[n]^T Cov(x) W[n]   -- a [kpad x kpad] second-moment matrix of X (one MFMA pass
+// over the transposed S16 copy the forward keeps anyway, 42 MB at the benchmark size) + 1024 small quadratic forms in fp64
+// replace the statistics-only GEMM pass (k_expand_fwd_s16<false>, 67-78 us + vp3d_bn_finalize).
+// CENTRED: the slab statistics this replaces subtract a slab mean before they square (no E[x^2] - E[x]^2 cancellation,
+// test_bn_statistics_are_robust_to_large_mean); here every column k is shifted by o_k = X[0][k] -- its first row, the same
+// offset in every workgroup, so the partial matrices simply add -- before the products are formed: Cov is shift-invariant and
+// the shifted data has |mean| ~ std.  The constant-1 column the im2row rows carry for the no-dy backward (one_col) is NOT
+// shifted: row `one_col` of the result holds the column sums  sum_m (x_k - o_k)  and its diagonal entry the row count.
+//   part[group][i][j] = 2^(2 e_x) * sum_{m in group} (x'_i[m] - o'_i) (x'_j[m] - o'_j)        x' = the S16-scaled values
+// Structure of k_expand_bwd_p_s16's X^T X ride-along: X^T slabs of 64 rows through a 2-deep LDS ring, wave w owns the blocks
+// (i, j) = (b / NJ, b % NJ) for b = w, w + 8; the fragments are re-centred and re-split in registers (3 fragments per k-step).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ExpandGramArgs {
+  const float* xt;             // S16 transposed X: [kpad][ld_t]
+  float* part;                 // [groups][kpad][kpad]
+  const float* x_bound;
+  int32_t M, kpad, ld_t, one_col;
+  uint32_t xt_bytes;
+  int32_t groups, rows_per;    // rows_per % 64 == 0
+};
+
+// scaled offset of row r of X^T (= column r of X): its first element, 0 for the constant-1 column
+__device__ __forceinline__ float gram_offset(const ExpandGramArgs& p, int r) {
+  if (r >= p.kpad || r == p.one_col) return 0.f;
+  const _Float16* g = reinterpret_cast<const _Float16*>(p.xt + (int64_t)r * p.ld_t);
+  return (float)g[0] + (float)g[8];                  // element 0 of the first S16 group: hi half, lo half 16 B further
+}
+
+constexpr int EG_STAGES = 4;                    // X^T slabs in flight + in use: the kernel is a 42-MB read, 6 slabs per workgroup --
+                                                // with a 2-deep ring every iteration waited out one DMA latency (20 us, 2.1 TB/s)
+template <int NJ>
+__global__ void __launch_bounds__(EB_NT, 1) k_expand_gram_s16(const ExpandGramArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[EG_STAGES * EB_STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, cl = lane & 31;
+  const int group = blockIdx.x;
+  const int row_begin = group * p.rows_per, row_end = min(p.M, row_begin + p.rows_per);
+  const int n_stage = (max(0, row_end - row_begin) + EB_SLAB - 1) / EB_SLAB;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.xt, 0, p.xt_bytes, 0x00020000);
+  auto issue_slab = [&](int S) {                    // (S >= n_stage: an all-zero DMA, so that the counted waits stay uniform)
+    char* sB = smem + (S % EG_STAGES) * EB_STAGE_B;
+    const int m0 = row_begin + S * EB_SLAB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = w * 4 + i;
+      const int r = 4 * pc + (lane >> 4), cp = lane & 15;
+      const int c = cp ^ (r & 15);
+      const int off = (r < p.kpad && S < n_stage) ? (int)(((int64_t)r * p.ld_t + m0) * 4 + c * 16) : kOobOff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sB + pc * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  // this wave's blocks: b0 = w (rows block ia, columns block jb) and b1 = w + 8 (rows block ib, the same columns)
+  constexpr int NB = NJ * NJ;
+  const bool has0 = w < NB, has1 = w + EB_NW < NB;
+  const int ia = has0 ? w / NJ : 0, jb = has0 ? w % NJ : 0, ib = has1 ? (w + EB_NW) / NJ : 0;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const int b_row = cl * EB_ROWB, swz = cl & 15;
+  // Centring happens ONCE per element, in place in LDS, before the k-steps read the slab (the first version re-centred every
+  // fragment in registers: 24 fragment passes per k-step and workgroup for 4 distinct fragments, 30 us of VALU): thread ->
+  // (row r, group g of 8 consecutive m) items, 128 rows x 8 groups = 1024 items over 512 threads
+  float o_it[2];
+  int r_it[2], g_it[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = tid + u * EB_NT;
+    r_it[u] = item >> 3;
+    g_it[u] = item & 7;
+    o_it[u] = gram_offset(p, r_it[u]);
+  }
+  auto centre_slab = [&](char* sB, int m0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = r_it[u], g = g_it[u];
+      if (r >= NJ * 32) continue;
+      char* row = sB + r * EB_ROWB;
+      f16x8* ph = reinterpret_cast<f16x8*>(row + (((2 * g) ^ (r & 15)) * 16));
+      f16x8* pl = reinterpret_cast<f16x8*>(row + (((2 * g + 1) ^ (r & 15)) * 16));
+      const f16x8 hi = *ph, lo = *pl;
+      const int n_valid = row_end - (m0 + 8 * g);            // elements of this group inside the row range
+      f16x8 fh, fl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = ((float)hi[e] + (float)lo[e]) - o_it[u];
+        if (e >= n_valid) v = 0.f;
+        const _Float16 hh = (_Float16)v;
+        fh[e] = hh;
+        fl[e] = (_Float16)(v - (float)hh);
+      }
+      *ph = fh;
+      *pl = fl;
+    }
+  };
+  auto frag = [&](const char* sB, int blk, int ks, f16x8& fh, f16x8& fl) {
+    const int co = ((4 * ks + 2 * h) ^ swz) * 16;
+    fh = *reinterpret_cast<const f16x8*>(sB + blk * 32 * EB_ROWB + b_row + co);
+    fl = *reinterpret_cast<const f16x8*>(sB + blk * 32 * EB_ROWB + b_row + (co ^ 16));
+  };
+
+  if (n_stage > 0) {
+#pragma unroll
+    for (int S = 0; S < EG_STAGES - 1; ++S) issue_slab(S);
+    for (int S = 0; S < n_stage; ++S) {
+      ex_wait_vmcnt<4 * (EG_STAGES - 2)>();          // slab S has landed (this wave's 4 pieces; the newer slabs stay in flight)
+      __builtin_amdgcn_s_barrier();                  // ... everybody's pieces; and everybody is done reading slab S-1
+      issue_slab(S + EG_STAGES - 1);                 // into the buffer slab S-1 has just left
+      char* sB = smem + (S % EG_STAGES) * EB_STAGE_B;
+      centre_slab(sB, row_begin + S * EB_SLAB);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes are done (NOT __syncthreads(): it also waits for
+      __builtin_amdgcn_s_barrier();                        // the slabs in flight, which is what the ring is there to avoid)
+      if (has0) {
+        // all fragments of the slab first (12 + 12 reads), then the MFMAs with the two blocks' chains interleaved
+        f16x8 ah[4], al[4], bh[4], bl[4], jh[4], jl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          frag(sB, jb, ks, jh[ks], jl[ks]);
+          frag(sB, ia, ks, ah[ks], al[ks]);
+          frag(sB, ib, ks, bh[ks], bl[ks]);            // (block 0 again when this wave has no second block: unused)
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], jh[ks], acc0, 0, 0, 0);
+          if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks], jh[ks], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], jl[ks], acc0, 0, 0, 0);
+          if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks], jl[ks], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], jh[ks], acc0, 0, 0, 0);
+          if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks], jh[ks], acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  ex_wait_vmcnt<0>();
+  const float sg = s16_pow2(2 * s16_exp_of(p.x_bound));
+  float* gout = p.part + (int64_t)group * p.kpad * p.kpad;
+  if (has0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      gout[(int64_t)(ia * 32 + r) * p.kpad + jb * 32 + cl] = acc0[reg] * sg;
+      if (has1) gout[(int64_t)(ib * 32 + r) * p.kpad + jb * 32 + cl] = acc1[reg] * sg;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
@@ -569,5 +718,39 @@ int expand_bwd_groups(int64_t M, int32_t C) {
   int groups = 256 / n_slices;
   while (groups > 8 && (int64_t)groups * 4 > slabs) groups >>= 1;
   return groups < 8 ? 8 : (groups / 8) * 8;
+}
+
+// row groups (= partial matrices) of vp3d_expand_stats_gram_s16: ~one workgroup per CU, whole 64-row slabs, at least 2 per group
+int expand_gram_groups(int64_t M) {
+  const int64_t slabs = (M + EB_SLAB - 1) / EB_SLAB;
+  int64_t g = slabs / 2;
+  if (g > 240) g = 240;
+  if (g < 1) g = 1;
+  const int64_t per = (slabs + g - 1) / g;           // slabs per group
+  return (int)((slabs + per - 1) / per);             // no empty group
+}
+
+int launch_expand_gram_s16(hipStream_t s, int64_t M, int32_t kpad, const float* xt, int64_t ld_t, const float* x_bound,
+                           int32_t one_col, int32_t groups, float* part) {
+  ExpandGramArgs a;
+  a.xt = xt;
+  a.part = part;
+  a.x_bound = x_bound;
+  a.M = (int32_t)M;
+  a.kpad = kpad;
+  a.ld_t = (int32_t)ld_t;
+  a.one_col = one_col;
+  a.xt_bytes = (uint32_t)((int64_t)kpad * ld_t * 4);
+  a.groups = groups;
+  const int64_t slabs = (M + EB_SLAB - 1) / EB_SLAB;
+  a.rows_per = (int32_t)((slabs + groups - 1) / groups) * EB_SLAB;
+  const dim3 grid(groups), block(EB_NT);
+  switch (kpad / 32) {
+    case 1: hipLaunchKernelGGL(k_expand_gram_s16<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_expand_gram_s16<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_expand_gram_s16<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_expand_gram_s16<4>, grid, block, 0, s, a); break;
+  }
+  return check_launch("expand_gram_s16");
 }
 }  // namespace vp3d

@@ -157,6 +157,9 @@ int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, con
                           const float* shift, const DropP& drop, const float* out_bound, float* out, uint8_t* bits);
 // expand layer, backward: partial P = G^T X per row group from go + activation bits (vp3d_expand_s16.hip)
 int expand_bwd_groups(int64_t M, int32_t C);
+int expand_gram_groups(int64_t M);
+int launch_expand_gram_s16(hipStream_t s, int64_t M, int32_t kpad, const float* xt, int64_t ld_t, const float* x_bound,
+                           int32_t one_col, int32_t groups, float* part);
 int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, const float* go, const float* go_bound,
                             const uint8_t* bits, float p, const float* xt, int64_t ld_t, const float* x_bound, int32_t groups,
                             float* part, float* gram_part);

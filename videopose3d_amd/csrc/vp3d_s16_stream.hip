@@ -926,6 +926,167 @@ int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float
   return check_launch("sum_slices");
 }
 
+// ---- expand layer: BatchNorm coefficients from the centred second-moment matrix of X (k_expand_gram_s16) ------------------------
+// block = 8 channels x 32 threads.  G [kpad][kpad] doubles: G[i][j] = sum_m (x_i - o_i)(x_j - o_j), row `one` = column sums of the
+// shifted data, G[one][one] = M (vp3d_expand_s16.hip).  Cov_ij = G_ij / M - s_i s_j / M^2 goes to LDS once per block; channel n:
+// mean = W[n] . (o + s / M),  var = W[n]^T Cov W[n]  (fp64), then exactly k_bn_finalize's outputs.
+static __global__ void __launch_bounds__(256) k_expand_stats_fin(int C, int kpad, int kv, int one, double M, const double* __restrict__ G,
+                                                                 const float* __restrict__ xt, int64_t ld_t,
+                                                                 const float* __restrict__ x_bound, const float* __restrict__ wp,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, float momentum_arg, const float* __restrict__ momentum_dev,
+                                                                 float* running_mean, float* running_var, int64_t* nbt, float* scale,
+                                                                 float* shift, float* save_mean, float* save_invstd) {
+  // LDS: S [kv][kpad] doubles (rows 0 .. kv-1 of G, then Cov in place), sv [kpad] (row `one` of G: the column sums), mx [kpad]
+  // (mean of x), then the block's 8 weight rows [8][kpad] floats.
+  // The kernel is 128 blocks of dependent latency chains, not bandwidth: G and the weights were written by kernels on other XCDs,
+  // so every batch of loads pays a trip past this XCD's L2 (~2 us).  Everything is therefore fetched in TWO bursts of 16-byte
+  // loads per thread (the first versions fetched entry by entry, 41 dependent batches: 40 us; then 6 + 7 batches: 32 us).
+  extern __shared__ double S[];
+  double* sv = S + (size_t)kv * kpad;
+  double* mx = sv + kpad;
+  float* w_s = reinterpret_cast<float*>(mx + kpad);
+  const float momentum = momentum_dev != nullptr ? momentum_dev[0] : momentum_arg;
+  const double inv_m = 1.0 / M;
+  const float xs = s16_pow2(s16_exp_of(x_bound));        // X^T holds x * 2^-e_x
+  const int tid = threadIdx.x;
+  {
+    const int n2 = kv * kpad / 2;                        // double2 units of the first kv rows (kpad is even)
+    const double2* src = reinterpret_cast<const double2*>(G);
+    double2* dst = reinterpret_cast<double2*>(S);
+    for (int i0 = tid; i0 < n2; i0 += 256 * 16) {
+      double2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = i0 + u * 256 < n2 ? src[i0 + u * 256] : double2{0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (i0 + u * 256 < n2) dst[i0 + u * 256] = v[u];
+    }
+    if (tid < kpad / 2) reinterpret_cast<double2*>(sv)[tid] = reinterpret_cast<const double2*>(G + (int64_t)one * kpad)[tid];
+    // the block's weight rows: 8 x kpad floats = 2 * kpad float4 (one per thread)
+    const int c0 = blockIdx.x * 8;
+    for (int i = tid; i < 2 * kpad; i += 256) {
+      const int rr = i / (kpad / 4), q4 = i - rr * (kpad / 4);
+      const float4 wv = c0 + rr < C ? reinterpret_cast<const float4*>(wp + (int64_t)(c0 + rr) * kpad)[q4] : float4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<float4*>(w_s + rr * kpad)[q4] = wv;
+    }
+  }
+  double o_k = 0.0;
+  if (tid < kv) {
+    const _Float16* g = reinterpret_cast<const _Float16*>(xt + (int64_t)tid * ld_t);
+    o_k = (double)(((float)g[0] + (float)g[8]) * xs);    // the offset k_expand_gram_s16 used (real units)
+  }
+  __syncthreads();
+  if (tid < kv) mx[tid] = o_k + sv[tid] * inv_m;
+  for (int i = tid; i < kv * kv; i += 256) {             // Cov in place (entries j >= kv of a row stay raw and unused)
+    const int r = i / kv, cc = i - r * kv;
+    S[r * kpad + cc] = (S[r * kpad + cc] - sv[r] * sv[cc] * inv_m) * inv_m;
+  }
+  __syncthreads();
+  // channel cl of the block, 32 threads per channel: thread t takes the columns j = t, t + 32, ... (adjacent threads read
+  // adjacent doubles of a Cov row: conflict-free; the 2 channels of a wave read the same address: broadcast)
+  const int cl = tid >> 5, t = tid & 31;
+  const int c = blockIdx.x * 8 + cl;
+  const float* wr = w_s + cl * kpad;
+  double m_acc = 0.0, v_acc = 0.0;
+  for (int j = t; j < kv; j += 32) {
+    const double wj = (double)wr[j];
+    m_acc += wj * mx[j];
+    double r0 = 0.0, r1 = 0.0;
+    int i = 0;
+    for (; i + 1 < kv; i += 2) {
+      r0 += S[i * kpad + j] * (double)wr[i];
+      r1 += S[(i + 1) * kpad + j] * (double)wr[i + 1];
+    }
+    if (i < kv) r0 += S[i * kpad + j] * (double)wr[i];
+    v_acc += wj * (r0 + r1);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    m_acc += __shfl_xor(m_acc, o);
+    v_acc += __shfl_xor(v_acc, o);
+  }
+  if (t == 0 && c < C) {
+    const double mean = m_acc;
+    double var = v_acc;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var != nullptr) {
+      const double unbiased = var * (M / (M > 1.0 ? M - 1.0 : 1.0));
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) nbt[0] += 1;
+}
+
+// sum of the partial second-moment matrices: 16 elements x 16 slice lanes per block (k_sum_slices' 4 lanes leave each thread a
+// chain of 54 loads for 216 slices: 15 us for 14 MB)
+static __global__ void __launch_bounds__(256) k_gram_reduce(int n, int splits, const float* __restrict__ ws, double* __restrict__ out) {
+  __shared__ double red[16][17];
+  const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
+  double a = 0.0;
+  if (i < n) {
+    for (int s0 = l; s0 < splits; s0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = s0 + 16 * u < splits ? ws[(int64_t)(s0 + 16 * u) * n + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += (double)v[u];
+    }
+  }
+  red[l][e] = a;
+  __syncthreads();
+  if (l == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][e];        // fixed order
+    out[i] = t;
+  }
+}
+
+int vp3d_expand_stats_gram_groups(int64_t M) { return M > 0 ? expand_gram_groups(M) : 0; }
+
+int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kpad, int32_t kv, int32_t one_col, const void* xt,
+                               int64_t ld_t, const float* x_bound, const float* w_packed, float* part, double* gram,
+                               const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                               float* save_mean, float* save_invstd) {
+  VP3D_REQUIRE(M > 1 && M < ((int64_t)1 << 31) && C > 0 && kpad >= 32 && kpad <= 128 && kpad % 32 == 0 && kv > 0 && kv < kpad &&
+                   one_col >= kv && one_col < kpad && xt && x_bound && w_packed && part && gram && gamma && beta && scale && shift &&
+                   save_mean && save_invstd && aligned16(xt) && aligned16(part) && ld_t >= M && ld_t % 8 == 0 &&
+                   (int64_t)kpad * ld_t * 4 < ((int64_t)1 << 31),
+               "expand_stats_gram_s16: bad argument (kpad <= 128 with a constant-1 padding column, transposed X below 2 GiB)");
+  const int groups = expand_gram_groups(M);
+  int rc = launch_expand_gram_s16((hipStream_t)stream, M, kpad, (const float*)xt, ld_t, x_bound, one_col, groups, part);
+  if (rc != VP3D_OK) return rc;
+  const int64_t n = (int64_t)kpad * kpad;
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (int)n, groups, part, gram);
+  rc = check_launch("expand_stats_gram(sum)");
+  if (rc != VP3D_OK) return rc;
+  const size_t lds = ((size_t)kv * kpad + 2 * kpad) * sizeof(double) + (size_t)8 * kpad * sizeof(float);
+  static bool attr_set[64] = {};
+  int dev_id = 0;
+  VP3D_REQUIRE(hipGetDevice(&dev_id) == hipSuccess && dev_id >= 0 && dev_id < 64, "expand_stats_gram_s16: hipGetDevice failed");
+  if (!attr_set[dev_id]) {
+    const hipError_t st = hipFuncSetAttribute((const void*)k_expand_stats_fin, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024 - 4096);
+    if (st != hipSuccess) (void)hipGetLastError();
+    VP3D_REQUIRE(st == hipSuccess, "expand_stats_gram_s16: cannot opt in to %zu B of dynamic LDS (%s)", lds, hipGetErrorString(st));
+    attr_set[dev_id] = true;
+  }
+  hipLaunchKernelGGL(k_expand_stats_fin, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, (double)M,
+                     gram, (const float*)xt, ld_t, x_bound, w_packed, gamma, beta, eps, momentum, momentum_dev, running_mean,
+                     running_var, num_batches_tracked, scale, shift, save_mean, save_invstd);
+  return check_launch("expand_stats_gram(fin)");
+}
+
 int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
                         int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
                         const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw) {

@@ -368,9 +368,19 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         fused0 = idx == 0 and fuse_expand and n_layers > 1
         dedicated0 = (fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
                       m_rows * kpad * 4 < 2 ** 31)                                     # vp3d_expand_fwd_s16 (32-bit byte offsets)
-        y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
-                                                                          stat_slab=slab)
-        coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr(), slab_rows=slab)
+        # expand layer statistics from the centred second-moment matrix of its 128-column input (S.expand_stats_gram: one MFMA
+        # pass over the transposed copy + per-channel quadratic forms in fp64) instead of a statistics-only pass over the conv
+        # output: needs the transposed copy (save) and the constant-1 padding column (one_col)
+        gram0 = (dedicated0 and a_t is not None and one_col >= 0 and bns[0].momentum is not None and
+                 a_t.data.numel() * 4 < 2 ** 31 and os.environ.get("VP3D_EXPAND_GRAM", "1") != "0")
+        if gram0:
+            y = None
+            coef = S.expand_stats_gram(a_t, w0_packed, bns[0], m_rows, plan.convs[0].taps * plan.convs[0].c_in, one_col,
+                                       mod._momentum_dev_ptr())
+        else:
+            y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
+                                                                              stat_slab=slab)
+            coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr(), slab_rows=slab)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:

@@ -218,6 +218,41 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
     return S16(out, out_bound)
 
 
+def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d, m_rows: int, kv: int, one_col: int,
+                      momentum_dev: Optional[int] = None) -> torch.Tensor:
+    """[4, C] = scale, shift, mean, invstd of the expand layer's training-mode BatchNorm (running statistics updated in place)
+    from the centred second-moment matrix of the layer's 128-column input -- no pass over the conv output
+    (vp3d_expand_stats_gram_s16; replaces expand_fwd(stats=...) + ops.bn_finalize).  x_t: the transposed S16 copy of the im2row
+    rows [kpad][pitch]; w_packed: fp32 weight rows [C][kpad]; one_col: the constant-1 padding column of the rows."""
+    xd = x_t.data
+    kpad, ld_t = xd.shape
+    c = bn.num_features
+    assert w_packed.shape == (c, kpad) and w_packed.dtype == torch.float32 and w_packed.is_contiguous()
+    if m_rows <= 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size [%d, %d]" % (m_rows, c))
+    L = _lib.lib()
+    groups = int(L.vp3d_expand_stats_gram_groups(m_rows))
+    dev = xd.device
+    part = torch.empty((groups, kpad, kpad), dtype=torch.float32, device=dev)
+    gram = torch.empty((kpad, kpad), dtype=torch.float64, device=dev)
+    buf = torch.empty((4, c), dtype=torch.float32, device=dev)
+    track = bn.track_running_stats and bn.running_mean is not None
+    assert bn.momentum is not None or not track, "cumulative-average BatchNorm: use ops.bn_finalize"
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    use_dev = momentum_dev is not None and track
+    with ops._Timed("stream_expand_stats_gram", 0.0, 4.0 * xd.numel(), (m_rows, c)):
+        check(L.vp3d_expand_stats_gram_s16(ops._stream(), m_rows, c, kpad, kv, one_col, xd.data_ptr(), ld_t, x_t.bound_ptr(),
+                                           w_packed.data_ptr(), part.data_ptr(), gram.data_ptr(), bn.weight.data_ptr(),
+                                           bn.bias.data_ptr(), float(bn.eps), 0.0 if use_dev else momentum,
+                                           momentum_dev if use_dev else None,
+                                           bn.running_mean.data_ptr() if track else None,
+                                           bn.running_var.data_ptr() if track else None,
+                                           bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
+                                           buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()),
+              "vp3d_expand_stats_gram_s16")
+    return buf
+
+
 _red_ok = {}
 
 
