@@ -1,6 +1,8 @@
 // HBM-bound kernels around the GEMMs: BatchNorm statistics / apply / backward, dropout (Philox, never stored),
 // weight packing / BN folding, split-K reduction of wgrad, column sums, camera projection.
 // All streaming kernels move 16 B per lane (float4) when the channel count allows it (C % 4 == 0).
+#include <cstdlib>
+
 #include "vp3d_internal.h"
 #include "vp3d_dropout.h"
 
@@ -31,13 +33,28 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
   const int c = blockIdx.x * FIN_CH + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-#pragma unroll 4
-    for (int s = g; s < nslab; s += FIN_GROUPS) {
-      const int64_t left = M - (int64_t)s * slab_rows;
-      const double cnt = (double)(left < slab_rows ? left : slab_rows);
-      const double sum = (double)psum[(int64_t)s * C + c];
-      a1 += sum;
-      a2 += (double)pm2[(int64_t)s * C + c] + sum * sum / cnt;
+    // 8 slabs = 16 loads in flight per thread (round 4: the partial rows were written by GEMM workgroups on other XCDs, so a
+    // batch of loads is a ~2-us trip past this XCD's L2 and the kernel is the number of dependent batches: `#pragma unroll 4`
+    // gave 4 of them for the 864 32-row slabs of a 27,648-row layer = 17 us, 2 for 432 slabs = 7 us).  Same summation order.
+    for (int s0 = g; s0 < nslab; s0 += FIN_GROUPS * 8) {
+      float ps[8], pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * FIN_GROUPS;
+        ps[u] = s < nslab ? psum[(int64_t)s * C + c] : 0.f;
+        pq[u] = s < nslab ? pm2[(int64_t)s * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * FIN_GROUPS;
+        if (s < nslab) {
+          const int64_t left = M - (int64_t)s * slab_rows;
+          const double cnt = (double)(left < slab_rows ? left : slab_rows);
+          const double sum = (double)ps[u];
+          a1 += sum;
+          a2 += (double)pq[u] + sum * sum / cnt;
+        }
+      }
     }
   }
   s1[g][cl] = a1;
@@ -51,6 +68,83 @@ __global__ void __launch_bounds__(FIN_CH * FIN_GROUPS) k_bn_finalize(
     __syncthreads();
   }
   if (g == 0 && c < C) {
+    const double S1 = s1[0][cl], S2 = s2[0][cl];
+    const double mean = S1 / (double)M;
+    double var = (S2 - S1 * mean) / (double)M;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var != nullptr) {
+      const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) nbt[0] += 1;
+}
+
+// The same with 16-byte loads: a block owns 16 channels as 4 lanes x float4 and splits the partial rows over 128 groups (512
+// threads).  The scalar kernel above issues one 4-byte load per (slab, channel): 27 load instructions per thread for the 864
+// 32-row slabs of a 27,648-row layer, each touching four half-used cache lines per wave -- 17-22 us on the forward's dependent
+// chain, proportional to the slab count (7 us for 432 slabs), whatever the number of loads in flight.  Summation order: slab
+// s = g, g + 128, ... per group, then a fixed tree over the groups (deterministic; not the scalar kernel's order).
+constexpr int FIN4_GROUPS = 128;
+__global__ void __launch_bounds__(4 * FIN4_GROUPS) k_bn_finalize_v4(
+    int C, int64_t M, int nslab, int slab_rows, const float* __restrict__ psum, const float* __restrict__ pm2,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum_arg,
+    const float* __restrict__ momentum_dev, float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+    float* save_mean, float* save_invstd) {
+  __shared__ double s1[FIN4_GROUPS][16], s2[FIN4_GROUPS][16];
+  const float momentum = momentum_dev != nullptr ? momentum_dev[0] : momentum_arg;
+  const int q = threadIdx.x & 3, g = threadIdx.x >> 2;
+  const int c4 = blockIdx.x * 16 + q * 4;                  // (C % 16 == 0: every quad exists)
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int s0 = g; s0 < nslab; s0 += FIN4_GROUPS * 4) {
+    f32x4 ps[4], pq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * FIN4_GROUPS;
+      ps[u] = s < nslab ? *reinterpret_cast<const f32x4*>(psum + (int64_t)s * C + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      pq[u] = s < nslab ? *reinterpret_cast<const f32x4*>(pm2 + (int64_t)s * C + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * FIN4_GROUPS;
+      if (s < nslab) {
+        const int64_t left = M - (int64_t)s * slab_rows;
+        const double inv_cnt = 1.0 / (double)(left < slab_rows ? left : slab_rows);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double sum = (double)ps[u][e];
+          a1[e] += sum;
+          a2[e] += (double)pq[u][e] + sum * sum * inv_cnt;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s1[g][q * 4 + e] = a1[e];
+    s2[g][q * 4 + e] = a2[e];
+  }
+  __syncthreads();
+  // fixed-shape tree over the groups: thread (g, q) folds its 4 channels
+  for (int o = FIN4_GROUPS / 2; o >= 1; o >>= 1) {
+    if (g < o) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[g][q * 4 + e] += s1[g + o][q * 4 + e];
+        s2[g][q * 4 + e] += s2[g + o][q * 4 + e];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) {
+    const int cl = threadIdx.x, c = blockIdx.x * 16 + cl;
     const double S1 = s1[0][cl], S2 = s2[0][cl];
     const double mean = S1 / (double)M;
     double var = (S2 - S1 * mean) / (double)M;
@@ -505,6 +599,21 @@ using namespace vp3d;
 
 extern "C" {
 
+// scalar or 16-byte-load flavour of the statistics finalize
+static void launch_bn_finalize(hipStream_t st, int C, int64_t M, int nslab, int slab_rows, const float* stat_sum, const float* stat_m2,
+                               const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
+                               float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
+                               float* save_invstd) {
+  const char* knob = getenv("VP3D_FIN_V4");                // (=0: the scalar kernel everywhere -- A/B runs; read per call)
+  if (C % 16 == 0 && aligned16(stat_sum) && aligned16(stat_m2) && nslab >= 64 && !(knob && knob[0] == '0'))
+    hipLaunchKernelGGL(k_bn_finalize_v4, dim3(C / 16), dim3(4 * FIN4_GROUPS), 0, st, C, M, nslab, slab_rows, stat_sum, stat_m2, gamma,
+                       beta, eps, momentum, momentum_dev, running_mean, running_var, nbt, scale, shift, save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, st, C, M, nslab, slab_rows,
+                       stat_sum, stat_m2, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var, nbt, scale, shift,
+                       save_mean, save_invstd);
+}
+
 int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* stat_sum, const float* stat_m2,
                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
@@ -513,9 +622,8 @@ int vp3d_bn_finalize(vp3d_stream_t stream, int32_t C, int64_t M, const float* st
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd,
                "bn_finalize: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, 64, stat_sum,
-                     stat_m2, gamma, beta, eps, momentum, (const float*)nullptr, running_mean, running_var, num_batches_tracked,
-                     scale, shift, save_mean, save_invstd);
+  launch_bn_finalize((hipStream_t)stream, C, M, nslab, 64, stat_sum, stat_m2, gamma, beta, eps, momentum, nullptr, running_mean,
+                     running_var, num_batches_tracked, scale, shift, save_mean, save_invstd);
   return check_launch("bn_finalize");
 }
 
@@ -527,9 +635,8 @@ int vp3d_bn_finalize_dm(vp3d_stream_t stream, int32_t C, int64_t M, const float*
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd && momentum_dev,
                "bn_finalize_dm: null pointer");
   const int nslab = (int)vp3d_stat_slabs(M);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab, 64, stat_sum,
-                     stat_m2, gamma, beta, eps, 0.f, momentum_dev, running_mean, running_var, num_batches_tracked, scale, shift,
-                     save_mean, save_invstd);
+  launch_bn_finalize((hipStream_t)stream, C, M, nslab, 64, stat_sum, stat_m2, gamma, beta, eps, 0.f, momentum_dev, running_mean,
+                     running_var, num_batches_tracked, scale, shift, save_mean, save_invstd);
   return check_launch("bn_finalize_dm");
 }
 
@@ -541,9 +648,8 @@ int vp3d_bn_finalize_slab(vp3d_stream_t stream, int32_t C, int64_t M, int32_t sl
                slab_rows);
   VP3D_REQUIRE(stat_sum && stat_m2 && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize_slab: null pointer");
   const int nslab = (int)((M + slab_rows - 1) / slab_rows);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, M, nslab,
-                     slab_rows, stat_sum, stat_m2, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var,
-                     num_batches_tracked, scale, shift, save_mean, save_invstd);
+  launch_bn_finalize((hipStream_t)stream, C, M, nslab, slab_rows, stat_sum, stat_m2, gamma, beta, eps, momentum, momentum_dev,
+                     running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd);
   return check_launch("bn_finalize_slab");
 }
 
