@@ -870,7 +870,8 @@ def test_tile_224_planned_for_the_benchmark_rows_and_finalize_agrees():
     assert S.plan(27648, 3072, 1024, mix=True) == (28, 1)
     assert S.plan(27648, 1024, 3072)[0] == 22 and S.plan(27648, 1024, 3072, raw=True, mix=True)[0] != 28
     assert S.plan(1024, 1024, 3072, mix=True)[0] == 20          # the T_out = 1 tail stays on split 128 x 128 tiles
-    assert S.plan(9216, 1024, 3072, mix=True) == S.plan(9216, 1024, 3072)   # less than a full round of 256-row tiles: unchanged
+    assert S.plan(9216, 1024, 3072, mix=True) == (28, 1)         # 144 tiles of 256 rows: one launch instead of 3 K slices + finish
+    assert S.plan(3072, 1024, 3072, mix=True) == S.plan(3072, 1024, 3072)      # 48 tiles: below the eligibility threshold
     g = torch.Generator().manual_seed(21)
     b, t, c = 40, 27, 256
     spec = ConvSpec(c, c, 3, 1, 3)

@@ -16,6 +16,7 @@
 //
 // All GEMM forms of the model are expressed as NT: forward (B = packed weight rows), dgrad (B = the transposed
 // pack [(tap,ci)][co]), wgrad (both operands pre-transposed by their producers).
+#include <cstdlib>
 #include <type_traits>
 
 #include "vp3d_internal.h"
@@ -1474,9 +1475,16 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
     }
   }
   // Configuration 28 (224 x 256 tiles, one K slice): where the 256-row tiling leaves most of its last round idle
-  // (only where the 256-row tiling runs at least one FULL round and strands part of the next: on smaller launches the randomised
-  // step A/B of round 4 shows nothing to gain -- 4.525 vs 4.505 ms with configuration 28 on the 9,216-row launches only)
-  if (allow_mix && !raw && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= 256) {
+  // Eligible from half a round of 256-row tiles up (VP3D_TILE_224_MIN_TILES, default 128; read once).  Round 4, alternating
+  // processes on one box, three pairs: 256 -> 4.478-4.486 ms, 128 -> 4.426-4.433 ms (-1.1 %), 32 and 1 like 128: with the fused
+  // BatchNorm-backward sums restricted to the 27,648-row activations, the 144-tile launches of the 9,216-row layers (forward
+  // K = 3072 without its 3-slice split-K + finishing pass, forward / dgrad K = 1024, dgrad 3072 x 3072) run better as 168 tiles of
+  // 224 rows than as 128 x 128 tiles or K slices -- the cost model below decides per launch.
+  static const int min_tiles = [] {
+    const char* v = getenv("VP3D_TILE_224_MIN_TILES");
+    return v ? atoi(v) : 128;
+  }();
+  if (allow_mix && !raw && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= min_tiles) {
     const int64_t tiles = (int64_t)((M + 223) / 224) * (N / 256);
     const double cost = kLaunchUs + cost_224(tiles, (double)nkt);
     if (cost < best * 0.97) {
