@@ -17,6 +17,10 @@
  *   vp3d_mpjpe            mpjpe / weighted_mpjpe (+ gradient)                    common/loss.py:11-25
  *   vp3d_tta_fold         test-time-augmentation un-flip + average                run.py:677-680
  *   vp3d_adam_step        optim.Adam(amsgrad=True).step() on flat buffers         run.py:252,264,420
+ *   vp3d_expand_stats_gram_s16   expand_bn's batch statistics (model.py:32,74,127,188) from the second-moment matrix of the
+ *                                layer's <= 128-column input instead of a pass over expand_conv's output
+ *   vp3d_range_stats      nothing in the reference: the dynamic-range statistic behind the split-fp16 arithmetic's guard (the
+ *                         reference's BatchNorm affine and conv weights are unconstrained, model.py:32,102,113-119)
  *
  * Conventions
  *   - Layout: activations are channels-last rows, x[b][t][c] ("NLC"); this IS the reference's module boundary
