@@ -854,12 +854,15 @@ def main():
                     y = ev(x)
                 torch.cuda.synchronize()
                 dte = (time.perf_counter() - t0) / k_eval
-                recs = []
-                ops.set_profiler(recs)
-                ev(x)
-                torch.cuda.synchronize()
-                ops.set_profiler(None)
-            big = [(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b, _s in recs if f > 1e11]
+                runs = []
+                for _ in range(3):                     # per-launch rates: the median of three instrumented forwards
+                    recs = []
+                    ops.set_profiler(recs)
+                    ev(x)
+                    torch.cuda.synchronize()
+                    ops.set_profiler(None)
+                    runs.append([(f, e0.elapsed_time(e1)) for _, f, e0, e1, _b, _s in recs if f > 1e11])
+            big = [(runs[0][i][0], sorted(r[i][1] for r in runs)[1]) for i in range(len(runs[0]))]
             tf = FLOP_EVAL_PER_FRAME * B / dte / 1e12
             return y, {"workload": "TemporalModel eval forward (BN folded), arc 3,3,3,3,3 C=1024 B=1024 T=243", "math": mth,
                        "ms": dte * 1e3, "frames_per_s": B / dte, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
