@@ -66,6 +66,11 @@ CASES = [  # (B, T, spec, cfg, splits)
     (31, 81, ConvSpec(64, 512, 3, 1, 3), 28, 1),        # ... M = 837 = 3 full tiles + 165 rows (5 blocks + 5 rows), strided
     (11, 67, ConvSpec(64, 2368, 1), 28, 1),             # ... ragged N (10 column tiles of 256, the last one 64 wide)
     (7, 40, ConvSpec(128, 256, 3, 9, 1), 28, 1),        # ... dilated taps
+    (8, 27, ConvSpec(256, 256, 3, 3, 1), 29, 1),        # 160 x 256 tiles (wave rows of 3 + 2 row blocks): one tile + a ragged one
+    (31, 81, ConvSpec(64, 512, 3, 1, 3), 29, 1),        # ... M = 837 = 5 full tiles + 37 rows, strided
+    (11, 67, ConvSpec(64, 2368, 1), 29, 1),             # ... ragged N
+    (31, 81, ConvSpec(64, 512, 3, 1, 3), 29, 3),        # ... with K slices + finishing pass (64-row slabs again)
+    (31, 81, ConvSpec(64, 512, 3, 1, 3), 28, 2),
 ]
 
 
@@ -82,7 +87,7 @@ def test_nt_gemm_vs_fp64(case):
     ref = torch.relu(ref)
     xs, ws = S.split(x), S.split(ops.pack_weight(w))
     m = b * spec.t_out(t)
-    slab = S.stat_slab_rows(cfg)                        # 64 rows; the 224-row tiling writes 32-row slabs
+    slab = S.stat_slab_rows(cfg, splits)                # 64 rows; the 224- / 160-row tilings write 32-row slabs in one K slice
     stats = ops.stat_buffers(m, spec.c_out, DEV, slab)
     am = S.new_bound(DEV)
     y = S.conv_nt(xs, ws, spec, bias=bias, relu=True, stats=stats, amax_out=am, cfg=cfg, splits=splits, stat_slab=slab)
@@ -95,14 +100,14 @@ def test_nt_gemm_vs_fp64(case):
         blk = raw[s0:s0 + slab]
         assert torch.allclose(stats[0][s0 // slab].double(), blk.sum(0), rtol=1e-4, atol=1e-4)
         assert torch.allclose(stats[1][s0 // slab].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
-    if cfg == 28:
+    if cfg in (28, 29) and splits == 1:
         # the same K order per element as the 256-row tiling: bit-identical output; a statistics buffer sized for the
         # other slab size is refused, not overrun
         y22 = S.conv_nt(xs, ws, spec, bias=bias, relu=True, cfg=22, splits=1)
         assert torch.equal(y, y22)
         from videopose3d_amd._lib import Vp3dError
         with pytest.raises(Vp3dError, match="slabs"):
-            S.conv_nt(xs, ws, spec, stats=ops.stat_buffers(m, spec.c_out, DEV), cfg=28, splits=1)
+            S.conv_nt(xs, ws, spec, stats=ops.stat_buffers(m, spec.c_out, DEV), cfg=cfg, splits=1)
 
 
 def test_nt_gemm_exponents_and_residual():
@@ -870,8 +875,12 @@ def test_tile_224_planned_for_the_benchmark_rows_and_finalize_agrees():
     assert S.plan(27648, 3072, 1024, mix=True) == (28, 1)
     assert S.plan(27648, 1024, 3072)[0] == 22 and S.plan(27648, 1024, 3072, raw=True, mix=True)[0] != 28
     assert S.plan(1024, 1024, 3072, mix=True)[0] == 20          # the T_out = 1 tail stays on split 128 x 128 tiles
-    assert S.plan(9216, 1024, 3072, mix=True) == (28, 1)         # 144 tiles of 256 rows: one launch instead of 3 K slices + finish
-    assert S.plan(3072, 1024, 3072, mix=True) == S.plan(3072, 1024, 3072)      # 48 tiles: below the eligibility threshold
+    assert S.plan(9216, 1024, 3072, mix=True) == (29, 1)         # 232 tiles of 160 rows in one launch instead of 3 K slices of
+                                                                 # 256 x 256 tiles + a finishing pass
+    assert S.plan(9216, 1024, 1024, mix=True) == (29, 1)         # 58 x 4 = 232 tiles of 160 rows: 91 % of one round
+    assert S.plan(3072, 1024, 3072, mix=True) == (29, 3)         # 80 tiles of 160 rows x 3 K slices = 240 workgroups
+    assert S.stat_slab_rows(29, 1) == 32 and S.stat_slab_rows(29, 3) == 64 and S.stat_slab_rows(22, 3) == 64
+    assert S.plan(1024, 1024, 1024, mix=True) == S.plan(1024, 1024, 1024)      # the smallest launches stay on 128 x 128 tiles
     g = torch.Generator().manual_seed(21)
     b, t, c = 40, 27, 256
     spec = ConvSpec(c, c, 3, 1, 3)

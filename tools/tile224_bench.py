@@ -31,7 +31,10 @@ shapes = [("fwd  L0  27648 x 1024 x 3072 + statistics", 1024, 81, ConvSpec(1024,
           ("fwd  L1  27648 x 1024 x 1024 + statistics", 1024, 27, ConvSpec(1024, 1024, 1), True),
           ("dgrad L0 27648 x 3072 x 1024 + amax", 1024, 27, ConvSpec(1024, 3072, 1), False),
           ("fwd  9216 x 1024 x 3072 + statistics", 1024, 27, ConvSpec(1024, 1024, 3, 1, 3), True),
-          ("dgrad 9216 x 3072 x 1024 + amax", 1024, 9, ConvSpec(1024, 3072, 1), False)]
+          ("dgrad 9216 x 3072 x 1024 + amax", 1024, 9, ConvSpec(1024, 3072, 1), False),
+          ("fwd  9216 x 1024 x 1024 + statistics", 1024, 9, ConvSpec(1024, 1024, 1), True),
+          ("dgrad 3072 x 3072 x 1024 + amax", 1024, 3, ConvSpec(1024, 3072, 1), False),
+          ("fwd  3072 x 1024 x 3072 + statistics", 1024, 9, ConvSpec(1024, 1024, 3, 1, 3), True)]
 for name, b, t, spec, with_stats in shapes:
     x = torch.relu(torch.randn(b, t, spec.c_in, device=dev))
     w = torch.randn(spec.c_out, spec.c_in, spec.taps, device=dev) * 0.02
@@ -40,12 +43,13 @@ for name, b, t, spec, with_stats in shapes:
     flops = 2.0 * m * spec.c_out * spec.taps * spec.c_in
     res = {}
     for rep in range(3):
-        for cfg in (22, 28):
+        for cfg in (22, 28, 29, 20):
             slab = S.stat_slab_rows(cfg)
             st = ops.stat_buffers(m, spec.c_out, dev, slab) if with_stats else None
             am = None if with_stats else S.new_bound(dev)
             us = timeit(lambda: S.conv_nt(xs, ws, spec, stats=st, amax_out=am, cfg=cfg, splits=1, stat_slab=slab))
             res.setdefault(cfg, []).append(us)
     a, b_ = min(res[22]), min(res[28])
-    print("%-44s cfg 22: %7.1f us (%5.1f TF)   cfg 28: %7.1f us (%5.1f TF)   %+5.1f %%   planner(mix): %s" % (
-        name, a, flops / a / 1e6, b_, flops / b_ / 1e6, (b_ / a - 1) * 100, S.plan(m, spec.c_out, spec.taps * spec.c_in, mix=True)), flush=True)
+    print("%-44s 256x256: %7.1f us (%5.1f TF)  224x256: %7.1f (%5.1f)  160x256: %7.1f (%5.1f)  128x128: %7.1f (%5.1f)   planner(mix): %s" % (
+        name, a, flops / a / 1e6, b_, flops / b_ / 1e6, min(res[29]), flops / min(res[29]) / 1e6, min(res[20]), flops / min(res[20]) / 1e6,
+        S.plan(m, spec.c_out, spec.taps * spec.c_in, mix=True)), flush=True)

@@ -1432,8 +1432,16 @@ static double cost_224(int64_t wgs, double nk) {
   return (double)per_cu * (nk * 0.893 * (per_cu >= 2 ? 2.22 : 1.68 + 0.54 * fill) + 7.6);
 }
 
+// 160-row tiles (configuration 29: wave rows of 3 + 2 row blocks): 5/7 of a 224-row tile's MFMAs per K-tile, a little more than
+// 5/7 of its time (fragment reads per MFMA 0.60 instead of 0.52, the same barrier and DMA issue)
+static double cost_160(int64_t wgs, double nk) {
+  const int64_t per_cu = (wgs + 255) / 256;
+  const double fill = wgs < 256 ? (double)wgs / 256.0 : 1.0;
+  return (double)per_cu * (nk * 0.67 * (per_cu >= 2 ? 2.22 : 1.68 + 0.54 * fill) + 6.6);
+}
+
 // rows per BatchNorm statistics slab that configuration cfg writes
-int nt_s16_stat_slab_rows(int cfg) { return cfg == 28 ? 32 : 64; }
+int nt_s16_stat_slab_rows(int cfg) { return (cfg == 28 || cfg == 29) ? 32 : 64; }
 
 void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, int* splits_out, int allow_mix) {
   const int nkt = K / 32;
@@ -1484,12 +1492,37 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
     const char* v = getenv("VP3D_TILE_224_MIN_TILES");
     return v ? atoi(v) : 128;
   }();
-  if (allow_mix && !raw && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= min_tiles) {
-    const int64_t tiles = (int64_t)((M + 223) / 224) * (N / 256);
-    const double cost = kLaunchUs + cost_224(tiles, (double)nkt);
-    if (cost < best * 0.97) {
-      best_cfg = 28;
-      best_s = 1;
+  // K slices for the two mixed tilings as well (VP3D_TILE_MIX_SPLITS=0: one slice only): the M = 3,072 / 1,024 layers are 20 / 7
+  // row tiles of 160 rows -- 80 tiles x 3 slices = 240 workgroups are one 94 %-full round where 192 tiles of 128 x 128 x 4 slices
+  // = 1.5 rounds of 512 slots
+  static const bool mix_splits = [] {
+    const char* v = getenv("VP3D_TILE_MIX_SPLITS");
+    return !(v && v[0] == '0');
+  }();
+  static const bool allow_160 = [] {
+    const char* v = getenv("VP3D_TILE_160");
+    return !(v && v[0] == '0');
+  }();
+  if (allow_mix && !raw && N % 256 == 0) {
+    const bool big = (int64_t)((M + 255) / 256) * (N / 256) >= min_tiles;      // eligibility of the one-slice launches
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8};
+    for (int which = 0; which < 2; ++which) {
+      if (which == 1 && !allow_160) break;
+      const int rows = which == 0 ? 224 : 160;
+      const int64_t tiles = (int64_t)((M + rows - 1) / rows) * (N / 256);
+      for (int si = 0; si < ((allow_split && mix_splits) ? 6 : 1); ++si) {
+        const int sp = kSplits[si];
+        if (sp > 1 && nkt / sp < 6) break;
+        if (sp == 1 && !big) continue;
+        const double nk = (double)((nkt + sp - 1) / sp);
+        double cost = kLaunchUs + (which == 0 ? cost_224(tiles * sp, nk) : cost_160(tiles * sp, nk));
+        if (sp > 1) cost += 5.5 + (double)sp * (double)M * (double)N * 8.0 / 7.4e6;
+        if (cost < best * 0.97) {
+          best = cost;
+          best_cfg = which == 0 ? 28 : 29;
+          best_s = sp;
+        }
+      }
     }
   }
   *cfg_out = best_cfg;
@@ -1531,7 +1564,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   a.a_bytes = (uint32_t)a_bytes;
   a.b_bytes = (uint32_t)b_bytes;
 #ifndef VP3D_BUILD_EXPERIMENTS
-  VP3D_REQUIRE(cfg == 0 || cfg == 4 || cfg == 20 || cfg == 22 || cfg == 28,
+  VP3D_REQUIRE(cfg == 0 || cfg == 4 || cfg == 20 || cfg == 22 || cfg == 28 || cfg == 29,
                "nt_s16: tile configuration %d is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)", cfg);
   (void)tickets;
   if ((cfg == 20 || cfg == 22) && (a_bytes >= ((int64_t)1 << 31) || b_bytes >= ((int64_t)1 << 31)))
@@ -1565,10 +1598,10 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     }
   }
 #endif  // VP3D_BUILD_EXPERIMENTS
-  if (cfg == 28) {
-    VP3D_REQUIRE(splits == 1 && !raw_partials && a.epi.act_scale == nullptr && !a.epi.red && a_bytes < ((int64_t)1 << 31) &&
+  if (cfg == 28 || cfg == 29) {
+    VP3D_REQUIRE(!raw_partials && a.epi.act_scale == nullptr && !a.epi.red && a_bytes < ((int64_t)1 << 31) &&
                      b_bytes < ((int64_t)1 << 31),
-                 "nt_s16: tile configuration 28 (224 x 256) takes one K slice, no fused activation / BatchNorm-backward sums and "
+                 "nt_s16: tile configurations 28 / 29 (224 / 160 x 256) take no raw output, no fused activation / BatchNorm-backward sums and "
                  "operands below 2 GiB");
   }
   VP3D_REQUIRE(a.epi.stat_sum == nullptr || splits > 1 || a.stat_slab_rows == nt_s16_stat_slab_rows(cfg),
@@ -1587,6 +1620,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
     case 20: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 0, 1>>(s, a, splits); break;
     case 22: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1>>(s, a, splits); break;
     case 28: rc = launch_cfg<Cfg<2, 4, 4, 2, 2, 32, 0, 1, 3>>(s, a, splits); break;  // 224x256: wave rows of 4 + 3 row blocks
+    case 29: rc = launch_cfg<Cfg<2, 4, 3, 2, 2, 32, 0, 1, 2>>(s, a, splits); break;  // 160x256: wave rows of 3 + 2 row blocks
 #ifdef VP3D_BUILD_EXPERIMENTS
     case 21: rc = launch_cfg<Cfg<2, 2, 2, 2, 2, 32, 1, 1>>(s, a, splits); break;   // measured alternatives
     case 23: rc = launch_cfg<Cfg<2, 4, 4, 2, 4, 16, 1, 1>>(s, a, splits); break;

@@ -360,7 +360,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # 224 x 256 tiles (tile configuration 28) where the 256-row tiling strands most of its last round: their statistics
         # come in 32-row slabs; not for the launches that carry a fused activation, nor under synchronised BatchNorm
         mix = idx > 0 and sync is None
-        slab = S.stat_slab_rows(S.plan(m_rows, spec.c_out, spec.taps * spec.c_in, mix=True)[0]) if mix else 64
+        slab = S.stat_slab_rows(*S.plan(m_rows, spec.c_out, spec.taps * spec.c_in, mix=True)) if mix else 64
         stats = ops.stat_buffers(m_rows, spec.c_out, dev, slab)
         # expand layer, fused: its GEMM (K = 128) is cheap enough to run twice -- pass 1 only produces the BatchNorm
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):

@@ -86,9 +86,10 @@ def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False) -> Tuple[
     return hit
 
 
-def stat_slab_rows(cfg: int) -> int:
-    """Rows per BatchNorm statistics slab that tile configuration cfg writes (64; 32 for the 224-row tiling)."""
-    return 32 if cfg == 28 else 64
+def stat_slab_rows(cfg: int, splits: int = 1) -> int:
+    """Rows per BatchNorm statistics slab of a launch in tile configuration cfg with `splits` K slices: 64; 32 for the 224- /
+    160-row tilings in ONE slice (a split launch's statistics come from its finishing pass: 64-row slabs whatever the tiling)."""
+    return 32 if (cfg in (28, 29) and splits <= 1) else 64
 
 
 def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=False, mix=False):
