@@ -641,6 +641,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     if (BSLOT == 2) fetch_bits(0);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
+      if (C::MIX && i >= rbw) break;                   // (the last wave row of a mixed tiling has fewer row blocks)
       if (BSLOT == 1) fetch_bits(i);
 #pragma unroll
       for (int j = 0; j < CB; ++j)
@@ -649,7 +650,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
           const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
           wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
         }
-      if (i + 1 < RB) {                                // (after the staging: this block's accumulator registers are free)
+      if (i + 1 < RB && (!C::MIX || i + 1 < rbw)) {    // (after the staging: this block's accumulator registers are free)
         fetch_y(i + 1);
         if (BSLOT == 2) fetch_bits(i + 1);
       }
@@ -1295,14 +1296,14 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
     }
   }
   if (a.epi.red) {
-    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && C::NT == 2 * C::BN && !C::MIX) {
+    if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && C::NT == 2 * C::BN && (!C::MIX || C::RB == 4)) {
       VP3D_REQUIRE(splits == 1 && a.epi.vec && a.N % C::BN == 0 && a.epi.ab_c % C::BN == 0 && a.m_begin == 0 && a.m_end == a.M,
                    "nt_s16: the fused BatchNorm-backward sums need one K slice, 16-byte aligned fp32 output and c_out, c_up "
                    "multiples of the %d-column tile", C::BN);
       hipLaunchKernelGGL((k_nt_s16<C, false, false, true>), dim3(positions), dim3(C::NT), 0, s, a);
       return check_launch("nt_s16(red)");
     } else {
-      set_error("nt_s16: the fused BatchNorm-backward sums exist for tile configurations 20 / 22 only (operands below 2 GiB)");
+      set_error("nt_s16: the fused BatchNorm-backward sums exist for tile configurations 20 / 22 / 28 only (operands below 2 GiB)");
       return VP3D_E_INVALID;
     }
   }
@@ -1599,7 +1600,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
   }
 #endif  // VP3D_BUILD_EXPERIMENTS
   if (cfg == 28 || cfg == 29) {
-    VP3D_REQUIRE(!raw_partials && a.epi.act_scale == nullptr && !a.epi.red && a_bytes < ((int64_t)1 << 31) &&
+    VP3D_REQUIRE(!raw_partials && a.epi.act_scale == nullptr && (!a.epi.red || cfg == 28) && a_bytes < ((int64_t)1 << 31) &&
                      b_bytes < ((int64_t)1 << 31),
                  "nt_s16: tile configurations 28 / 29 (224 / 160 x 256) take no raw output, no fused activation / BatchNorm-backward sums and "
                  "operands below 2 GiB");

@@ -257,16 +257,26 @@ def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d
 _red_ok = {}
 
 
+def red_cfg(m: int, n: int, k: int, c_up: int) -> int:
+    """Tile configuration in which a dgrad launch [m, n, k] can carry the BatchNorm-backward column sums of its upstream
+    activation (vp3d_s16_red), or 0: one K slice on the 128 x 128 / 256 x 256 / 224 x 256 buffer-descriptor tilings (20 / 22 /
+    28), whole column tiles.  (Cached: asked per launch.)"""
+    key = (m, n, k, c_up, os.environ.get("VP3D_TILE_224", "1"), os.environ.get("VP3D_RED_224", "1"))
+    hit = _red_ok.get(key)
+    if hit is None:
+        hit = 0
+        if c_up > 0 and c_up % 256 == 0 and n % c_up == 0:
+            cfg, splits = plan(m, n, k, mix=os.environ.get("VP3D_RED_224", "1") != "0")     # (=0: A/B runs)
+            if not (cfg == 28 and splits == 1):
+                cfg, splits = plan(m, n, k)
+            if cfg in (20, 22, 28) and splits == 1 and n % (128 if cfg == 20 else 256) == 0:
+                hit = cfg
+        _red_ok[key] = hit
+    return hit
+
+
 def red_supported(m: int, n: int, k: int, c_up: int) -> bool:
-    """Can a dgrad launch [m, n, k] carry the BatchNorm-backward column sums of its upstream activation (vp3d_s16_red)?
-    One K slice on the 128x128 / 256x256 buffer-descriptor tilings, whole column tiles.  (Cached: asked per launch.)"""
-    key = (m, n, k, c_up)
-    ok = _red_ok.get(key)
-    if ok is None:
-        cfg, splits = plan(m, n, k)
-        bn = 256 if cfg == 22 else 128
-        ok = _red_ok[key] = bool(cfg in (20, 22) and splits == 1 and c_up > 0 and c_up % 256 == 0 and n % c_up == 0 and n % bn == 0)
-    return ok
+    return red_cfg(m, n, k, c_up) != 0
 
 
 RED_CFG_KEY = 1000              # profiler rows: tile configuration + 1000 = the instance that carries the fused sums
@@ -298,6 +308,8 @@ def gemm_rows(x: S16, wt: S16, rm: RowMap, c_in: int, c_src: int, n: int, out: t
     struct -- the launch also reduces the BatchNorm backward of the activation whose gradient it writes."""
     xd, wd = x.data, wt.data
     m, k = rm.batch * rm.t_dst, rm.taps * c_in
+    if red is not None and cfg < 0:
+        cfg, splits = red_cfg(m, n, k, red.c_up), 1  # (the configuration red_supported() answered for)
     o, ws = _opts(x, wt, m, n, k, xd.device, amax_out, cfg, splits, mix=mix and red is None)
     if red is not None:
         o.red = C.addressof(red)
