@@ -387,6 +387,10 @@ def instrumented(step, ops, n_prof, math):
         names = {22: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>> (256x256 tile, 8 waves of 128x64; forward + dgrad launches)",
                  28: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>> (224x256 tile, 8 waves: wave rows of 4 + 3 row blocks; the forward and "
                      "plain-dgrad launches of the 27,648-row layers: 496 / 1488 tiles = 1.94 / 5.81 rounds of 256 CUs)",
+                 29: "k_nt_s16<Cfg<2,4,3,2,2,32,0,1,2>> (160x256 tile, 8 waves: wave rows of 3 + 2 row blocks; the 9,216-row launches: "
+                     "232 tiles = 91 % of one round of 256 CUs; 3072 x 1024 x 3072 as 80 tiles x 3 K slices)",
+                 1028: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>, RED> (224x256 tile dgrad + the BatchNorm-backward column sums of the upstream "
+                       "activation, vp3d_s16_red)",
                  20: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>> (128x128 tile, 4 waves, 2 workgroups per CU)",
                  1022: "k_nt_s16<Cfg<2,4,4,2,2,32,0,1>, RED> (256x256 tile dgrad + the BatchNorm-backward column sums of the "
                        "upstream activation: reads that activation's conv output and bits in the epilogue, vp3d_s16_red)",
