@@ -261,10 +261,13 @@ typedef struct vp3d_s16 {
    * caller announced is refused, never silently mis-indexed. */
   int32_t stat_slab_rows;
 } vp3d_s16;
-/* Configuration 28: 224 x 256 tiles (the 8 waves of configuration 22; wave row 0 owns 4 row blocks of 32, wave row 1 owns 3):
+/* Configuration 29: the same with wave rows of 3 + 2 row blocks = 160 x 256 tiles (the 9,216-row launches: 58 x 4 = 232 tiles = 91 %
+ * of one round); both take K slices like 20 / 22 (their statistics then come from the finishing pass: 64-row slabs); the fused
+ * BatchNorm-backward sums exist for 28, not for 29.
+ * Configuration 28: 224 x 256 tiles (the 8 waves of configuration 22; wave row 0 owns 4 row blocks of 32, wave row 1 owns 3):
  * B * T_out = 27,648 rows of the benchmark step are 124 x 4 = 496 such tiles = 1.94 rounds of the 256 CUs, where the 432
- * tiles of 256 x 256 = 1.69 rounds cost 2.  One K slice, fp32 or S16 output, bias / ReLU / residual / statistics (32-row
- * slabs) / amax epilogues; no fused activation, no fused BatchNorm-backward sums, operands below 2 GiB.
+ * tiles of 256 x 256 = 1.69 rounds cost 2.  fp32 or S16 output, bias / ReLU / residual / statistics (32-row slabs in one K
+ * slice) / amax epilogues; no fused activation, operands below 2 GiB.
  * vp3d_nt_s16_plan flags: bit 0 = raw partial output (weight gradients), bit 1 = configuration 28 may be chosen (the caller
  * sizes its statistics for vp3d_nt_s16_stat_slab_rows(cfg) and does not attach act / red epilogues). */
 int vp3d_nt_s16_plan(int64_t M, int32_t N, int32_t K, int32_t flags, int32_t* cfg, int32_t* splits);

@@ -604,8 +604,7 @@ static void launch_bn_finalize(hipStream_t st, int C, int64_t M, int nslab, int 
                                const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
                                float* save_invstd) {
-  const char* knob = getenv("VP3D_FIN_V4");                // (=0: the scalar kernel everywhere -- A/B runs; read per call)
-  if (C % 16 == 0 && aligned16(stat_sum) && aligned16(stat_m2) && nslab >= 64 && !(knob && knob[0] == '0'))
+  if (C % 16 == 0 && aligned16(stat_sum) && aligned16(stat_m2) && nslab >= 64)
     hipLaunchKernelGGL(k_bn_finalize_v4, dim3(C / 16), dim3(4 * FIN4_GROUPS), 0, st, C, M, nslab, slab_rows, stat_sum, stat_m2, gamma,
                        beta, eps, momentum, momentum_dev, running_mean, running_var, nbt, scale, shift, save_mean, save_invstd);
   else

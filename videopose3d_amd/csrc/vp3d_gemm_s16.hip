@@ -1484,22 +1484,15 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
     }
   }
   // Configuration 28 (224 x 256 tiles, one K slice): where the 256-row tiling leaves most of its last round idle
-  // Eligible from half a round of 256-row tiles up (VP3D_TILE_224_MIN_TILES, default 128; read once).  Round 4, alternating
-  // processes on one box, three pairs: 256 -> 4.478-4.486 ms, 128 -> 4.426-4.433 ms (-1.1 %), 32 and 1 like 128: with the fused
-  // BatchNorm-backward sums restricted to the 27,648-row activations, the 144-tile launches of the 9,216-row layers (forward
-  // K = 3072 without its 3-slice split-K + finishing pass, forward / dgrad K = 1024, dgrad 3072 x 3072) run better as 168 tiles of
-  // 224 rows than as 128 x 128 tiles or K slices -- the cost model below decides per launch.
-  static const int min_tiles = [] {
-    const char* v = getenv("VP3D_TILE_224_MIN_TILES");
-    return v ? atoi(v) : 128;
-  }();
-  // K slices for the two mixed tilings as well (VP3D_TILE_MIX_SPLITS=0: one slice only): the M = 3,072 / 1,024 layers are 20 / 7
-  // row tiles of 160 rows -- 80 tiles x 3 slices = 240 workgroups are one 94 %-full round where 192 tiles of 128 x 128 x 4 slices
-  // = 1.5 rounds of 512 slots
-  static const bool mix_splits = [] {
-    const char* v = getenv("VP3D_TILE_MIX_SPLITS");
-    return !(v && v[0] == '0');
-  }();
+  // One-slice launches are eligible from half a round of 256-row tiles up.  Round 4, alternating processes on one box, three
+  // pairs (a temporary knob): eligibility from 256 tiles -> 4.478-4.486 ms, from 128 -> 4.426-4.433 ms (-1.1 %), 32 and 1 like 128
+  // -- the 144-tile launches of the 9,216-row layers run better as 168 tiles of 224 rows (and better still as 232 tiles of 160
+  // rows, below) than as 128 x 128 tiles or K slices of 256 x 256 ones; the cost model decides per launch.
+  constexpr int min_tiles = 128;
+  // K slices for the two mixed tilings as well: the M = 3,072 layers are 20 row tiles of 160 rows -- 80 tiles x 3 slices = 240
+  // workgroups are one 94 %-full round where 192 tiles of 128 x 128 x 4 slices = 1.5 rounds of 512 slots (step 4.275-4.299 ->
+  // 4.201-4.232 ms, alternating processes, a temporary knob)
+  constexpr bool mix_splits = true;
   static const bool allow_160 = [] {
     const char* v = getenv("VP3D_TILE_160");
     return !(v && v[0] == '0');

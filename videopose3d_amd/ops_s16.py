@@ -261,12 +261,12 @@ def red_cfg(m: int, n: int, k: int, c_up: int) -> int:
     """Tile configuration in which a dgrad launch [m, n, k] can carry the BatchNorm-backward column sums of its upstream
     activation (vp3d_s16_red), or 0: one K slice on the 128 x 128 / 256 x 256 / 224 x 256 buffer-descriptor tilings (20 / 22 /
     28), whole column tiles.  (Cached: asked per launch.)"""
-    key = (m, n, k, c_up, os.environ.get("VP3D_TILE_224", "1"), os.environ.get("VP3D_RED_224", "1"))
+    key = (m, n, k, c_up, os.environ.get("VP3D_TILE_224", "1"))
     hit = _red_ok.get(key)
     if hit is None:
         hit = 0
         if c_up > 0 and c_up % 256 == 0 and n % c_up == 0:
-            cfg, splits = plan(m, n, k, mix=os.environ.get("VP3D_RED_224", "1") != "0")     # (=0: A/B runs)
+            cfg, splits = plan(m, n, k, mix=True)
             if not (cfg == 28 and splits == 1):
                 cfg, splits = plan(m, n, k)
             if cfg in (20, 22, 28) and splits == 1 and n % (128 if cfg == 20 else 256) == 0:
