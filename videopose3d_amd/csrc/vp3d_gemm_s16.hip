@@ -1130,7 +1130,7 @@ struct TnArgs {
   const float* bound_b;
   int Mk, lda, ldb, NA, NB, taps, c_in;
   uint32_t a_bytes, b_bytes;
-  int m_tiles, n_tiles, pos, splits, kt_per_split;
+  int m_tiles, n_tiles, splits, kt_per_split, per_xcd;
 };
 
 // 8 k values of one column: two transpose reads, `second` bytes (4 rows) apart
@@ -1149,10 +1149,20 @@ __global__ void __launch_bounds__(TN_NT, 2) k_tn_s16(const TnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / 4, wn = w % 4;
-  const int split = blockIdx.x / p.pos;
-  const int bid = blockIdx.x - split * p.pos;
+  // (K slice, tile) units in slice-major order, XCD x (= workgroup id % 8: its own L2) takes the contiguous share
+  // [x * per_xcd, (x + 1) * per_xcd): the units that run side by side on an XCD are tiles of the SAME K slice, which stream the
+  // same operand rows in step, so a row panel is fetched once per XCD for all of them.  (Tile-major shares -- every slice of a
+  // few tiles per XCD -- fetched 680 / 1614 MB for the 231 / 466 MB of the two 27,648-row launches: profiles/r04_step_table.txt.)
+  // Measured against the tile-major shares, same process, shuffled order (profiles/r04_tn_slice_major_ab.txt): the two 27,648-row
+  // launches + their reductions 449 -> 437 and 166 -> 156 us, the step 4.225 -> 4.198 ms; results are bit-identical (the
+  // partial of a (slice, tile) unit does not depend on which workgroup forms it).
   int tile_m, tile_n;
-  if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos >> 3, tile_m, tile_n)) return;
+  const int tiles = p.m_tiles * p.n_tiles;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int u = xcd * p.per_xcd + q;
+  if (q >= p.per_xcd || u >= tiles * p.splits) return;
+  const int split = u / tiles;
+  tile_from_linear(u - split * tiles, p.m_tiles, p.n_tiles, tile_m, tile_n);
   const int na0 = tile_m * TN_BM, nb0 = tile_n * G::BN;
   const int tap = nb0 / p.c_in, ci0 = nb0 - tap * p.c_in;        // a column tile lies inside one tap (C_in % BN == 0)
   const int nkt_all = (p.Mk + TN_BK - 1) / TN_BK;
@@ -1663,11 +1673,12 @@ int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld
   a.Mk = (int)Mk; a.lda = (int)ld_dy; a.ldb = (int)ld_x; a.NA = c_out; a.NB = taps * c_in; a.taps = taps; a.c_in = c_in;
   a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
   a.m_tiles = c_out / TN_BM; a.n_tiles = a.NB / (narrow ? 128 : 256);
-  a.pos = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);
   a.splits = splits;
   a.kt_per_split = (nkt + splits - 1) / splits;
-  if (narrow) hipLaunchKernelGGL(k_tn_s16<1>, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
-  else hipLaunchKernelGGL(k_tn_s16<2>, dim3(a.pos * splits), dim3(TN_NT), 0, s, a);
+  a.per_xcd = (a.m_tiles * a.n_tiles * splits + 7) / 8;            // 8 equal XCD shares of the (slice, tile) units
+  const unsigned grid = 8u * a.per_xcd;
+  if (narrow) hipLaunchKernelGGL(k_tn_s16<1>, dim3(grid), dim3(TN_NT), 0, s, a);
+  else hipLaunchKernelGGL(k_tn_s16<2>, dim3(grid), dim3(TN_NT), 0, s, a);
   return check_launch("wgrad_rows_s16");
 }
 
