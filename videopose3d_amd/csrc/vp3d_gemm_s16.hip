@@ -47,13 +47,6 @@ __device__ __forceinline__ void tile_from_linear(int L, int m_tiles, int n_tiles
     tile_n = full + (r - tile_m * gl);
   }
 }
-__device__ __forceinline__ bool tile_of(int bid, int m_tiles, int n_tiles, int per_xcd, int& tile_m, int& tile_n) {
-  const int xcd = bid & 7, q = bid >> 3;
-  const int L = xcd * per_xcd + q;
-  if (q >= per_xcd || L >= m_tiles * n_tiles) return false;
-  tile_from_linear(L, m_tiles, n_tiles, tile_m, tile_n);
-  return true;
-}
 
 // ---- stream-K (SK instances) -------------------------------------------------------------------------------------------
 // A launch of T tiles on P resident workgroups leaves the last ceil(T/P)-th round partly empty (432 tiles of 256x256 on
@@ -87,10 +80,14 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
 
   const int nkt_all = p.K / BK;
   // ---- work of this workgroup: one (tile, K range) segment, or (stream-K workgroups) a run of them ------------------------
-  // uniform split-K: blockIdx = split * positions + position (the tiles of one K range are dispatched together and
-  // share operand panels in L2); every split writes its raw, scaled partial matrix [M][N] at part + split*part_stride
-  const int split = SK ? 0 : blockIdx.x / p.pos_full;
-  const int bid = blockIdx.x - split * p.pos_full;
+  // uniform split-K: the (K range, tile) units in range-major order, XCD x = blockIdx % 8 takes the contiguous share
+  // [x * per_xcd, (x + 1) * per_xcd) -- the tiles of ONE K range run side by side on an XCD and share its operand panels in that
+  // XCD's L2 (one K range: the tile order of tile_of); every split writes its raw, scaled partial matrix [M][N] at
+  // part + split*part_stride
+  const int bid = blockIdx.x;
+  const int nt_tiles = p.m_tiles * p.n_tiles;
+  const int nt_unit = (bid & 7) * (p.pos_full >> 3) + (bid >> 3);
+  const int split = SK ? 0 : nt_unit / nt_tiles;
   const int sk_T_dp = p.m_tiles * p.n_tiles - p.sk_tiles;           // stream-K: tiles [0, sk_T_dp) run whole
   const int64_t sk_U = (int64_t)p.sk_tiles * nkt_all;
   int sk_rank = 0;
@@ -867,7 +864,8 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
 
   if constexpr (!SK) {
     int tile_m, tile_n;
-    if (!tile_of(bid, p.m_tiles, p.n_tiles, p.pos_full >> 3, tile_m, tile_n)) return;
+    if (nt_unit >= nt_tiles * p.splits) return;        // (the grid is 8 x per_xcd: the last share may be short)
+    tile_from_linear(nt_unit - split * nt_tiles, p.m_tiles, p.n_tiles, tile_m, tile_n);
     const int kt_begin = split * p.kt_per_split;
     run_segment(tile_m, tile_n, kt_begin, min(nkt_all, kt_begin + p.kt_per_split), 0);
   } else {
@@ -1290,15 +1288,15 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   a.m_end = m_end < 0 ? a.M : m_end;
   a.m_tiles = (a.m_end - a.m_begin + C::BM - 1) / C::BM;
   a.n_tiles = (a.N + C::BN - 1) / C::BN;
-  const int positions = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);       // 8 equal XCD shares (tile_of)
+  const int positions = 8 * ((a.m_tiles * a.n_tiles + 7) / 8);       // 8 equal XCD shares
   const int nkt = a.K / C::BKE;
-  a.pos_full = positions;
+  a.pos_full = 8 * ((a.m_tiles * a.n_tiles * splits + 7) / 8);        // grid: 8 equal XCD shares of the (K range, tile) units
   a.tail_pos = 0;
   a.splits = splits;
   a.kt_per_split = (nkt + splits - 1) / splits;
   if (a.epi.act_scale != nullptr) {
     if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && !C::MIX) {          // (instantiated for the planner's configurations only)
-      hipLaunchKernelGGL((k_nt_s16<C, true>), dim3(positions * splits), dim3(C::NT), 0, s, a);
+      hipLaunchKernelGGL((k_nt_s16<C, true>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
       return check_launch("nt_s16(act)");
     } else {
       set_error("nt_s16: the fused activation epilogue exists for tile configurations 20 / 22 / 30 only");
@@ -1317,7 +1315,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
       return VP3D_E_INVALID;
     }
   }
-  hipLaunchKernelGGL((k_nt_s16<C>), dim3(positions * splits), dim3(C::NT), 0, s, a);
+  hipLaunchKernelGGL((k_nt_s16<C>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
   return check_launch("nt_s16");
 }
 
