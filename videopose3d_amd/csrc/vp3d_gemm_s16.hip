@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   // ---- work of this workgroup: one (tile, K range) segment, or (stream-K workgroups) a run of them ------------------------
   // uniform split-K: the (K range, tile) units in range-major order, XCD x = blockIdx % 8 takes the contiguous share
   // [x * per_xcd, (x + 1) * per_xcd) -- the tiles of ONE K range run side by side on an XCD and share its operand panels in that
-  // XCD's L2 (one K range: the tile order of tile_of); every split writes its raw, scaled partial matrix [M][N] at
+  // XCD's L2 (tile_from_linear orders the tiles of a range in compact patches); every split writes its raw, scaled partial matrix [M][N] at
   // part + split*part_stride
   const int bid = blockIdx.x;
   const int nt_tiles = p.m_tiles * p.n_tiles;
