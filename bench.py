@@ -397,7 +397,8 @@ def instrumented(step, ops, n_prof, math):
                  1020: "k_nt_s16<Cfg<2,2,2,2,2,32,0,1>, RED> (128x128 tile dgrad + BatchNorm-backward column sums)",
                  "tn": "k_tn_s16<2> (rows-form weight gradient, 256x256 tile, transpose reads)",
                  "ex": "k_expand_fwd_s16 (expand layer forward: statistics + activation pass)",
-                 "exb": "k_expand_bwd_p_s16 (expand layer backward: P = G^T X from go + bits)"}
+                 "exb": "k_expand_bwd_p_s16 (expand layer backward: P = G^T X from go + bits)",
+                 None: "k_rows_gemm / k_red_gemm (fp32 MFMA kernels: the shrink conv's forward, dgrad and wgrad)"}
         grp = {}
         for r in per_launch:
             g = grp.setdefault(r.get("cfg"), dict(us=0.0, flops=0.0, mb=0.0, n=0.0))
