@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the time of the dgrad-form S16 GEMM (M x 3072 x 1024, residual + amax epilogue) go?  Times the launch with
-the epilogue features toggled, in the planner's configuration and in the plain 256x256 / 128x128 ones (HIP events)."""
+the epilogue features toggled, in the planner's configuration (-1) and in the 224x256 / 256x256 / 128x128 ones (HIP events)."""
 import os
 import sys
 
@@ -35,12 +35,12 @@ def run(bb, t_o, n_taps, c=1024):
     rm = RowMap(bb, t_o, t_o, 1, 0, 0, 1)
     am = S.new_bound(dev)
     flops = 2.0 * m * n_taps * c * c
-    for cfg in (-1, 22, 20):
+    for cfg in (-1, 28, 22, 20):
         line = "M=%6d N=%5d K=%d cfg %3d:" % (m, n_taps * c, c, cfg)
         for tag, use_r, use_am in (("plain", 0, 0), ("amax", 0, 1), ("res", 1, 0), ("res+amax", 1, 1)):
             e = ops._epi(residual=(r, 1, 0, (n_taps // 2) * c), n_cols=n_taps * c) if use_r else None
             us = timeit(lambda: S.gemm_rows(dy, wd, rm, c, c, n_taps * c, dx, n_taps * t_o * c, n_taps * c, epi=e,
-                                            amax_out=am if use_am else None, cfg=cfg, family="tconv_dgrad"))
+                                            amax_out=am if use_am else None, cfg=cfg, family="tconv_dgrad", mix=True))
             line += "  %s %7.1f us %6.1f TF" % (tag, us, flops / us / 1e6)
         print(line, flush=True)
 
