@@ -779,9 +779,64 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
     return;
   }
+  // fp32 residual rows of a 32-row block are fetched BEFORE the block is staged and stored (the mixed tilings: hipcc hoists these
+  // loads itself in the 256-row instance -- residual + 7 us on the 27,648 x 3072 x 1024 dgrad launch -- and leaves them between
+  // the stores of every pass in the 224-row one: + 55 us, tools/dgrad_epi_bench.py; a wave that mixes loads and stores only gets
+  // whole-counter waits).  8 x 4 VGPRs; the K loop's operand registers are dead here.  Its own copy of the row loop (the
+  // vector path only), so that the general loop below keeps its size.
+  bool rows_done = false;
+  if constexpr (C::MIX && !SK) {
+    if (!partial && vec && e.R != nullptr && !e.r_s16) {          // (uniform)
+      constexpr int NPSG = 32 / ERPP;
+      f32x4 rpre[NPSG];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if (i >= rbw) break;
+        // (branch-free: a lane without a residual element reads the first 16 bytes of R and discards them -- with the loads
+        //  under exec branches every one of them waited for its own two row-table reads)
+#pragma unroll
+        for (int ps = 0; ps < NPSG; ++ps) {
+          const int lr = (wm * RB + i) * 32 + ps * ERPP + rr;
+          const int b = tab_b[lr], t = tab_t[lr];
+          const int tr = t * e.r_stride + e.r_off;
+          const bool ok = rcol_ok & (m0 + lr < p.m_end) & (n < Nlim) & ((unsigned)tr < (unsigned)e.r_t);
+          const int64_t off = ok ? (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0 + n : (int64_t)0;
+          const f32x4 x = *reinterpret_cast<const f32x4*>(e.R + off);
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          rpre[ps] = ok ? x : z;
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            wreg[r * WCOLS + j * 32 + cl] = acc[i][j][reg];
+          }
+        epi_stage_sync();
+#pragma unroll
+        for (int ps = 0; ps < NPSG; ++ps) {
+          const int r = ps * ERPP + rr;
+          const int lr = (wm * RB + i) * 32 + r;
+          if (m0 + lr >= p.m_end || n >= Nlim) continue;
+          f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
+          const int b = tab_b[lr], t = tab_t[lr];
+          v += bias;
+          if (e.relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+          }
+          v += rpre[ps];                                // (zeros where there is no residual)
+          *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+        epi_stage_sync();
+      }
+      rows_done = true;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    if (C::MIX && i >= rbw) break;
+    if (rows_done || (C::MIX && i >= rbw)) break;
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
