@@ -779,19 +779,21 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
     return;
   }
-  // fp32 residual rows of a 32-row block are fetched BEFORE the block is staged and stored (the mixed tilings: hipcc hoists these
-  // loads itself in the 256-row instance -- residual + 7 us on the 27,648 x 3072 x 1024 dgrad launch -- and leaves them between
-  // the stores of every pass in the 224-row one: + 55 us, tools/dgrad_epi_bench.py; a wave that mixes loads and stores only gets
-  // whole-counter waits).  8 x 4 VGPRs; the K loop's operand registers are dead here.  Its own copy of the row loop (the
-  // vector path only), so that the general loop below keeps its size.
+  // fp32 residual rows of a 32-row block are fetched BEFORE the block is staged and stored: a wave that mixes loads and stores
+  // only gets whole-counter waits from hipcc, so a residual load between the stores of a pass exposes a load + store latency
+  // per pass.  Left to itself hipcc hoists the loads in some instances and not in others (27,648 x 3072 x 1024 dgrad launch,
+  // residual on a third of the tiles: + 7 us on 256-row tiles, + 55 us on 224-row ones; residual on every tile, N = 1024:
+  // + 51 us on 256-row tiles); with the explicit batch + 9 / + 9 / + 18 us (tools/dgrad_epi_bench.py,
+  // profiles/r04_dgrad_residual_prefetch_ab.txt).  8 x 4 VGPRs, the K loop's operand registers are dead here.  Its own copy of
+  // the row loop (the vector path only), so that the general loop below keeps its size.
   bool rows_done = false;
-  if constexpr (C::MIX && !SK) {
+  if constexpr (!SK) {
     if (!partial && vec && e.R != nullptr && !e.r_s16) {          // (uniform)
       constexpr int NPSG = 32 / ERPP;
       f32x4 rpre[NPSG];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
-        if (i >= rbw) break;
+        if (C::MIX && i >= rbw) break;
         // (branch-free: a lane without a residual element reads the first 16 bytes of R and discards them -- with the loads
         //  under exec branches every one of them waited for its own two row-table reads)
 #pragma unroll
