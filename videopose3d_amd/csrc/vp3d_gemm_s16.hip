@@ -788,24 +788,35 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   // the row loop (the vector path only), so that the general loop below keeps its size.
   bool rows_done = false;
   if constexpr (!SK) {
-    if (!partial && vec && e.R != nullptr && !e.r_s16) {          // (uniform)
+    if (!partial && vec && !e.r_s16) {                            // (uniform)
       constexpr int NPSG = 32 / ERPP;
+      const bool has_res = e.R != nullptr;                        // (uniform)
       f32x4 rpre[NPSG];
+      int bq[NPSG], tq[NPSG];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         if (C::MIX && i >= rbw) break;
-        // (branch-free: a lane without a residual element reads the first 16 bytes of R and discards them -- with the loads
-        //  under exec branches every one of them waited for its own two row-table reads)
+        // the block's row-table entries in one batch (the general loop reads them pass by pass: two dependent LDS round trips
+        // in front of every store)
 #pragma unroll
         for (int ps = 0; ps < NPSG; ++ps) {
           const int lr = (wm * RB + i) * 32 + ps * ERPP + rr;
-          const int b = tab_b[lr], t = tab_t[lr];
-          const int tr = t * e.r_stride + e.r_off;
-          const bool ok = rcol_ok & (m0 + lr < p.m_end) & (n < Nlim) & ((unsigned)tr < (unsigned)e.r_t);
-          const int64_t off = ok ? (int64_t)b * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0 + n : (int64_t)0;
-          const f32x4 x = *reinterpret_cast<const f32x4*>(e.R + off);
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          rpre[ps] = ok ? x : z;
+          bq[ps] = tab_b[lr];
+          tq[ps] = tab_t[lr];
+        }
+        // (branch-free: a lane without a residual element reads the first 16 bytes of R and discards them -- with the loads
+        //  under exec branches every one of them waited for its own two row-table reads)
+        if (has_res) {
+#pragma unroll
+          for (int ps = 0; ps < NPSG; ++ps) {
+            const int lr = (wm * RB + i) * 32 + ps * ERPP + rr;
+            const int tr = tq[ps] * e.r_stride + e.r_off;
+            const bool ok = rcol_ok & (m0 + lr < p.m_end) & (n < Nlim) & ((unsigned)tr < (unsigned)e.r_t);
+            const int64_t off = ok ? (int64_t)bq[ps] * e.r_bpitch + (int64_t)tr * e.r_ld - e.r_col0 + n : (int64_t)0;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(e.R + off);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rpre[ps] = ok ? x : z;
+          }
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j)
@@ -819,17 +830,18 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
         for (int ps = 0; ps < NPSG; ++ps) {
           const int r = ps * ERPP + rr;
           const int lr = (wm * RB + i) * 32 + r;
-          if (m0 + lr >= p.m_end || n >= Nlim) continue;
+          const bool ok = (m0 + lr < p.m_end) & (n < Nlim);
           f32x4 v = *reinterpret_cast<const f32x4*>(wreg + r * WCOLS + c4);
-          const int b = tab_b[lr], t = tab_t[lr];
           v += bias;
           if (e.relu) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
           }
-          v += rpre[ps];                                // (zeros where there is no residual)
-          *reinterpret_cast<f32x4*>(e.C + (int64_t)b * e.c_bpitch + (int64_t)t * e.ldc + n) = v;
-          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          if (has_res) v += rpre[ps];                   // (zeros where there is no residual)
+          if (ok) {
+            *reinterpret_cast<f32x4*>(e.C + (int64_t)bq[ps] * e.c_bpitch + (int64_t)tq[ps] * e.ldc + n) = v;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          }
         }
         epi_stage_sync();
       }
