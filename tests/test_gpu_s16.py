@@ -128,6 +128,41 @@ def test_nt_gemm_exponents_and_residual():
     assert float(((y0.double() * 1e4 - (ref - r[:, 1::2][:, :t].double())).abs() / den).max()) > 1e-3
 
 
+@pytest.mark.parametrize("cfg", [20, 22, 28, 29])
+@pytest.mark.parametrize("bb,t_o,with_res", [(5, 37, True), (3, 100, True), (5, 37, False)])
+def test_dgrad_epilogue_residual_rows_as_a_batch(cfg, bb, t_o, with_res):
+    """The dgrad-form launch of the strided conv (dx[b, 3 t + tap] = dy[b, t] @ Wd_tap, the skip connection's gradient joins
+    at the centre tap: reference common/model.py:191-196 backward) in every tiling: the fp32 epilogue fetches a 32-row block's
+    residual rows and row-table entries in one batch -- ragged row counts (185 / 300 rows against 128- / 160- / 224- / 256-row
+    tiles), three column tiles of which one carries the residual, amax of what was stored; all tilings agree bit for bit (same K
+    order per element)."""
+    from videopose3d_amd._lib import RowMap
+    g = torch.Generator().manual_seed(41)
+    c, taps = 256, 3
+    dy = (torch.randn(bb, t_o, c, generator=g) * 0.3).to(DEV)
+    wd = (torch.randn(taps * c, c, generator=g) * 0.05).to(DEV)
+    r = torch.randn(bb, t_o, c, generator=g).to(DEV)
+    ref = (dy.double().reshape(-1, c) @ wd.double().t()).reshape(bb, t_o, taps * c)
+    den = (dy.double().abs().reshape(-1, c) @ wd.double().abs().t()).reshape(bb, t_o, taps * c) + 1e-30
+    if with_res:
+        ref[:, :, c:2 * c] += r.double()
+    rm = RowMap(bb, t_o, t_o, 1, 0, 0, 1)
+    e = ops._epi(residual=(r, 1, 0, (taps // 2) * c), n_cols=taps * c) if with_res else None
+    outs = {}
+    for cf in (cfg, 22):
+        dx = torch.full((bb, taps * t_o, c), float("nan"), dtype=torch.float32, device=DEV)
+        am = S.new_bound(DEV)
+        S.gemm_rows(S.split(dy), S.split(wd), rm, c, c, taps * c, dx, taps * t_o * c, taps * c, epi=e, amax_out=am, cfg=cf,
+                    splits=1, family="tconv_dgrad", mix=True)
+        got = dx.view(bb, t_o, taps * c)
+        assert bool(torch.isfinite(got).all())
+        err = (got.double() - ref).abs() - (r.double().abs().repeat(1, 1, taps) * 2.0 ** -22 if with_res else 0.0)
+        assert float((err / den).max()) < GEMM_TOL
+        assert float(am.max()) == float(got.abs().max())
+        outs[cf] = got.clone()
+    assert torch.equal(outs[cfg], outs[22])
+
+
 def test_split_join_and_transposed_copy():
     g = torch.Generator().manual_seed(7)
     m, c = 200, 128                                     # ragged: 200 rows -> transposed pitch 256, zero padded
