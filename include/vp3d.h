@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 107
+#define VP3D_VERSION 108
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -504,6 +504,15 @@ int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kp
 int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
                         int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
                         const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw);
+/* The same from the FORWARD's centred second-moment matrix (vp3d_expand_stats_gram_s16's `gram` output, kept until backward):
+ * x_t / ld_t / x_bound name the transposed S16 X whose first column holds the offsets o_k the forward centred with;
+ *   (X^T X)_ij = G_ij + o_i G[one][j] + o_j G[one][i] + M o_i o_j   in fp64 inside the launch
+ * -- the backward then needs no second-moment matrix of its own: vp3d_expand_bwd_p_s16 runs with gram_partials == NULL and
+ * vp3d_sum_slices is not called (x_t == NULL: `gram` is X^T X itself, i.e. vp3d_expand_bwd_s16). */
+int vp3d_expand_bwd_gram_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
+                             int32_t splits, const float* p_partials, const double* gram, const void* x_t, int64_t ld_t,
+                             const float* x_bound, const float* w_packed, const float* scale, const float* mean,
+                             const float* invstd, float* dgamma, float* dbeta, float* dw);
 /* Weight gradient of a (strided) conv straight from S16 ROWS -- no transposed copies: the kernel transposes on the LDS
  * read (ds_read_b64_tr_b16).  Replaces autograd's conv weight gradient (model.py:178-180 backward) like
  * vp3d_tconv_nt_s16 in raw-partials mode does:

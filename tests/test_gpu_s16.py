@@ -1019,3 +1019,58 @@ def test_expand_statistics_from_the_centred_gram_matrix(joints, b, shift, scale)
         unb = var * m / (m - 1)
         assert torch.allclose(bn_b.running_var.double(), 0.9 + 0.1 * unb, rtol=1e-5, atol=1e-7)
     assert int(bn_b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("joints,b,shift,scale,p", [(17, 96, 0.0, 0.5, 0.25), (17, 37, 300.0, 1.0, 0.0), (15, 64, -40.0, 3e-3, 0.5)])
+def test_expand_backward_rebuilds_xtx_from_the_forward_centred_gram(joints, b, shift, scale, p):
+    """vp3d_expand_bwd_gram_s16: the expand layer's backward (dW, dgamma, dbeta from P = G^T X, X^T X and the weights) with X^T X
+    rebuilt in fp64 from the FORWARD's centred second-moment matrix (vp3d_expand_stats_gram_s16's `gram`) + the offsets in the
+    first column of the transposed X, against the same launch fed the exact float64 X^T X of the S16-rounded operands, and
+    against the ride-along form (X^T X accumulated in fp32 inside the P launch + vp3d_sum_slices) -- incl. an input 300 standard
+    deviations away from zero, where the uncentred fp32 products lose what the centred ones keep."""
+    from videopose3d_amd import engine_s16
+    g = torch.Generator().manual_seed(37)
+    c, t = 256, 27
+    c_in = joints * 2
+    spec = ConvSpec(c_in, c, 3, 1, 3)
+    kpad = engine_s16.expand_kpad(spec)
+    kv = 3 * c_in
+    one_col = kv
+    x = (torch.randn(b, t, c_in, generator=g) * scale + shift).to(DEV)
+    w = ((torch.rand(c, c_in, 3, generator=g) * 2 - 1) * 0.1).to(DEV)
+    xb = S.amax(x, floor=1.0)
+    x_rows, x_t = S.im2row_split(x, spec, kpad, one_col, xb, want_t=True)
+    w_packed = ops.pack_weight(w, ld_out=kpad)
+    m = b * spec.t_out(t)
+    bn = torch.nn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+        bn.bias.copy_(torch.linspace(-1, 1, c))
+    coef, gram_c = S.expand_stats_gram(x_t, w_packed, bn, m, kv, one_col, want_gram=True)
+    xr = S.join(x_rows).double().reshape(m, kpad)
+    xx = xr.t() @ xr                                                       # exact X^T X of the S16-rounded rows (incl. the 1 column)
+    # the matrix itself: G + o_i G[one][j] + o_j G[one][i] + M o_i o_j  ==  X^T X
+    o = xr[0].clone()
+    o[one_col] = 0.0
+    g1 = gram_c[one_col]
+    rebuilt = gram_c + o[:, None] * g1[None, :] + o[None, :] * g1[:, None] + float(m) * o[:, None] * o[None, :]
+    assert float(gram_c[one_col, one_col]) == float(m)
+    den_xx = xr.abs().t() @ xr.abs() + 1e-30
+    assert float(((rebuilt - xx).abs() / den_xx)[:kv + 1, :kv + 1].max()) < 1e-6
+    go = (torch.randn(b, spec.t_out(t), c, generator=g) * 1e-3).to(DEV)
+    gb = S.amax(go)
+    bits = torch.randint(0, 256, (m * c // 8,), generator=g, dtype=torch.uint8).to(DEV)
+    ws, n, gram_ride = S.expand_p_from_go(go, gb, bits, p, x_t, want_gram=True)
+    ws2, n2 = S.expand_p_from_go(go, gb, bits, p, x_t, want_gram=False)
+    assert n2 == n and torch.equal(ws, ws2)                                # (P does not depend on the ride-along)
+    args = (w_packed, coef, m, c_in, 3, one_col, False)
+    ideal = S.expand_bwd(None, x_t, xx.contiguous(), *args, partials=(ws, n))
+    ride = S.expand_bwd(None, x_t, gram_ride, *args, partials=(ws, n))
+    cent = S.expand_bwd(None, x_t, gram_c, *args, partials=(ws, n), gram_centred=x_t)
+    for k, name in enumerate(("dW", "dgamma", "dbeta")):
+        ref = ideal[k].double()
+        tol = 2e-6 * float(ref.abs().max())
+        assert float((cent[k].double() - ref).abs().max()) <= tol, name
+        if shift == 0.0:                                                   # (the fp32 ride-along: a sanity bound, on centred data)
+            assert float((ride[k].double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), name
+    assert torch.equal(cent[1], ideal[1]) and torch.equal(cent[2], ideal[2])   # (dgamma / dbeta do not involve X^T X)

@@ -146,6 +146,8 @@ SIGNATURES = {
     "vp3d_sum_slices": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "vp3d_expand_bwd_s16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp]),
+    "vp3d_expand_bwd_gram_s16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp]),
     "vp3d_split_t": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "vp3d_pack_weight_s16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
     "vp3d_amax_multi": (C.c_int, [_vp, _i32, _P(_vp), _P(_i64), _vp]),
@@ -208,8 +210,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 107:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (107); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 108:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (108); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

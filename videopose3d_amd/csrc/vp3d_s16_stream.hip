@@ -735,18 +735,37 @@ __global__ void __launch_bounds__(256) k_expand_bwd_post(int C, int kpad, int kv
                                                          const float* __restrict__ wp, const float* __restrict__ scale,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          double inv_m, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         float* __restrict__ dw) {
+                                                         float* __restrict__ dw, const float* __restrict__ xt, int64_t ld_t,
+                                                         const float* __restrict__ x_bound) {
   extern __shared__ double s_lds[];                    // S rows 0 .. kv-1 ([kv][kpad] doubles), then the block's 8 weight rows
   float* w_s = reinterpret_cast<float*>(s_lds + (size_t)kv * kpad);
   const int cl = threadIdx.x >> 5, jq = threadIdx.x & 31, j0 = jq * 4;
   const int c = blockIdx.x * 8 + cl;
   const bool live = c < C && j0 < kpad;
   // S = X^T X into LDS (the loop below reads every row of it for every channel: from L2 that was 17 dependent batches)
-  {
+  if (xt == nullptr) {
     const int n2 = kv * kpad / 2;                      // double2 units
     const double2* src = reinterpret_cast<const double2*>(S);
     double2* dst = reinterpret_cast<double2*>(s_lds);
     for (int i = threadIdx.x; i < n2; i += 256) dst[i] = src[i];
+  } else {
+    // S is the FORWARD's centred second-moment matrix G (vp3d_expand_stats_gram_s16: G_ij = sum_m (x_i - o_i)(x_j - o_j) with
+    // o_k = X[0][k], the constant-1 column unshifted, so row `one` holds the column sums of the shifted data and G[one][one] = M):
+    //   (X^T X)_ij = G_ij + o_i G[one][j] + o_j G[one][i] + M o_i o_j        (fp64)
+    // -- the backward forms no second-moment matrix of its own (no ride-along MFMAs in the P launch, no vp3d_sum_slices).
+    __shared__ double o_s[128], g1_s[128];
+    if ((int)threadIdx.x < kpad) {
+      const int k = threadIdx.x;
+      const _Float16* g = reinterpret_cast<const _Float16*>(xt + (int64_t)k * ld_t);
+      o_s[k] = k == one ? 0.0 : (double)(((float)g[0] + (float)g[8]) * s16_pow2(s16_exp_of(x_bound)));
+      g1_s[k] = S[(int64_t)one * kpad + k];
+    }
+    __syncthreads();
+    const double m_rows = g1_s[one];
+    for (int i = threadIdx.x; i < kv * kpad; i += 256) {
+      const int r = i / kpad, cc = i - r * kpad;
+      s_lds[i] = S[i] + o_s[r] * g1_s[cc] + o_s[cc] * g1_s[r] + m_rows * o_s[r] * o_s[cc];
+    }
   }
   double P[4] = {0.0, 0.0, 0.0, 0.0};
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1087,14 +1106,17 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
   return check_launch("expand_stats_gram(fin)");
 }
 
-int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
-                        int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
-                        const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw) {
+int vp3d_expand_bwd_gram_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
+                             int32_t splits, const float* p_partials, const double* gram, const void* x_t, int64_t ld_t,
+                             const float* x_bound, const float* w_packed, const float* scale, const float* mean,
+                             const float* invstd, float* dgamma, float* dbeta, float* dw) {
   const int kv = c_in * taps;
   VP3D_REQUIRE(C > 0 && c_in > 0 && taps > 0 && kpad % 4 == 0 && kpad <= 128 && kv < kpad && one_col >= kv && one_col < kpad &&
                    M > 0 && splits > 0 && p_partials && gram && w_packed && scale && mean && invstd && dgamma && dbeta && dw &&
                    aligned16(p_partials),
                "expand_bwd_s16: bad argument (kpad <= 128, a spare padding column for the bias)");
+  VP3D_REQUIRE(x_t == nullptr || (x_bound != nullptr && ld_t >= 16 && aligned16(x_t)),
+               "expand_bwd_gram_s16: the centred form needs the transposed S16 X (its first column holds the offsets) and its bound");
   const size_t lds = (size_t)kv * kpad * sizeof(double) + 8 * 128 * sizeof(float);
   // > 64 KiB of dynamic LDS needs the opt-in, and the attribute is PER DEVICE: one flag per device ordinal (a process that
   // drives several GPUs launches this on each of them); a failed opt-in is reported, not swallowed
@@ -1109,8 +1131,16 @@ int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t t
     attr_set[dev_id] = true;
   }
   hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
-                     splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw);
+                     splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw,
+                     (const float*)x_t, ld_t, x_bound);
   return check_launch("expand_bwd_s16");
+}
+
+int vp3d_expand_bwd_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int32_t taps, int32_t kpad, int32_t one_col, int64_t M,
+                        int32_t splits, const float* p_partials, const double* gram, const float* w_packed,
+                        const float* scale, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw) {
+  return vp3d_expand_bwd_gram_s16(stream, C, c_in, taps, kpad, one_col, M, splits, p_partials, gram, nullptr, 0, nullptr, w_packed,
+                                  scale, mean, invstd, dgamma, dbeta, dw);
 }
 
 int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const float* go, const float* y,

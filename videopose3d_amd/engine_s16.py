@@ -129,13 +129,14 @@ def forward_eval(mod, x3: torch.Tensor) -> torch.Tensor:
 # training (strided model)
 # --------------------------------------------------------------------------------------------------------
 class _Saved:
-    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows", "one_col", "w_packed", "wform", "xin_f32")
+    __slots__ = ("x_t", "y", "coef", "drop", "wd", "t_in", "kpad", "bits", "x_rows", "one_col", "w_packed", "wform", "xin_f32", "gram_fwd")
 
     def __init__(self, x_t, y, coef, drop, wd, t_in, kpad, bits, x_rows=None):
         self.x_t, self.y, self.coef, self.drop, self.wd, self.t_in, self.kpad = x_t, y, coef, drop, wd, t_in, kpad
         self.one_col, self.w_packed = -1, None   # expand layer: bias column of the im2row rows, fp32 weight pack (shortcut)
         self.wform = "tcopy"      # weight-gradient form: "rows" (x_rows), "tcopy" (x_t from the producer), "gather" (x_rows ->
         self.xin_f32 = None       # vp3d_gather_t_s16 in backward); expand layer with an input gradient: fp32 im2row rows
+        self.gram_fwd = None      # expand layer: the forward's centred second-moment matrix of X (float64), for its backward
         self.x_rows = x_rows      # rows-form wgrad (wgrad_from_rows): the layer input as S16 rows instead of x_t
         self.bits = bits          # activation bits ([bn(y) > 0 and kept], 1 bit / element): what backward reads instead
                                   # of regenerating the Philox mask
@@ -375,8 +376,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
                  a_t.data.numel() * 4 < 2 ** 31 and os.environ.get("VP3D_EXPAND_GRAM", "1") != "0")
         if gram0:
             y = None
-            coef = S.expand_stats_gram(a_t, w0_packed, bns[0], m_rows, plan.convs[0].taps * plan.convs[0].c_in, one_col,
-                                       mod._momentum_dev_ptr())
+            coef, gram_fwd = S.expand_stats_gram(a_t, w0_packed, bns[0], m_rows, plan.convs[0].taps * plan.convs[0].c_in, one_col,
+                                                 mod._momentum_dev_ptr(), want_gram=True)
         else:
             y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
                                                                               stat_slab=slab)
@@ -397,6 +398,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
                 saved[0].xin_f32 = xin_f32
             if idx == 0 and one_col >= 0:
                 saved[0].one_col, saved[0].w_packed = one_col, w0_packed
+                # (the centred second-moment matrix of X: the layer's backward rebuilds X^T X from it instead of forming its own)
+                saved[0].gram_fwd = gram_fwd if gram0 else None
                 if S.expand_rows_form(spec.c_out, kpad):
                     saved[0].x_rows = a                  # P = G^T X reads the rows; the transposed copy only feeds X^T X
         if fused0:
@@ -700,7 +703,13 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
         rows0 = L[0].x_rows is not None
         p0 = p if L[0].drop is not None else 0.0
         g0, part0 = None, None
-        if fused_p:                                  # vp3d_expand_bwd_p_s16: G = go * keep * bits is never stored
+        gram_c = None
+        if fused_p and L[0].gram_fwd is not None:
+            # X^T X from the forward's centred second-moment matrix (in the last launch, fp64): no ride-along MFMAs in the
+            # P launch, no vp3d_sum_slices behind it
+            ws0, n0 = S.expand_p_from_go(dh, bounds[0], L[0].bits, p0, L[0].x_t, want_gram=False)
+            part0, gram_xx, gram_c = (ws0, n0), L[0].gram_fwd, L[0].x_t
+        elif fused_p:                                # vp3d_expand_bwd_p_s16: G = go * keep * bits is never stored
             ws0, n0, gram_xx = S.expand_p_from_go(dh, bounds[0], L[0].bits, p0, L[0].x_t, want_gram=True)
             part0 = (ws0, n0)
         else:
@@ -712,7 +721,8 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             o_g = o_bt = None
         m0 = dh.shape[0] * dh.shape[1]
         dw0, dg0, db0 = S.expand_bwd(g0, L[0].x_rows if rows0 else L[0].x_t, gram_xx, L[0].w_packed, L[0].coef, m0, spec0.c_in,
-                                     spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt, partials=part0)
+                                     spec0.taps, L[0].one_col, rows0, out_dw=o_w, out_dgamma=o_g, out_dbeta=o_bt, partials=part0,
+                                     gram_centred=gram_c)
         grads[0], grads[1], grads[2] = sunk(dw0, o_w), sunk(dg0, o_g), sunk(db0, o_bt)
     else:
         dy0, dy0_t = act_bwd(0, dh)

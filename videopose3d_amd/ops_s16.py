@@ -220,11 +220,13 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
 
 
 def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d, m_rows: int, kv: int, one_col: int,
-                      momentum_dev: Optional[int] = None) -> torch.Tensor:
+                      momentum_dev: Optional[int] = None, want_gram: bool = False):
     """[4, C] = scale, shift, mean, invstd of the expand layer's training-mode BatchNorm (running statistics updated in place)
     from the centred second-moment matrix of the layer's 128-column input -- no pass over the conv output
     (vp3d_expand_stats_gram_s16; replaces expand_fwd(stats=...) + ops.bn_finalize).  x_t: the transposed S16 copy of the im2row
-    rows [kpad][pitch]; w_packed: fp32 weight rows [C][kpad]; one_col: the constant-1 padding column of the rows."""
+    rows [kpad][pitch]; w_packed: fp32 weight rows [C][kpad]; one_col: the constant-1 padding column of the rows.
+    want_gram: also return the matrix itself (float64 [kpad][kpad]) -- the backward of the layer rebuilds X^T X from it
+    (expand_bwd(gram_centred=x_t)) instead of forming its own."""
     xd = x_t.data
     kpad, ld_t = xd.shape
     c = bn.num_features
@@ -251,7 +253,7 @@ def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d
                                            bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
                                            buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()),
               "vp3d_expand_stats_gram_s16")
-    return buf
+    return (buf, gram) if want_gram else buf
 
 
 _red_ok = {}
@@ -431,9 +433,12 @@ def expand_p_from_go(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.T
 
 
 def expand_bwd(g: Optional[S16], x: S16, gram_xx: torch.Tensor, w_packed: torch.Tensor, coef: torch.Tensor, m_rows: int, c_in: int,
-               taps: int, one_col: int, rows: bool, out_dw=None, out_dgamma=None, out_dbeta=None, partials=None):
+               taps: int, one_col: int, rows: bool, out_dw=None, out_dgamma=None, out_dbeta=None, partials=None,
+               gram_centred: Optional[S16] = None):
     """(dW [C][c_in][taps], dgamma, dbeta) of the expand layer from G^T X, X^T X and the packed weight (see include/vp3d.h).
-    rows: g [.., C] and x [.., kpad] are S16 rows (vp3d_wgrad_rows_s16); else both are transposed operands [C or kpad][Mp]."""
+    rows: g [.., C] and x [.., kpad] are S16 rows (vp3d_wgrad_rows_s16); else both are transposed operands [C or kpad][Mp].
+    gram_centred: the transposed S16 X when ``gram_xx`` is the FORWARD's centred second-moment matrix (expand_stats_gram's
+    second result) instead of X^T X -- the launch rebuilds X^T X from it in fp64 (vp3d_expand_bwd_gram_s16)."""
     dev = x.data.device
     if partials is not None:                          # (ws, splits) from expand_p_from_go
         ws, splits = partials
@@ -455,10 +460,15 @@ def expand_bwd(g: Optional[S16], x: S16, gram_xx: torch.Tensor, w_packed: torch.
     else:
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         dgam, dbet = dgb[0], dgb[1]
-    check(_lib.lib().vp3d_expand_bwd_s16(ops._stream(), c, c_in, taps, kpad, one_col, m_rows, splits, ws.data_ptr(),
-                                         gram_xx.data_ptr(), w_packed.data_ptr(), coef[0].data_ptr(), coef[2].data_ptr(),
-                                         coef[3].data_ptr(), dgam.data_ptr(), dbet.data_ptr(), dw.data_ptr()),
-          "vp3d_expand_bwd_s16")
+    assert gram_xx.dtype == torch.float64 and gram_xx.shape == (kpad, kpad)
+    xt = gram_centred
+    check(_lib.lib().vp3d_expand_bwd_gram_s16(ops._stream(), c, c_in, taps, kpad, one_col, m_rows, splits, ws.data_ptr(),
+                                              gram_xx.data_ptr(), xt.data.data_ptr() if xt is not None else None,
+                                              xt.data.shape[1] if xt is not None else 0,
+                                              xt.bound_ptr() if xt is not None else None, w_packed.data_ptr(),
+                                              coef[0].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), dgam.data_ptr(),
+                                              dbet.data_ptr(), dw.data_ptr()),
+          "vp3d_expand_bwd_gram_s16")
     return dw, dgam, dbet
 
 
