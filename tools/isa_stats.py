@@ -3,7 +3,8 @@
 
 Splits the .hip_fatbin section into its per-translation-unit bundles, unbundles the gfx950 code objects and prints, per
 kernel: VGPRs / AGPRs / SGPRs, LDS bytes, private-segment (scratch) bytes, spilled registers (from the code-object metadata)
-and the number of scratch_ / v_mfma / buffer_load..lds / ds_read instructions in the disassembly."""
+and the number of scratch_ / v_mfma / buffer_load..lds / ds_read instructions in the disassembly; scr_loop = the scratch
+instructions that lie between the kernel's first and last v_mfma (spills inside the K loop; the others are prologue / epilogue)."""
 import os
 import re
 import subprocess
@@ -42,7 +43,7 @@ with tempfile.TemporaryDirectory() as d:
             m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
             if m:
                 cur = m.group(1)
-                cnt[cur] = dict(scratch=0, mfma=0, ldsdma=0, ds_read=0, insts=0)
+                cnt[cur] = dict(scratch=0, mfma=0, ldsdma=0, ds_read=0, insts=0, first_mfma=-1, last_mfma=-1, scr_at=[])
                 continue
             if cur is None or "\t" not in line:
                 continue
@@ -50,8 +51,12 @@ with tempfile.TemporaryDirectory() as d:
             c["insts"] += 1
             if "scratch_" in line:
                 c["scratch"] += 1
+                c["scr_at"].append(c["insts"])
             if "v_mfma" in line:
                 c["mfma"] += 1
+                if c["first_mfma"] < 0:
+                    c["first_mfma"] = c["insts"]
+                c["last_mfma"] = c["insts"]
             if re.search(r"(buffer|global)_load.* lds", line) or "global_load_lds" in line:
                 c["ldsdma"] += 1
             if "ds_read" in line or "ds_load" in line:
@@ -59,12 +64,14 @@ with tempfile.TemporaryDirectory() as d:
         for name, mt in meta.items():
             rows.append((name, mt, cnt.get(name, {})))
     demangle = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
-    print("%-5s %-5s %-5s %-7s %-8s %-6s %-7s %-6s %-6s %-7s %-7s  %s" % ("vgpr", "agpr", "sgpr", "lds", "scratchB", "vspill", "scr_ins", "mfma", "ldsdma", "ds_read", "insts", "kernel"))
+    print("%-5s %-5s %-5s %-7s %-8s %-6s %-7s %-8s %-6s %-6s %-7s %-7s  %s" % ("vgpr", "agpr", "sgpr", "lds", "scratchB", "vspill", "scr_ins", "scr_loop", "mfma", "ldsdma", "ds_read", "insts", "kernel"))
     tot = 0
     for (name, mt, c), dn in sorted(zip(rows, demangle), key=lambda r: r[1]):
         if flt and flt not in dn:
             continue
         tot += c.get("scratch", 0)
-        print("%-5s %-5s %-5s %-7s %-8s %-6s %-7s %-6s %-6s %-7s %-7s  %s" % (mt["vgpr"], mt["agpr"], mt["sgpr"], mt["lds"], mt["scratch"], mt["spill"],
-                                                                  c.get("scratch", "?"), c.get("mfma", "?"), c.get("ldsdma", "?"), c.get("ds_read", "?"), c.get("insts", "?"), dn[:150]))
+        # scr_loop: scratch instructions BETWEEN the kernel's first and last v_mfma (the K loop); the rest sit in prologue / epilogue
+        in_loop = sum(1 for x in c.get("scr_at", []) if c.get("first_mfma", -1) <= x <= c.get("last_mfma", -1))
+        print("%-5s %-5s %-5s %-7s %-8s %-6s %-7s %-8s %-6s %-6s %-7s %-7s  %s" % (mt["vgpr"], mt["agpr"], mt["sgpr"], mt["lds"], mt["scratch"], mt["spill"],
+                                                                       c.get("scratch", "?"), in_loop, c.get("mfma", "?"), c.get("ldsdma", "?"), c.get("ds_read", "?"), c.get("insts", "?"), dn[:150]))
     print("total scratch instructions: %d" % tot)
