@@ -520,6 +520,30 @@ def test_build_is_gated_by_a_content_hash_not_by_mtimes(tmp_path, monkeypatch):
     assert g._source_hash() != h0                        # the flags are part of the identity
 
 
+def test_no_kernel_spills_inside_its_mfma_loop():
+    """tools/isa_stats.py over the shipped library (no GPU needed): whatever a kernel spills, the scratch instructions lie outside
+    the span between its first and last v_mfma -- the claim DESIGN.md 4.8 / 4.9 makes for the register-tight GEMM instances -- and the
+    total stays small (a regression here means a K loop started paying scratch traffic per iteration)."""
+    import subprocess
+    import sys
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(tools, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump", "llvm-readelf")):
+        pytest.skip("LLVM binutils of the ROCm image not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_stats.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    cols = lines[0].split()
+    i_loop, i_ins, i_mfma = cols.index("scr_loop"), cols.index("scr_ins"), cols.index("mfma")
+    rows = [ln.split(None, len(cols) - 1) for ln in lines[1:] if ln and ln[0].isdigit()]
+    assert len(rows) > 40, "the kernel table looks truncated"
+    gemm = [rw for rw in rows if int(rw[i_mfma]) > 0]
+    assert len(gemm) >= 15
+    for rw in rows:
+        assert int(rw[i_loop]) == 0, "scratch instructions inside the MFMA span of %s" % rw[-1][:120]
+    assert sum(int(rw[i_ins]) for rw in rows) <= 64
+
+
 def test_range_guard_host_logic_without_gpu():
     """The guard never touches a CPU model, parameter loads / .to() ask for a fresh measurement, deep copies build their own state,
     and dp's launcher helpers behave (RCCL channel budget as defaults, core slices disjoint)."""
