@@ -520,6 +520,45 @@ def test_build_is_gated_by_a_content_hash_not_by_mtimes(tmp_path, monkeypatch):
     assert g._source_hash() != h0                        # the flags are part of the identity
 
 
+def test_gemm_unit_order_covers_every_slice_and_tile_once():
+    """The (K slice, tile) -> workgroup mapping of k_tn_s16 / k_nt_s16 (csrc/vp3d_gemm_s16.hip: tile_from_linear + the slice-major
+    XCD shares), restated in Python: for every geometry the grid of 8 x per_xcd workgroups forms each (slice, tile) unit exactly
+    once, the surplus workgroups of the last share return, an XCD's share is contiguous in slice-major order, and a share of
+    whole slices contains every tile of those slices (what lets the tiles of a slice share operand panels in one L2)."""
+    def tile_from_linear(L, m_tiles, n_tiles):
+        gn = min(n_tiles, 8)
+        full = (n_tiles // gn) * gn
+        in_full = m_tiles * full
+        if L < in_full:
+            blk, r = divmod(L, m_tiles * gn)
+            tm = r // gn
+            return tm, blk * gn + (r - tm * gn)
+        gl, r = n_tiles - full, L - in_full
+        tm = r // gl
+        return tm, full + (r - tm * gl)
+
+    for m_tiles, n_tiles, splits in [(4, 4, 16), (4, 12, 5), (4, 12, 16), (1, 1, 1), (1, 3, 4), (124, 12, 1), (58, 4, 1), (20, 4, 3),
+                                     (8, 8, 4), (3, 5, 7), (4, 1, 5), (7, 9, 2), (4, 12, 1)]:
+        tiles = m_tiles * n_tiles
+        units = tiles * splits
+        per_xcd = (units + 7) // 8
+        seen = {}
+        for b in range(8 * per_xcd):
+            xcd, q = b & 7, b >> 3
+            u = xcd * per_xcd + q
+            if u >= units:
+                continue
+            split, L = divmod(u, tiles)
+            tm, tn = tile_from_linear(L, m_tiles, n_tiles)
+            assert 0 <= tm < m_tiles and 0 <= tn < n_tiles and 0 <= split < splits
+            assert (split, tm, tn) not in seen
+            seen[(split, tm, tn)] = xcd
+        assert len(seen) == units
+        if units % 8 == 0 and per_xcd % tiles == 0:        # whole slices per XCD: all tiles of a slice sit on one XCD
+            for split in range(splits):
+                assert len({x for (s_, _, _), x in seen.items() if s_ == split}) == 1
+
+
 def test_no_kernel_spills_inside_its_mfma_loop():
     """tools/isa_stats.py over the shipped library (no GPU needed): whatever a kernel spills, the scratch instructions lie outside
     the span between its first and last v_mfma -- the claim DESIGN.md 4.8 / 4.9 makes for the register-tight GEMM instances -- and the
