@@ -13,13 +13,15 @@ Workload (BASELINE.json `metric`: "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 
 Arithmetic: the headline runs the library default, "f16x3" = split-fp16 operands on v_mfma_f32_32x32x16_f16 with fp32
 accumulation (fp32-class results: 22+ operand bits, exact products; same parity tests and tolerances as the fp32 path);
 the same step on the exact-fp32 MFMA kernels (math "f32", v_mfma_f32_32x32x2_f32) is timed next to it (`f32_mfma`).
-Extra fields in the same JSON line:
+Rank 0 prints ONE JSON line on stdout, <= 2 KB (final_line): the contract's fields + roofline + cpu_baseline + mpjpe_vs_ref +
+f32_mfma + cfg2_eval_fwd.  Everything else measured here (per-launch tables, streaming kernels, per-step timings, drop-in /
+hipGraph / PyTorch-ROCm sections) is written to bench_detail.json next to this file (and to gpurun_out/ when that exists).
+Sections of the record:
   cfg2_eval_fwd : BASELINE.json configs[1] -- TemporalModel eval forward, B=1024, T=243 (5.34 TFLOP / call)
   roofline      : dominant GEMM kernel family of the step, algorithmic FLOPs / HIP-event launch durations
   cpu_baseline  : the reference's CPU path (ATen/oneDNN through oracle/torch_cpu_path.py, kind "port") on this
                   host's cores, bounded sample of the same workload; mpjpe_vs_ref = HIP vs that path on the sample
   rocm_reference_baseline : the same reference path executed by PyTorch-ROCm (MIOpen) on this GPU, B=1024 (N=1 only)
-Rank 0 prints ONE JSON line on stdout.
 """
 import argparse
 import json
@@ -47,6 +49,95 @@ SUSTAINED_F16_MFMA_TFLOPS = 1700.0    # what a bare v_mfma_f32_32x32x16_f16 loop
 ACHIEVABLE_HBM_GBPS = 6300.0           # MI355X_MICROARCH.md: what a streaming kernel sustains of the 8 TB/s HBM3E peak
 FLOP_TRAIN_PER_FRAME = 1023866880     # fwd 352,569,344 + bwd 671,297,536 (conv MACs x 2)
 FLOP_EVAL_PER_FRAME = 5217830912      # TemporalModel forward on a 243-frame window
+
+
+DETAIL_FILE = "bench_detail.json"
+FINAL_LINE_MAX = 2048
+
+
+def _r(v, nd=4):
+    """Round floats for the final line (the side file keeps full precision)."""
+    if isinstance(v, float):
+        return float("%.*g" % (nd + 2, v))
+    return v
+
+
+def final_line(out):
+    """The ONE stdout line the driver parses: <= FINAL_LINE_MAX bytes, exactly the fields of the bench contract (metric .. config,
+    roofline, cpu_baseline) plus the three precision-matched companions.  Everything else `main` measured -- per-launch tables,
+    streaming kernels, per-step timings, the drop-in / hipGraph / PyTorch-ROCm sections and all prose -- goes to DETAIL_FILE
+    (BENCH_r04: a 20 KB line was not parsed by the driver)."""
+    def pick(d, keys):
+        return {k: _r(d[k]) for k in keys if d is not None and k in d}
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "math", "data")}
+    line["config"] = out.get("config")
+    roof = out.get("roofline")
+    if roof:
+        line["roofline"] = pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel",
+                                       "launches_per_step", "avg_launch_ms"))
+        if isinstance(line["roofline"].get("kernel"), str):
+            line["roofline"]["kernel"] = line["roofline"]["kernel"].split(" (")[0]
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    if out.get("mpjpe_vs_ref"):
+        line["mpjpe_vs_ref"] = pick(out["mpjpe_vs_ref"], ("value", "tolerance", "sample_b"))
+    line["step_frac_of_roofline"] = _r(out.get("step_frac_of_roofline"))
+    if out.get("f32_mfma"):
+        line["f32_mfma"] = pick(out["f32_mfma"], ("value", "ms_per_step", "step_frac_of_fp32_mfma_peak"))
+    ev = out.get("cfg2_eval_fwd")
+    if ev:
+        line["cfg2_eval_fwd"] = {"ms": _r(ev["ms"]), "tflops": _r(ev["tflops"]), "frac": _r(ev.get("frac")), "math": ev.get("math")}
+    ev32 = out.get("cfg2_eval_fwd_f32_mfma")
+    if ev32:
+        line["cfg2_eval_fwd_f32_mfma"] = {"ms": _r(ev32["ms"]), "frac": _r(ev32.get("frac"))}
+    ref = out.get("rocm_reference_baseline")
+    if ref and "value" in ref:
+        line["rocm_reference"] = {"value": _r(ref["value"]), "speedup": _r(out.get("speedup_vs_rocm_reference"))}
+    c5 = out.get("cfg5_semi_supervised_step")
+    if c5:
+        line["cfg5_ms"] = pick(c5, ("ms_per_step", "graph_replay_ms_per_step"))
+    if out.get("range_guard") is not None:
+        line["range_guard"] = out["range_guard"]
+    for k in ("value_path", "dry_run", "barrier_to_barrier_s"):
+        if k in out:
+            line[k] = _r(out[k])
+    la = out.get("launcher")
+    if la:
+        line["launcher"] = {"rccl_env": la.get("rccl_env")}
+        if out.get("dry_run"):
+            line["launcher"]["cores_per_rank"] = la.get("cores_per_rank")
+        elif la.get("cores_of_rank0") is not None:
+            line["launcher"]["n_cores_of_rank0"] = len(la["cores_of_rank0"])
+    if "eager" in out:
+        line["eager"] = pick(out["eager"], ("value", "ms_per_step"))
+    line["detail"] = out.get("detail_file")
+    s = json.dumps(line, separators=(",", ":"))
+    for k in ("launcher", "cfg5_ms", "rocm_reference", "cfg2_eval_fwd_f32_mfma", "range_guard", "step_frac_of_roofline"):   # never reached today:
+        if len(s) <= FINAL_LINE_MAX:                                                                           # the contract's
+            break                                                                                              # fields stay
+        line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= FINAL_LINE_MAX, len(s)
+    return s
+
+
+def write_detail(out):
+    """Full measurement record next to bench.py (and under gpurun_out/ when that exists, so that it travels back)."""
+    paths = [os.path.join(ROOT, DETAIL_FILE)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_FILE))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            continue
+    return written
 
 
 def synthetic_batch(batch, gen):
@@ -220,7 +311,9 @@ def cpu_baseline(dev, budget_s=4.0):
     except OSError:
         cpu_name = "?"
     base = dict(value=bsz / dt, unit="frames/s", cores=int(torch.get_num_threads()), kind="port",
-                sample="oracle/torch_cpu_path.py (ATen/oneDNN conv1d/batch_norm/relu + autograd = what the reference "
+                sample="cfg3 train step fwd+bwd (dropout 0.25) on oracle/torch_cpu_path.py (ATen/oneDNN), B=%d, 3 iters x %.1f s, %d threads, %s"
+                       % (bsz, dt, best_t, cpu_name),
+                sample_detail="oracle/torch_cpu_path.py (ATen/oneDNN conv1d/batch_norm/relu + autograd = what the reference "
                        "runs on CPU), TemporalModelOptimized1f arc 3,3,3,3,3 C=1024 train fwd+bwd, BN statistics, dropout 0.25 (the headline's workload), "
                        "B=%d x 243 frames, 3 timed iters after 1 warm-up, %.2f s/iter, %d threads (fastest of a 8,16,.. sweep); "
                        "host: %d logical CPUs (%d usable by this container), %s"
@@ -586,12 +679,18 @@ def dry_run(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": None, "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
-                          "barrier_to_barrier_s": dt,
-                          "launcher": {"rccl_env": {k: os.environ.get(k) for k in dp.RCCL_ENV_DEFAULTS} if world > 1 else None,
-                                       "cores_per_rank": allc}}), flush=True)
+        out = {"metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": None, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
+               "barrier_to_barrier_s": dt,
+               "launcher": {"rccl_env": {k: os.environ.get(k) for k in dp.RCCL_ENV_DEFAULTS} if world > 1 else None,
+                            "cores_per_rank": allc}}
+        if os.environ.get("VP3D_DRY_RUN_DETAIL"):        # CPU test hook: a full-size record (e.g. the committed r04 line) through
+            with open(os.environ["VP3D_DRY_RUN_DETAIL"]) as f:      # the SAME final_line() the GPU run prints
+                big = json.load(f)
+            big.update(out)
+            out = big
+        print(final_line(out), flush=True)
 
 
 def main():
@@ -713,8 +812,7 @@ def main():
     dt = time_steps(step, args.warmup, args.steps, windows=n_windows, do_settle=not args.no_settle, detail=timing)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
-    dtype = ("f32 (products on split-fp16 MFMA: 22+ bit operands, exact fp16 products, fp32 accumulate)" if math == "f16x3"
-             else "f32")
+    dtype = "f16x3 (split-fp16 operands, fp32 accumulate)" if math == "f16x3" else "f32"
 
     out = {
         "metric": "frames/sec (fwd+bwd) 243-frame arc=3,3,3,3,3 B=1024", "value": value, "unit": "frames/s",
@@ -777,6 +875,8 @@ def main():
     # Everything below that runs training steps is executed by EVERY rank: a step contains collectives (the bucketed
     # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.
     out["roofline"], out["kernels"] = instrumented(step, ops, 3, math)
+    from videopose3d_amd import range_guard
+    out["range_guard"] = {k: v for k, v in range_guard.status(model).items() if k in ("tripped", "last", "checks")}
     gemm_ms = sum(v["ms_per_step"] for v in out["kernels"].values())
     out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
 
@@ -871,6 +971,8 @@ def main():
             tf = FLOP_EVAL_PER_FRAME * B / dte / 1e12
             return y, {"workload": "TemporalModel eval forward (BN folded), arc 3,3,3,3,3 C=1024 B=1024 T=243", "math": mth,
                        "ms": dte * 1e3, "frames_per_s": B / dte, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
+                       # fraction of THIS arithmetic's MFMA roofline (north_star: ">= 50 % ... TemporalModel forward at B=1024")
+                       "frac": tf / (PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC_F16X3 if mth == "f16x3" else PEAK_F32_MFMA_TFLOPS),
                        "iters": k_eval, "big_gemm_tflops": [round(f / ms / 1e9, 1) for f, ms in big]}
         y_a, out["cfg2_eval_fwd"] = eval_section(math)
         if math != "f32" and not args.no_f32:
@@ -899,7 +1001,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["detail_file"] = write_detail(out)
+        print(final_line(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -53,3 +53,48 @@ def test_bench_gpus2_self_launch_real_step_two_ranks_on_one_gpu():
     assert out["value_path"] in ("eager", "graph_replay") and out["launcher"]["rccl_env"]["NCCL_MAX_NCHANNELS"] == "8"
     if out["value_path"] == "graph_replay":
         assert out["eager"]["ms_per_step"] >= out["ms_per_step"]
+
+
+def test_final_line_is_short_and_carries_the_contract(tmp_path):
+    """BENCH_r04: the driver could not parse a 20 KB line.  The full-size record of a real run (profiles/r04_bench_line.json, the
+    biggest line this bench ever printed) goes through the SAME final_line() the GPU run prints: the last stdout line must stay
+    under 4096 bytes (bench.py's own bound is 2048), parse, and carry `roofline` and `cpu_baseline` with the contract's keys."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["VP3D_DRY_RUN_DETAIL"] = os.path.join(ROOT, "profiles", "r04_bench_line.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--dry-run"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096 and len(r.stdout) < 4096, (len(last), len(r.stdout))
+    out = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert out["roofline"]["frac"] == pytest.approx(out["roofline"]["achieved"] / out["roofline"]["peak"], rel=1e-3)
+    assert "model" not in out["config"] and "workload" in out["config"]
+
+
+def test_final_line_unit():
+    """final_line() on a hand-made record: bound respected even when every optional section is present and verbose."""
+    sys.path.insert(0, ROOT)
+    import bench
+    big = {"metric": "m", "value": 1.23456789e5, "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 4.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 operands, fp32 accumulate)",
+           "math": "f16x3", "data": "synthetic", "config": {"workload": "w" * 150, "global_batch": 8192, "parallelism": "dp8"},
+           "roofline": {"bound": "mfma", "achieved": 370.0, "peak": 833.3, "unit": "TFLOP/s", "frac": 0.444, "traffic": 6.9e8,
+                        "algorithmic_bytes": 3.9e8, "kernel": "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>> (" + "x" * 500 + ")",
+                        "per_launch": [{"a": 1}] * 500, "note": "n" * 5000},
+           "cpu_baseline": {"value": 338.2, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 900},
+           "mpjpe_vs_ref": {"value": 2.4e-6, "tolerance": 1e-3, "unit": "u" * 300},
+           "f32_mfma": {"value": 1e5, "ms_per_step": 10.2, "step_frac_of_fp32_mfma_peak": 0.65, "roofline": {"x": "y" * 3000}},
+           "cfg2_eval_fwd": {"ms": 13.8, "tflops": 386.0, "frac": 0.463, "math": "f16x3", "workload": "z" * 300},
+           "launcher": {"rccl_env": {"NCCL_MAX_NCHANNELS": "8"}, "cores_of_rank0": list(range(64))},
+           "timing": {"step_ms": [4.0] * 200}}
+    s = bench.final_line(big)
+    assert len(s) <= bench.FINAL_LINE_MAX
+    o = json.loads(s)
+    assert o["roofline"]["kernel"] == "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>>" and "per_launch" not in o["roofline"]
+    assert len(o["cpu_baseline"]["sample"]) <= 160 and o["value"] == pytest.approx(1.23456789e5, rel=1e-5)
