@@ -876,7 +876,8 @@ def main():
     # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.
     out["roofline"], out["kernels"] = instrumented(step, ops, 3, math)
     from videopose3d_amd import range_guard
-    out["range_guard"] = {k: v for k, v in range_guard.status(model).items() if k in ("tripped", "last", "checks")}
+    out["range_guard"] = {k: v for k, v in range_guard.status(model).items() if k in ("tripped", "last", "io_last", "checks", "gram_off", "gram_log2_kappa")}
+    out["range_guard"]["tick_us_per_call"] = round(range_guard.status(model).get("tick_us_per_call", 0.0), 1)
     gemm_ms = sum(v["ms_per_step"] for v in out["kernels"].values())
     out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
 

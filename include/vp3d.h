@@ -724,13 +724,20 @@ int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* g
  * second-moment matrix of X CENTRED at its first row (no E[x^2] - E[x]^2 cancellation; the constant-1 column `one_col` of the
  * rows is not shifted and yields the column sums), `part` = vp3d_expand_stats_gram_groups(M) partial [kpad][kpad] matrices, `gram`
  * = their sum as kpad * kpad doubles; then C quadratic forms in fp64 give exactly vp3d_bn_finalize's outputs (momentum_dev != NULL
- * is read at execution time instead of `momentum`).  w_packed: the fp32 weight rows [C][kpad] (columns >= kv are padding). */
+ * is read at execution time instead of `momentum`).  w_packed: the fp32 weight rows [C][kpad] (columns >= kv are padding).
+ * The matrix carries a relative error of ~4e-9 (exact products, one fp32 accumulator per 64-row slab, fp64 across slabs), which
+ * var_n sees multiplied by kappa_n = sum_ij |w_i Cov_ij w_j| / (var_n + eps) -- large for temporal-difference filters over
+ * correlated keypoint columns.  illcond (device int32, may be NULL; the caller zeroes it when it starts a measurement) receives
+ * atomicMax of floor(log2 kappa_n) over the channels: above VP3D_GRAM_KAPPA_LOG2_MAX the statistics are no longer inside what
+ * the reference's own fp32 conv + BatchNorm leaves (1e-6 sqrt(kappa)) and the caller should use the pass over the conv output
+ * (vp3d_expand_fwd_s16 statistics + vp3d_bn_finalize), which has no such term. */
+#define VP3D_GRAM_KAPPA_LOG2_MAX 16
 int vp3d_expand_stats_gram_groups(int64_t M);
 int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kpad, int32_t kv, int32_t one_col, const void* xt,
                                int64_t ld_t, const float* x_bound, const float* w_packed, float* part, double* gram,
                                const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                               float* save_mean, float* save_invstd);
+                               float* save_mean, float* save_invstd, int32_t* illcond);
 
 /* Guard of the split-fp16 arithmetic (videopose3d_amd/range_guard.py).  The S16 operand format keeps one exponent per
  * tensor, while the reference's BatchNorm affine and conv weights are unconstrained (common/model.py:32,102,113-119): this
@@ -741,6 +748,10 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
  *           (kfac = sqrt(M_l - 1) in training: the activation bound of vp3d_act_bounds_multi per channel; ~4 in eval);
  *   out[1]  tensors i < n_tensors: groups = rows of row_len[i] contiguous floats (Conv1d.weight [C_out][C_in*taps]: output rows).
  * ws: sum(rows) ints of workspace.  At most vp3d_range_max_tensors() layers / tensors. */
+/* The same statistic over the COLUMNS of a row-major [M][C] tensor (C <= 1024): the input batch of model.py:63-77 (C = joints x
+ * features: one hot keypoint column) and the loss gradient at the head (C = joints x 3).  atomicMax-ed into *out; ws = C ints,
+ * zero on entry, left zero. */
+int vp3d_range_cols(vp3d_stream_t stream, int64_t M, int32_t C, const float* x, int64_t ld, int32_t* ws, int32_t* out);
 int vp3d_range_max_tensors(void);
 int vp3d_range_stats(vp3d_stream_t stream, int32_t n_layers, int32_t C, const float* const* gamma, const float* const* beta,
                      const float* kfac, int32_t n_tensors, const float* const* w, const int64_t* rows, const int64_t* row_len,

@@ -1021,6 +1021,92 @@ def test_expand_statistics_from_the_centred_gram_matrix(joints, b, shift, scale)
     assert int(bn_b.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("step,wscale", [(1e-1, 0.1), (1e-2, 0.1), (1e-2, 1.0), (3e-3, 1.0), (1e-3, 1.0), (1e-4, 3.0)])
+def test_expand_statistics_gram_on_correlated_columns_and_difference_filters(step, wscale):
+    """The ill-conditioned case of var_n = W[n]^T Cov(x) W[n] (round-4 advisor finding): real 2D-pose windows are random walks in
+    time (x_{t+1} = x_t + step * noise: adjacent taps of one joint correlate to 1 - step^2 / 2) and trained filters include
+    temporal differences (w = (a, -a, 0), (a, -2a, a)), so var_n is kappa_n = sum |w_i Cov_ij w_j| / (var_n + eps) times smaller
+    than the terms it is the sum of, and every relative error e of the second-moment matrix arrives in invstd as e * kappa_n / 2.
+    The reference (fp32 conv output, then BatchNorm) has its own floor there: the fp32 noise of y is ~6e-8 sqrt(K) of
+    sum |w||x|, i.e. ~1e-6 sqrt(kappa_n) of the normalised output.  Bar: invstd within 2e-5 + 1e-6 sqrt(kappa_n) of float64 -- not
+    worse than what the reference's own arithmetic leaves -- for every channel with kappa_n <= 2^16, AND the kernel must report
+    floor(log2 max kappa) so that range_guard can move the layer to the statistics pass beyond that (GRAM_KAPPA_LOG2_MAX)."""
+    from videopose3d_amd import engine_s16, range_guard
+    g = torch.Generator().manual_seed(77)
+    c, t, b, joints = 256, 27, 64, 17
+    c_in = joints * 2
+    spec = ConvSpec(c_in, c, 3, 1, 3)
+    kpad = engine_s16.expand_kpad(spec)
+    kv = 3 * c_in
+    one_col = kv
+    x0 = torch.randn(b, 1, c_in, generator=g) * 0.4
+    x = (x0 + step * torch.randn(b, t, c_in, generator=g).cumsum(1)).to(DEV)
+    w = torch.zeros(c, c_in, 3)
+    a = (torch.rand(c, c_in, generator=g) * 2 - 1) * wscale
+    w[0::4, :, 0], w[0::4, :, 1] = a[0::4], -a[0::4]                           # first difference
+    w[1::4, :, 0], w[1::4, :, 1], w[1::4, :, 2] = a[1::4], -2 * a[1::4], a[1::4]    # second difference
+    w[2::4] = (torch.rand(c // 4, c_in, 3, generator=g) * 2 - 1) * wscale          # generic
+    w[3::4, :, 1] = a[3::4]                                                      # centre tap only
+    w = w.to(DEV)
+    xb = S.amax(x, floor=1.0)
+    x_rows, x_t = S.im2row_split(x, spec, kpad, one_col, xb, want_t=True)
+    w_packed = ops.pack_weight(w, ld_out=kpad)
+    m = b * spec.t_out(t)
+    bn = torch.nn.BatchNorm1d(c).to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    coef = S.expand_stats_gram(x_t, w_packed, bn, m, kv, one_col, illcond=flag)
+    xr = S.join(x_rows).double().reshape(m, kpad)[:, :kv]
+    wd = w_packed.double()[:, :kv]
+    y = xr @ wd.t()
+    var = y.var(0, unbiased=False)
+    cov = torch.cov(xr.t(), correction=0)
+    kappa = ((wd.abs() @ cov.abs()) * wd.abs()).sum(1) / (var + 1e-5)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    err = (coef[3].double() / invstd - 1).abs()
+    bar = 2e-5 + 1e-6 * kappa.sqrt()
+    ok = kappa <= 2.0 ** range_guard.GRAM_KAPPA_LOG2_MAX
+    worst = int((err / bar * ok).argmax())
+    print("step %g w %g: kappa max 2^%.1f (flag %d), invstd err max %.3g overall; worst guarded channel err %.3g bar %.3g kappa %.3g"
+          % (step, wscale, float(kappa.max().log2()), int(flag), float(err.max()), float(err[worst]), float(bar[worst]),
+             float(kappa[worst])))
+    assert bool((err[ok] <= bar[ok]).all()), (float(err[worst]), float(bar[worst]), float(kappa[worst]))
+    assert abs(int(flag) - int(torch.floor(kappa.max().log2()))) <= 1, (int(flag), float(kappa.max().log2()))
+    err_m = (coef[2].double() - y.mean(0)).abs()
+    assert bool((err_m <= 2e-5 * (y.mean(0).abs() + var.sqrt()) + 1e-6 * (xr.abs() @ wd.abs().t()).mean(0)).all())
+
+
+def test_gram_statistics_fall_back_to_the_pass_over_the_conv_output_when_ill_conditioned():
+    """Model level: difference-type expand filters on random-walk keypoints with kappa > 2^16 -> range_guard reads the kernel's
+    flag CONSUME_AFTER calls after the first periodic measurement, warns once, and the expand layer's statistics come from the
+    pass over the conv output from then on (output then within the fp32 engine's own distance of the float64 oracle)."""
+    from videopose3d_amd import range_guard
+    torch.manual_seed(3)
+    fw = [3, 3, 3]
+    m = V.TemporalModelOptimized1f(17, 2, 17, fw, dropout=0.0, channels=1024).to(DEV).train()
+    m.math = "f16x3"
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(1280, 1, 17, 2, generator=g) * 0.4            # (45 GFLOP forward: above the split-fp16 engine's size threshold)
+    x = (x0 + 1e-4 * torch.randn(1280, 27, 17, 2, generator=g).cumsum(1)).to(DEV)
+    with torch.no_grad():
+        wgt = m.expand_conv.weight
+        a = (torch.rand(1024, 34, generator=g) * 2 - 1).to(DEV) * 3.0
+        wgt[:, :, 0], wgt[:, :, 1], wgt[:, :, 2] = a, -a, 0.0
+    range_guard.invalidate(m)
+    import warnings as _w
+    with _w.catch_warnings(record=True) as rec:
+        _w.simplefilter("always")
+        for _ in range(2 + range_guard.CONSUME_AFTER + 1):
+            m(x)
+        torch.cuda.synchronize()
+    st = range_guard.status(m)
+    assert st["gram_off"] and st["gram_log2_kappa"] >= range_guard.GRAM_KAPPA_LOG2_MAX, st
+    assert sum("ill-conditioned" in str(r.message) for r in rec) == 1
+    assert not st["tripped"]
+    range_guard.invalidate(m)                                  # a re-load measures afresh: the matrix path is tried again
+    m(x)
+    assert not range_guard.status(m)["gram_off"]
+
+
 @pytest.mark.parametrize("joints,b,shift,scale,p", [(17, 96, 0.0, 0.5, 0.25), (17, 37, 300.0, 1.0, 0.0), (15, 64, -40.0, 3e-3, 0.5)])
 def test_expand_backward_rebuilds_xtx_from_the_forward_centred_gram(joints, b, shift, scale, p):
     """vp3d_expand_bwd_gram_s16: the expand layer's backward (dW, dgamma, dbeta from P = G^T X, X^T X and the weights) with X^T X
@@ -1074,3 +1160,51 @@ def test_expand_backward_rebuilds_xtx_from_the_forward_centred_gram(joints, b, s
         if shift == 0.0:                                                   # (the fp32 ride-along: a sanity bound, on centred data)
             assert float((ride[k].double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), name
     assert torch.equal(cent[1], ideal[1]) and torch.equal(cent[2], ideal[2])   # (dgamma / dbeta do not involve X^T X)
+
+
+def test_range_cols_statistic_and_hot_input_joint_trips_the_guard():
+    """vp3d_range_cols: spread of the per-column maxima of a row-major tensor (binary orders between the hottest column and the
+    median one; zero columns left out; ws left zero), and the guard acting on it: an input batch with one joint 2^20 hotter than
+    the others (and, separately, a loss gradient with one hot column) moves the model to the exact-fp32 engine."""
+    import ctypes as C
+    from videopose3d_amd import _lib, engine, range_guard
+    x = torch.rand(4000, 34, device=DEV) + 0.5
+    x[:, 7] *= 2.0 ** 9
+    x[:, 3] = 0.0
+    ws = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    out = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().vp3d_range_cols(ops._stream(), 4000, 34, x.data_ptr(), 34, ws.data_ptr(), out.data_ptr()), "range_cols")
+    assert int(out) in (9, 10) and int(ws.abs().sum()) == 0
+    xs = torch.rand(100, 64, device=DEV)[:, :51]                                  # a strided view: ld = 64
+    out.zero_()
+    _lib.check(_lib.lib().vp3d_range_cols(ops._stream(), 100, 51, xs.data_ptr(), 64, ws.data_ptr(), out.data_ptr()), "range_cols")
+    assert int(out) <= 1
+    keep = dict(engine.S16_MIN_FORWARD_FLOPS)
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})
+    try:
+        import warnings as _w
+        for hot_input in (True, False):
+            torch.manual_seed(1)
+            m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], dropout=0.0, channels=256).to(DEV).train()
+            m.math = "f16x3"
+            xin = (torch.randn(64, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+            tgt = torch.randn(64, 1, 17, 3, device=DEV) * 0.3
+            wgt = torch.ones(1, 1, 17, 1, device=DEV)
+            if hot_input:
+                xin[:, :, 5] *= 2.0 ** 20
+            else:
+                wgt[:, :, 11] = 2.0 ** 20                                          # the loss weighs one joint 2^20 times the others
+            with _w.catch_warnings(record=True) as rec:
+                _w.simplefilter("always")
+                for _ in range(2 * range_guard.CHECK_EVERY + 2 * range_guard.CONSUME_AFTER + 2):
+                    m.zero_grad(set_to_none=True)
+                    (m(xin) * wgt - tgt).abs().mean().backward()
+                    if range_guard.tripped(m):
+                        break
+            st = range_guard.status(m)
+            assert st["tripped"], (hot_input, st)
+            assert (st["io_last"][0] if hot_input else st["io_last"][1]) >= 19, st
+            assert not engine.use_s16(m, 27, True, batch=64)
+            assert sum("dynamic range" in str(r.message) for r in rec) == 1
+    finally:
+        engine.S16_MIN_FORWARD_FLOPS.update(keep)

@@ -593,7 +593,8 @@ def test_range_guard_host_logic_without_gpu():
     e0 = m.__dict__.get("_range_epoch", 0)
     range_guard.tick(m, True, torch.zeros(4, 27, 34))     # CPU tensor: nothing happens, no state
     assert m.__dict__.get("_range_state") is None and not range_guard.tripped(m)
-    assert range_guard.status(m) == dict(tripped=False, last=None, checks=0, sync_checks=0)
+    assert range_guard.status(m) == dict(tripped=False, last=None, checks=0, sync_checks=0, gram_off=False, gram_log2_kappa=None)
+    assert not range_guard.gram_disabled(m) and range_guard.gram_flag(m) is None
     m.load_state_dict(m.state_dict())
     assert m.__dict__["_range_epoch"] == e0 + 1
     m.float()                                              # nn.Module._apply

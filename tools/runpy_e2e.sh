@@ -1,0 +1,104 @@
+#!/bin/bash
+# The reference's UNMODIFIED run.py, end to end on the MI355X, twice: with `from common.model import *` resolved to this
+# package through the import shim (PYTHONPATH) and with the reference's own classes on PyTorch-ROCm.
+# Same synthetic Human3.6M-shaped dataset (tools/make_synth_h36m.py), same command lines, same seeds.
+#
+# The reference checkout is not part of this repository and /root/reference does not exist on the GPU box: the caller stages it
+# as a git-ignored tarball (tools/runpy_stage.sh -> _ref_stage.tgz, deleted after the call); it is unpacked OUTSIDE the
+# repository (/tmp) and only read there.
+#
+#   gpurun -- 'bash tools/runpy_e2e.sh [phases]'   (sup semi supdrop eval steps optc prof; default all)  -> gpurun_out/runpy/*.log   (tools/runpy_summary.py turns them into profiles/r05_runpy_*)
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/runpy
+mkdir -p "$OUT"
+W=/tmp/vp3d_ref
+rm -rf $W && mkdir -p $W && tar xzf "$REPO/_ref_stage.tgz" -C $W || { echo "no staged reference"; exit 1; }
+cd $W/VideoPose3D || exit 1
+sha256sum run.py common/model.py > "$OUT/reference_sha256.txt"
+python "$REPO/tools/make_synth_h36m.py" --reference . > "$OUT/make_synth.log" 2>&1 || { cat "$OUT/make_synth.log"; exit 1; }
+export MIOPEN_USER_DB_PATH=/tmp/miopen_db MIOPEN_LOG_LEVEL=1
+
+one() {   # one <who: ours|ref|refcpu> <name> <run.py args...>
+    who=$1; name=$2; shift 2
+    log="$OUT/${name}_${who}.log"
+    echo "# python run.py $*   [$who]" > "$log"
+    t0=$(date +%s.%N)
+    if [ "$who" = ours ]; then
+        # -X importtime: which file `common.model` came from is on record (stderr), nothing else changes
+        PYTHONPATH="$REPO/videopose3d_amd:$REPO" timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+    elif [ "$who" = refcpu ]; then      # the reference classes on the host's cores (no device visible to torch)
+        CUDA_VISIBLE_DEVICES=-1 HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+    else
+        timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+    fi
+    rc=$?
+    t1=$(date +%s.%N)
+    echo "# exit $rc wall_s $(python -c "print('%.1f' % ($t1 - $t0))")" >> "$log"
+    grep -E "videopose3d_amd\.model|videopose3d_amd\._lib| common\.model" "$OUT/${name}_${who}.err" | sed 's/^/# import: /' >> "$log"
+    grep -v "^import time:" "$OUT/${name}_${who}.err" | tail -20 > "$OUT/${name}_${who}.stderr_tail"
+    rm -f "$OUT/${name}_${who}.err"
+    tail -4 "$log"
+}
+
+PHASES=${*:-sup semi supdrop eval steps optc prof}
+has() { case " $PHASES " in *" $1 "*) return 0;; esac; return 1; }
+SUP="-k synth -arc 3,3,3,3,3 -e 3 -b 1024 -drop 0 --checkpoint-frequency 1"
+SEMI="-k synth -arc 3,3,3 -e 3 -b 1024 -drop 0 -str S1 -sun S5,S6,S7,S8 --warmup 1 --checkpoint-frequency 1"
+if has sup; then for who in ours ref; do
+    one $who sup $SUP -c ck_sup_$who                                  # supervised, cfg3 shape (run.py:398-420), dropout 0: comparable losses
+done; fi
+if has semi; then for who in ours ref; do
+    one $who semi $SEMI -c ck_semi_$who                               # semi-supervised (run.py:322-396): two models + project_to_2d
+done; fi
+# the default command line (dropout 0.25; masks differ between the two, so only rates and loss levels compare)
+if has supdrop; then for who in ours ref; do
+    one $who supdrop -k synth -arc 3,3,3,3,3 -e 2 -b 1024 --checkpoint-frequency 10 -c ck_supdrop_$who
+done; fi
+# --evaluate: each implementation evaluates BOTH checkpoints (state_dict interchange in both directions, run.py:203-210, 652-721).
+# run.py:207 calls torch.load() without weights_only=False on a checkpoint that holds a numpy RandomState (run.py:600-608): torch >= 2.6
+# refuses that for EITHER implementation; TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 is torch's own switch for such scripts.
+if has eval; then
+    for who in ours ref; do
+        [ -f ck_sup_$who/epoch_1.bin ] || one $who evalprep -k synth -arc 3,3,3,3,3 -e 1 -b 1024 -drop 0 --checkpoint-frequency 1 -c ck_sup_$who
+    done
+    export TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1
+    for who in ours ref; do
+        for ck in ours ref; do
+            one $who eval_ck${ck} -k synth -arc 3,3,3,3,3 -c ck_sup_$ck --evaluate epoch_1.bin
+        done
+    done
+    unset TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD
+fi
+# per-STEP loss trajectories out of the unmodified script: one batch per epoch (--subset 0.008: 1,056 training windows, -b 1200), so
+# the `3d_train` figure run.py prints per epoch is the loss of ONE optimizer step; 12 steps with the lr / BatchNorm-momentum
+# schedules of run.py:583-593.  Three executions of the same command: this package, the reference classes on PyTorch-ROCm, the
+# reference classes on the CPU (the distance between the last two is the reference's own implementation-to-implementation noise).
+if has steps; then
+    STEPS="-k synth -arc 3,3,3,3,3 -e 12 -b 1200 --subset 0.008 -drop 0 --no-eval --checkpoint-frequency 100"
+    one ours steps $STEPS -c ck_steps_ours
+    one ref steps $STEPS -c ck_steps_ref
+    one refcpu steps $STEPS -c ck_steps_refcpu
+fi
+# what an epoch costs without run.py's evaluation passes, unmodified vs with the opt-in edits of INTEGRATION.md 3b (device
+# generators + fused loss + fused Adam: tools/runpy_optc_patch.py writes run_optc.py next to run.py)
+if has optc; then
+    python "$REPO/tools/runpy_optc_patch.py" . > "$OUT/optc_patch.log" 2>&1
+    NOEV="-k synth -arc 3,3,3,3,3 -e 3 -b 1024 --no-eval --checkpoint-frequency 100"
+    one ours noeval $NOEV -c ck_ne_ours
+    one ref noeval $NOEV -c ck_ne_ref
+    cp run.py run_unmodified.py && cp run_optc.py run.py
+    one ours optc_noeval $NOEV -c ck_ne_optc
+    one ours optc_sup $SUP -c ck_sup_optc
+    cp run_unmodified.py run.py
+fi
+# kernel-level evidence that the shim run executes this package's HIP kernels: one short epoch under rocprofv3
+if has prof; then
+cd /tmp && export TMPDIR=/tmp
+( cd $W/VideoPose3D && PYTHONPATH="$REPO/videopose3d_amd:$REPO" timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o rp -- \
+    python run.py -k synth -arc 3,3,3,3,3 -e 1 -b 1024 --subset 0.3 --no-eval -c ck_prof > "$OUT/prof_run.log" 2>&1 )
+{ echo "# rocprofv3 --kernel-trace --stats -- python run.py -k synth -arc 3,3,3,3,3 -e 1 -b 1024 --subset 0.3 --no-eval   [ours, import shim]";
+  python "$REPO/tools/prof_summary.py" "$OUT/prof/rp_results.db" 30; } > "$OUT/runpy_kernel_trace_stats.txt" 2>&1
+rm -rf "$OUT/prof"
+fi
+ls -la "$OUT"

@@ -182,7 +182,8 @@ SIGNATURES = {
     "vp3d_adam_step": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _P(Adam)]),
     "vp3d_expand_stats_gram_groups": (C.c_int, [_i64]),
     "vp3d_expand_stats_gram_s16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
-                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_range_cols": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "vp3d_range_max_tensors": (C.c_int, []),
     "vp3d_range_stats": (C.c_int, [_vp, _i32, _i32, _P(_vp), _P(_vp), _P(_f32), _i32, _P(_vp), _P(_i64), _P(_i64), _vp, _i64, _vp]),
 }

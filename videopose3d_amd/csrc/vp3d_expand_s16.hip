@@ -550,9 +550,19 @@ __global__ void __launch_bounds__(EB_NT, 1) k_expand_gram_s16(const ExpandGramAr
   constexpr int NB = NJ * NJ;
   const bool has0 = w < NB, has1 = w + EB_NW < NB;
   const int ia = has0 ? w / NJ : 0, jb = has0 ? w % NJ : 0, ib = has1 ? (w + EB_NW) / NJ : 0;
+  // ACCUMULATION (round 5): var_n = W[n]^T Cov W[n] cancels by kappa_n = sum |w_i w_j Cov_ij| / var_n (temporal-difference filters
+  // over frame-to-frame correlated keypoints: 1e3 .. 1e5), so every relative error of G arrives in var_n times kappa_n.  The products
+  // are exact (all four hi/lo terms; the lo*lo term used to be dropped: a one-sided 2^-22 / 3 on the diagonal); what rounds is the
+  // fp32 accumulator.  It therefore only ever holds ONE 64-row slab -- the twelve small terms first, the four hi*hi terms last --
+  // and is added to fp64 registers after every slab: ~2 * 2^-24 of a slab's sum per slab, independent between the ~M / 64 slabs
+  // -> ~4e-9 of G at the benchmark size (was ~1e-7: 72 fp32 accumulations per group + the dropped term).
   f32x16 acc0, acc1;
+  double dacc0[16], dacc1[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    acc0[r] = acc1[r] = 0.f;
+    dacc0[r] = dacc1[r] = 0.0;
+  }
   const int b_row = cl * EB_ROWB, swz = cl & 15;
   // Centring happens ONCE per element, in place in LDS, before the k-steps read the slab (the first version re-centred every
   // fragment in registers: 24 fragment passes per k-step and workgroup for 4 distinct fragments, 30 us of VALU): thread ->
@@ -616,26 +626,43 @@ __global__ void __launch_bounds__(EB_NT, 1) k_expand_gram_s16(const ExpandGramAr
           frag(sB, ib, ks, bh[ks], bl[ks]);            // (block 0 again when this wave has no second block: unused)
         }
 #pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                 // small terms first: lo*lo, then the two cross terms
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], jl[ks], acc0, 0, 0, 0);
+          if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks], jl[ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], jh[ks], acc0, 0, 0, 0);
           if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks], jh[ks], acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], jl[ks], acc0, 0, 0, 0);
           if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks], jl[ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], jh[ks], acc0, 0, 0, 0);
           if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks], jh[ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                   // this slab's sums leave the fp32 accumulator
+          dacc0[r] += (double)acc0[r];
+          acc0[r] = 0.f;
+          if (has1) {
+            dacc1[r] += (double)acc1[r];
+            acc1[r] = 0.f;
+          }
         }
       }
     }
   }
   ex_wait_vmcnt<0>();
-  const float sg = s16_pow2(2 * s16_exp_of(p.x_bound));
+  const double sg = (double)s16_pow2(2 * s16_exp_of(p.x_bound));
   float* gout = p.part + (int64_t)group * p.kpad * p.kpad;
   if (has0) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      gout[(int64_t)(ia * 32 + r) * p.kpad + jb * 32 + cl] = acc0[reg] * sg;
-      if (has1) gout[(int64_t)(ib * 32 + r) * p.kpad + jb * 32 + cl] = acc1[reg] * sg;
+      gout[(int64_t)(ia * 32 + r) * p.kpad + jb * 32 + cl] = (float)(dacc0[reg] * sg);
+      if (has1) gout[(int64_t)(ib * 32 + r) * p.kpad + jb * 32 + cl] = (float)(dacc1[reg] * sg);
     }
   }
 }

@@ -125,6 +125,46 @@ __global__ void __launch_bounds__(256) k_range_rows_finish(RowsArgs a) {
   if (threadIdx.x == 0) atomicMax(a.out + 1, s);
 }
 
+// ---- per-COLUMN maxima of a row-major [M][C] tensor (the input batch: C = joints x 2 keypoint columns; the loss gradient at the
+// head: C = joints x 3) -> spread of the columns.  One hot column raises the tensor's single S16 exponent exactly as one hot
+// BatchNorm channel does.  Non-negative floats order as their bit patterns: LDS atomicMax per element, one global atomicMax
+// per (block, column); ws [C] ints are zero on entry and zeroed again by the finishing block.
+constexpr int kMaxRangeCols = 1024;
+
+__global__ void __launch_bounds__(256) k_range_cols(const float* __restrict__ x, int64_t M, int C, int64_t ld, int rows_per_block,
+                                                    int32_t* ws) {
+  __shared__ int cmax[kMaxRangeCols];
+  for (int c = threadIdx.x; c < C; c += 256) cmax[c] = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const int64_t n = (r1 - r0) * C;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    float v = fabsf(x[(r0 + r) * ld + c]);
+    if (v != v) v = __int_as_float(0x7f800000);          // nan counts as inf
+    atomicMax(&cmax[c], __float_as_int(v));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256)
+    if (cmax[c] > 0) atomicMax(ws + c, cmax[c]);
+}
+
+__global__ void __launch_bounds__(256) k_range_cols_finish(int C, int32_t* ws, int32_t* out) {
+  __shared__ int hist[512];
+  __shared__ int sh;
+  for (int b = threadIdx.x; b < 512; b += 256) hist[b] = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int e = exp_of(__int_as_float(ws[c]));
+    ws[c] = 0;
+    if (e != kNoExp) atomicAdd(&hist[e + 200], 1);
+  }
+  const int s = spread_from_hist(hist, &sh);
+  if (threadIdx.x == 0) atomicMax(out, s);
+}
+
 }  // namespace
 }  // namespace vp3d
 
@@ -133,6 +173,19 @@ using namespace vp3d;
 extern "C" {
 
 int vp3d_range_max_tensors(void) { return kMaxRangeTensors; }
+
+int vp3d_range_cols(vp3d_stream_t stream, int64_t M, int32_t C, const float* x, int64_t ld, int32_t* ws, int32_t* out) {
+  VP3D_REQUIRE(M > 0 && C > 0 && C <= kMaxRangeCols && x && ld >= C && ws && out, "range_cols: bad argument (at most %d columns)",
+               kMaxRangeCols);
+  int64_t blocks = (M + 63) / 64;
+  if (blocks > 2048) blocks = 2048;
+  const int rows_per_block = (int)((M + blocks - 1) / blocks);
+  blocks = (M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(k_range_cols, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, M, (int)C, ld, rows_per_block, ws);
+  if (int rc = check_launch("range_cols")) return rc;
+  hipLaunchKernelGGL(k_range_cols_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)C, ws, out);
+  return check_launch("range_cols_finish");
+}
 
 int vp3d_range_stats(vp3d_stream_t stream, int32_t n_layers, int32_t C, const float* const* gamma, const float* const* beta,
                      const float* kfac, int32_t n_tensors, const float* const* w, const int64_t* rows, const int64_t* row_len,

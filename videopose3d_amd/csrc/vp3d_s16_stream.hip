@@ -955,7 +955,7 @@ static __global__ void __launch_bounds__(256) k_expand_stats_fin(int C, int kpad
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, float momentum_arg, const float* __restrict__ momentum_dev,
                                                                  float* running_mean, float* running_var, int64_t* nbt, float* scale,
-                                                                 float* shift, float* save_mean, float* save_invstd) {
+                                                                 float* shift, float* save_mean, float* save_invstd, int32_t* illcond) {
   // LDS: S [kv][kpad] doubles (rows 0 .. kv-1 of G, then Cov in place), sv [kpad] (row `one` of G: the column sums), mx [kpad]
   // (mean of x), then the block's 8 weight rows [8][kpad] floats.
   // The kernel is 128 blocks of dependent latency chains, not bandwidth: G and the weights were written by kernels on other XCDs,
@@ -1007,28 +1007,44 @@ static __global__ void __launch_bounds__(256) k_expand_stats_fin(int C, int kpad
   const int cl = tid >> 5, t = tid & 31;
   const int c = blockIdx.x * 8 + cl;
   const float* wr = w_s + cl * kpad;
-  double m_acc = 0.0, v_acc = 0.0;
+  // d_acc = sum_ij |w_i| |Cov_ij| |w_j|: what the relative error of the matrix (~4e-9, k_expand_gram_s16) is multiplied by on its
+  // way into var; kappa = d_acc / (var + eps) is this channel's conditioning (1 for a one-tap filter, ~1e4 for a temporal
+  // difference over frame-to-frame correlated keypoints).  illcond <- max over channels of floor(log2 kappa): the host
+  // (range_guard) moves the layer back to the statistics pass over the conv output when that reaches GRAM_KAPPA_LOG2_MAX.
+  double m_acc = 0.0, v_acc = 0.0, d_acc = 0.0;
   for (int j = t; j < kv; j += 32) {
     const double wj = (double)wr[j];
     m_acc += wj * mx[j];
-    double r0 = 0.0, r1 = 0.0;
+    double r0 = 0.0, r1 = 0.0, a0 = 0.0, a1 = 0.0;
     int i = 0;
     for (; i + 1 < kv; i += 2) {
-      r0 += S[i * kpad + j] * (double)wr[i];
-      r1 += S[(i + 1) * kpad + j] * (double)wr[i + 1];
+      const double s0 = S[i * kpad + j], s1 = S[(i + 1) * kpad + j], w0 = (double)wr[i], w1 = (double)wr[i + 1];
+      r0 += s0 * w0;
+      r1 += s1 * w1;
+      a0 += fabs(s0) * fabs(w0);
+      a1 += fabs(s1) * fabs(w1);
     }
-    if (i < kv) r0 += S[i * kpad + j] * (double)wr[i];
+    if (i < kv) {
+      r0 += S[i * kpad + j] * (double)wr[i];
+      a0 += fabs(S[i * kpad + j]) * fabs((double)wr[i]);
+    }
     v_acc += wj * (r0 + r1);
+    d_acc += fabs(wj) * (a0 + a1);
   }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) {
     m_acc += __shfl_xor(m_acc, o);
     v_acc += __shfl_xor(v_acc, o);
+    d_acc += __shfl_xor(d_acc, o);
   }
   if (t == 0 && c < C) {
     const double mean = m_acc;
     double var = v_acc;
     if (var < 0.0) var = 0.0;
+    if (illcond != nullptr) {
+      const double kappa = d_acc / (var + (double)eps);
+      if (kappa >= 2.0) atomicMax(illcond, kappa < 1e300 ? ilogb(kappa) : 1000);
+    }
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float sc = (float)((double)gamma[c] * invstd);
     save_mean[c] = (float)mean;
@@ -1076,7 +1092,7 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
                                int64_t ld_t, const float* x_bound, const float* w_packed, float* part, double* gram,
                                const float* gamma, const float* beta, float eps, float momentum, const float* momentum_dev,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                               float* save_mean, float* save_invstd) {
+                               float* save_mean, float* save_invstd, int32_t* illcond) {
   VP3D_REQUIRE(M > 1 && M < ((int64_t)1 << 31) && C > 0 && kpad >= 32 && kpad <= 128 && kpad % 32 == 0 && kv > 0 && kv < kpad &&
                    one_col >= kv && one_col < kpad && xt && x_bound && w_packed && part && gram && gamma && beta && scale && shift &&
                    save_mean && save_invstd && aligned16(xt) && aligned16(part) && ld_t >= M && ld_t % 8 == 0 &&
@@ -1102,7 +1118,7 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
   }
   hipLaunchKernelGGL(k_expand_stats_fin, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, (double)M,
                      gram, (const float*)xt, ld_t, x_bound, w_packed, gamma, beta, eps, momentum, momentum_dev, running_mean,
-                     running_var, num_batches_tracked, scale, shift, save_mean, save_invstd);
+                     running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, illcond);
   return check_launch("expand_stats_gram(fin)");
 }
 

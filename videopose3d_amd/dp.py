@@ -12,6 +12,7 @@ sum, which is the ONE exchange step: a single sum all-reduce of a flat fp32 grad
 from __future__ import annotations
 
 import os
+import sys
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -53,7 +54,11 @@ def pin_rank_to_cores(local_rank: int, local_world: int):
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
     Returns (rank, world, local_rank).  A single process without those variables is world 1 (no group).  For world > 1 the
-    RCCL channel budget (RCCL_ENV_DEFAULTS) is put into the environment before the communicator is created."""
+    RCCL channel budget (RCCL_ENV_DEFAULTS) is put into the environment before the communicator is created -- as DEFAULTS
+    (values already in the environment win), announced once on rank 0's stderr because the setting is process-wide (it also
+    caps sync-BN's all_gather, broadcast_parameters and the user's own collectives), and skipped altogether with
+    VP3D_RCCL_CHANNELS=0.  The numbers are a guess with a measured lower bound: 8 resident stand-in workgroups cost the backward
+    GEMMs +14.5 % on one GPU (profiles/r04_cu_hog_interference.txt); real RCCL kernels over xGMI have not been measurable here."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,8 +66,12 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        for k, v in RCCL_ENV_DEFAULTS.items():
-            os.environ.setdefault(k, v)
+        if os.environ.get("VP3D_RCCL_CHANNELS", "1") != "0":
+            for k, v in RCCL_ENV_DEFAULTS.items():
+                os.environ.setdefault(k, v)
+            if rank == 0:
+                print("[videopose3d_amd.dp] RCCL channel budget for this process: %s (VP3D_RCCL_CHANNELS=0 leaves RCCL's own defaults)"
+                      % ", ".join("%s=%s" % (k, os.environ[k]) for k in RCCL_ENV_DEFAULTS), file=sys.stderr, flush=True)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -403,6 +403,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     if saved.get("s16"):
         from . import engine_s16
+        range_guard.measure_head_gradient(mod, gout3)
         return engine_s16.backward_train(mod, saved, gout3, need_dx)
     return _backward_train_f32(mod, saved, gout3, need_dx)
 

@@ -26,7 +26,7 @@ from typing import List
 
 import torch
 
-from . import engine, ops, ops_s16 as S
+from . import engine, ops, ops_s16 as S, range_guard
 from ._lib import RowMap
 from .plan import ConvSpec, StackPlan
 
@@ -373,11 +373,11 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # pass over the transposed copy + per-channel quadratic forms in fp64) instead of a statistics-only pass over the conv
         # output: needs the transposed copy (save) and the constant-1 padding column (one_col)
         gram0 = (dedicated0 and a_t is not None and one_col >= 0 and bns[0].momentum is not None and
-                 a_t.data.numel() * 4 < 2 ** 31 and os.environ.get("VP3D_EXPAND_GRAM", "1") != "0")
+                 a_t.data.numel() * 4 < 2 ** 31 and not range_guard.gram_disabled(mod))
         if gram0:
             y = None
             coef, gram_fwd = S.expand_stats_gram(a_t, w0_packed, bns[0], m_rows, plan.convs[0].taps * plan.convs[0].c_in, one_col,
-                                                 mod._momentum_dev_ptr(), want_gram=True)
+                                                 mod._momentum_dev_ptr(), want_gram=True, illcond=range_guard.gram_flag(mod))
         else:
             y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
                                                                               stat_slab=slab)

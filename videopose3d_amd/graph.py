@@ -173,7 +173,7 @@ class GraphedTrainStep:
         """What selects an entry (one live graph per key) ..."""
         m = self.model
         return (tuple(x.shape), tuple(t.shape), x.device.index, m.math,
-                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]))
+                engine.use_s16(m, x.shape[1], True, batch=x.shape[0]), range_guard.gram_disabled(m))
 
     def _guard(self):
         """... and what invalidates it: the captured launches hold raw device addresses and launch-argument scalars.
@@ -321,7 +321,9 @@ class GraphedStep:
 
     def _key(self, args):
         k = tuple((tuple(a.shape), a.dtype, a.device.index) if torch.is_tensor(a) else a for a in args)
-        return k + tuple((m.math, m.training) for m in self.models)
+        # (the guard's decisions are part of the key: a trip -- or the expand layer's statistics going back to the pass over the
+        #  conv output -- re-captures the step on the other kernels, as in GraphedTrainStep)
+        return k + tuple((m.math, m.training, range_guard.tripped(m), range_guard.gram_disabled(m)) for m in self.models)
 
     def _guard(self):
         g = ()
@@ -384,6 +386,8 @@ class GraphedStep:
         """One step on the arguments; returns what ``fn`` returned (static tensors that the next call overwrites)."""
         if any(torch.is_tensor(a) and not a.is_cuda for a in args) or not next(self.models[0].parameters()).is_cuda:
             raise Vp3dError("GraphedStep runs on the GPU only")
+        for m in self.models:                         # the dynamic-range guard ticks per replay (shape of the capture's warm-up)
+            range_guard.tick_replay(m)
         key = self._key(args)
         e = self._cache.get(key)
         if e is not None and e.guard != self._guard():

@@ -220,13 +220,16 @@ def expand_fwd(x: S16, wt: S16, *, stats=None, act=None) -> Optional[S16]:
 
 
 def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d, m_rows: int, kv: int, one_col: int,
-                      momentum_dev: Optional[int] = None, want_gram: bool = False):
+                      momentum_dev: Optional[int] = None, want_gram: bool = False, illcond: Optional[torch.Tensor] = None):
     """[4, C] = scale, shift, mean, invstd of the expand layer's training-mode BatchNorm (running statistics updated in place)
     from the centred second-moment matrix of the layer's 128-column input -- no pass over the conv output
     (vp3d_expand_stats_gram_s16; replaces expand_fwd(stats=...) + ops.bn_finalize).  x_t: the transposed S16 copy of the im2row
     rows [kpad][pitch]; w_packed: fp32 weight rows [C][kpad]; one_col: the constant-1 padding column of the rows.
     want_gram: also return the matrix itself (float64 [kpad][kpad]) -- the backward of the layer rebuilds X^T X from it
-    (expand_bwd(gram_centred=x_t)) instead of forming its own."""
+    (expand_bwd(gram_centred=x_t)) instead of forming its own.
+    illcond: int32 device scalar that receives max over channels of floor(log2 kappa_n), kappa_n = sum |w_i Cov_ij w_j| /
+    (var_n + eps) -- how ill-conditioned the quadratic form is (range_guard moves the layer back to the statistics pass at
+    GRAM_KAPPA_LOG2_MAX)."""
     xd = x_t.data
     kpad, ld_t = xd.shape
     c = bn.num_features
@@ -251,7 +254,8 @@ def expand_stats_gram(x_t: S16, w_packed: torch.Tensor, bn: torch.nn.BatchNorm1d
                                            bn.running_mean.data_ptr() if track else None,
                                            bn.running_var.data_ptr() if track else None,
                                            bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
-                                           buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr()),
+                                           buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr(),
+                                           illcond.data_ptr() if illcond is not None else None),
               "vp3d_expand_stats_gram_s16")
     return (buf, gram) if want_gram else buf
 

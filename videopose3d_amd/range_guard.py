@@ -11,16 +11,31 @@ sooner from a factor 2^14 on.  The guard keeps the model out of that regime:
 
 * statistic (device, ``vp3d_range_stats``): log2 of (largest / median) of the per-channel activation bound
   ``|gamma_c| * sqrt(M - 1) + |beta_c|`` over every BatchNorm layer, and of the per-output-row maximum of every conv weight;
+* the same spread over the COLUMNS of the two tensors that enter the stack from outside -- the input batch (joints x 2 keypoint
+  columns: one hot joint) at the measured forward, the loss gradient at the head (joints x 3 columns) at that step's backward
+  (``vp3d_range_cols``) -- so that the guard's claim does not rest on the measurement that a hot joint happens to be harmless
+  (tools/range_edges.py: "joint x 10000" stays on the fp32 engine's own error because the hot column dominates both
+  arithmetics alike); limit ``IO_SPREAD_MAX`` = 12;
 * limits: ``ACT_SPREAD_MAX`` = 12 and ``W_SPREAD_MAX`` = 16 binary orders -- below them no element that is within 2^-5 of
   its channel's typical magnitude has lost a bit (activation bounds are ~2^6 loose: 12 + 6 <= 17; weight bounds are
   measured: 16 < 17);
 * action: above a limit the model's calls run on the exact-fp32 engine (``engine.use_s16`` -> False, one warning), until its
   parameters are re-loaded (``load_state_dict`` / ``.to()``) and measure inside the limits again;
 * no host synchronisation in the steady state: the statistic is launched every ``CHECK_EVERY`` calls behind the step's other
-  work, its two integers are copied to pinned host memory and looked at by a LATER call once the copy's event has completed
-  (parameters move by an optimizer step at a time; the limits sit 2^5..2^8 below the first measurable effect).  After
-  ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call measures synchronously (one 8-byte
-  read-back per load, not per step).
+  work, its integers are copied to pinned host memory and looked at exactly ``CONSUME_AFTER`` calls LATER (the copy finished
+  a step ago, so waiting on its event costs nothing -- and, unlike polling the event, every rank of a data-parallel job acts
+  on a measurement at the same step).  Parameters move by an optimizer step at a time; the limits sit 2^5..2^8 below the
+  first measurable effect.  After ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call
+  measures synchronously (one read-back per load, not per step).
+* what it protects is "not worse than the exact-fp32 engine", not "accurate": where BOTH arithmetics lose precision (e.g. every
+  layer's beta at 2^14: gmax ~ 0.1 on either engine, tools/range_edges.py) the model stays on split-fp16.
+
+A third integer rides along: the conditioning of the expand layer's BatchNorm statistics when they are taken from the input's
+second-moment matrix (``vp3d_expand_stats_gram_s16``: var_n = W[n]^T Cov W[n], accurate to ~4e-9 * kappa_n with kappa_n =
+sum |w_i Cov_ij w_j| / (var_n + eps)).  Temporal-difference filters over frame-to-frame correlated keypoints have kappa ~ 1e3..1e5;
+the statistics kernel writes max_n floor(log2 kappa_n) during the training forwards, and at ``GRAM_KAPPA_LOG2_MAX`` (2^16: the
+matrix path's error, 4e-9 * kappa / 2 of invstd, reaches what the reference's own fp32 conv + BatchNorm leaves, 1e-6 sqrt(kappa))
+the layer goes back to the statistics pass over the conv output (no such term; +70 us per step), until the parameters are re-loaded.
 
 ``VP3D_RANGE_GUARD=0`` disables it (tools/range_edges.py measures the raw format that way).
 """
@@ -38,7 +53,10 @@ from ._lib import check
 
 ACT_SPREAD_MAX = 12
 W_SPREAD_MAX = 16
+IO_SPREAD_MAX = 12       # columns of the input batch / of the loss gradient at the head: A operands like the activations
 CHECK_EVERY = 16
+CONSUME_AFTER = 2        # a measurement launched at call n is acted on at call n + CONSUME_AFTER (deterministic across ranks)
+GRAM_KAPPA_LOG2_MAX = 16  # include/vp3d.h: VP3D_GRAM_KAPPA_LOG2_MAX
 EVAL_KFAC = 4.0          # eval: |bn(y)_c| ~ |gamma_c| * |xhat| + |beta_c| with |xhat| of a few standard deviations
 
 
@@ -47,12 +65,22 @@ def enabled() -> bool:
 
 
 class _State:
-    __slots__ = ("device", "out", "host", "event", "ws", "pending", "calls", "epoch", "tripped", "last", "checks", "sync_checks")
+    __slots__ = ("device", "out", "host", "event", "ws", "pending", "calls", "epoch", "tripped", "last", "checks", "sync_checks",
+                 "launched_at", "gram_off", "gram_last", "last_call", "tick_us", "cols_ws", "armed", "io_last")
 
     def __init__(self, device, ws_ints):
         self.device = device
-        self.out = torch.zeros(2, dtype=torch.int32, device=device)
-        self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        # [activation spread, weight-row spread, gram log2 kappa, input-column spread, head-gradient-column spread]
+        self.out = torch.zeros(5, dtype=torch.int32, device=device)
+        self.host = torch.zeros(5, dtype=torch.int32).pin_memory()
+        self.cols_ws = torch.zeros(1024, dtype=torch.int32, device=device)
+        self.armed = False           # the backward of the measured step adds the head gradient's column spread (out[4])
+        self.io_last = None          # (input, head gradient) column spreads of the last consumed measurement
+        self.launched_at = 0
+        self.gram_off = False        # expand-layer statistics back on the pass over the conv output
+        self.gram_last = None        # max floor(log2 kappa) seen by the last consumed measurement
+        self.last_call = None        # (training, batch, frames) of the last eager tick: what a graph replay ticks with
+        self.tick_us = 0.0           # host time spent in tick(), accumulated (bench.py reports it per call)
         self.event = torch.cuda.Event()
         self.ws = torch.empty(max(1, ws_ints), dtype=torch.int32, device=device)
         self.pending = False
@@ -74,12 +102,25 @@ def tripped(mod) -> bool:
     return bool(st is not None and st.tripped and enabled())
 
 
+def gram_disabled(mod) -> bool:
+    """The expand layer's statistics must come from the pass over the conv output (ill-conditioned quadratic forms measured)."""
+    st = mod.__dict__.get("_range_state")
+    return bool(st is not None and st.gram_off and enabled())
+
+
+def gram_flag(mod):
+    """Device int32 scalar the statistics kernel atomicMax-es floor(log2 kappa) into (None before the first guarded call)."""
+    st = mod.__dict__.get("_range_state")
+    return st.out[2:] if st is not None and enabled() else None
+
+
 def status(mod) -> dict:
     st = mod.__dict__.get("_range_state")
     if st is None:
-        return dict(tripped=False, last=None, checks=0, sync_checks=0)
+        return dict(tripped=False, last=None, checks=0, sync_checks=0, gram_off=False, gram_log2_kappa=None)
     return dict(tripped=st.tripped, last=st.last, checks=st.checks, sync_checks=st.sync_checks,
-                limits=(ACT_SPREAD_MAX, W_SPREAD_MAX))
+                limits=(ACT_SPREAD_MAX, W_SPREAD_MAX), io_last=st.io_last, gram_off=st.gram_off, gram_log2_kappa=st.gram_last,
+                tick_us_per_call=st.tick_us / max(1, st.calls + st.sync_checks))
 
 
 def _ptrs(ts):
@@ -89,11 +130,31 @@ def _ptrs(ts):
     return arr
 
 
-def _launch(mod, st: _State, m_rows) -> None:
-    """Enqueue one measurement on the current stream: zero, statistics, 8-byte copy to pinned memory, event."""
+def measure_head_gradient(mod, gout3: torch.Tensor) -> None:
+    """Backward of a step whose forward launched a measurement: column spread of the loss gradient at the head (out[4]; it
+    reaches the host with the NEXT measurement's copy)."""
+    st = mod.__dict__.get("_range_state")
+    if st is None or not st.armed or not enabled() or torch.cuda.is_current_stream_capturing():
+        return
+    st.armed = False
+    from . import ops
+    g = gout3.detach()
+    if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape[-1] <= 1024):
+        return
+    check(_lib.lib().vp3d_range_cols(ops._stream(), g.numel() // g.shape[-1], g.shape[-1], g.data_ptr(), g.shape[-1],
+                                     st.cols_ws.data_ptr(), st.out[4:].data_ptr()), "vp3d_range_cols")
+
+
+def _launch(mod, st: _State, m_rows, x3=None) -> None:
+    """Enqueue one measurement on the current stream: zero, statistics, copy to pinned memory, event."""
     from . import engine, ops
     bns, convs = engine._bns(mod), engine._convs(mod)
-    st.out.zero_()
+    st.out[:2].zero_()                               # (out[2], out[4] accumulate over the steps since the last measurement)
+    st.out[3:4].zero_()
+    if x3 is not None and x3.dtype == torch.float32 and x3.is_contiguous() and x3.shape[-1] <= 1024:
+        check(_lib.lib().vp3d_range_cols(ops._stream(), x3.numel() // x3.shape[-1], x3.shape[-1], x3.data_ptr(), x3.shape[-1],
+                                         st.cols_ws.data_ptr(), st.out[3:].data_ptr()), "vp3d_range_cols")
+        st.armed = True
     lim = int(_lib.lib().vp3d_range_max_tensors())
     stream = ops._stream()
     for lo in range(0, max(len(bns), len(convs)), lim):
@@ -111,21 +172,33 @@ def _launch(mod, st: _State, m_rows) -> None:
                                           (C.c_int64 * max(1, len(rlen)))(*rlen), st.ws.data_ptr(), st.ws.numel(),
                                           st.out.data_ptr()), "vp3d_range_stats")
     st.host.copy_(st.out, non_blocking=True)
+    st.out[2:3].zero_()
+    st.out[4:].zero_()
     st.event.record()
     st.pending = True
+    st.launched_at = st.calls
     st.checks += 1
 
 
 def _consume(mod, st: _State, epoch: int) -> None:
-    a, w = int(st.host[0]), int(st.host[1])
-    st.last, st.pending, st.epoch = (a, w), False, epoch
-    now = a > ACT_SPREAD_MAX or w > W_SPREAD_MAX
+    a, w, xi, go = int(st.host[0]), int(st.host[1]), int(st.host[3]), int(st.host[4])
+    st.last, st.io_last, st.pending, st.epoch = (a, w), (xi, go), False, epoch
+    now = a > ACT_SPREAD_MAX or w > W_SPREAD_MAX or xi > IO_SPREAD_MAX or go > IO_SPREAD_MAX
     if now and not st.tripped:
         warnings.warn("videopose3d_amd: intra-tensor dynamic range outside the split-fp16 format's lossless window "
-                      "(per-channel BatchNorm bound spread 2^%d, limit 2^%d; weight-row spread 2^%d, limit 2^%d): this model "
-                      "now runs on the exact-fp32 engine (math='f32' kernels) until its parameters are re-loaded"
-                      % (a, ACT_SPREAD_MAX, w, W_SPREAD_MAX), RuntimeWarning, stacklevel=3)
+                      "(per-channel BatchNorm bound spread 2^%d, limit 2^%d; weight-row spread 2^%d, limit 2^%d; input / head-gradient "
+                      "column spread 2^%d / 2^%d, limit 2^%d): this model now runs on the exact-fp32 engine (math='f32' kernels) "
+                      "until its parameters are re-loaded"
+                      % (a, ACT_SPREAD_MAX, w, W_SPREAD_MAX, xi, go, IO_SPREAD_MAX), RuntimeWarning, stacklevel=3)
     st.tripped = st.tripped or now                   # sticky within a parameter epoch (tick clears it on a re-load)
+    k = int(st.host[2])
+    st.gram_last = k
+    if k >= GRAM_KAPPA_LOG2_MAX and not st.gram_off:
+        warnings.warn("videopose3d_amd: expand-layer BatchNorm statistics are ill-conditioned as a quadratic form of the input's "
+                      "second-moment matrix (kappa 2^%d, limit 2^%d: difference-type filters over correlated input columns): this "
+                      "model now takes them from a pass over the conv output until its parameters are re-loaded"
+                      % (k, GRAM_KAPPA_LOG2_MAX), RuntimeWarning, stacklevel=3)
+        st.gram_off = True
 
 
 def tick(mod, training: bool, x3: torch.Tensor) -> None:
@@ -133,32 +206,52 @@ def tick(mod, training: bool, x3: torch.Tensor) -> None:
     measure synchronously after an abrupt parameter change, launch the periodic asynchronous measurement."""
     if not enabled() or getattr(mod, "math", "f32") != "f16x3" or not x3.is_cuda:
         return
+    _tick(mod, bool(training), int(x3.shape[0]), int(x3.shape[1]), x3.device, x3)
+
+
+def tick_replay(mod) -> None:
+    """The same for a replay of a captured step whose inputs this module never sees (graph.GraphedStep): ticks with the shape of
+    the model's last eager call (the capture's warm-up)."""
+    st = mod.__dict__.get("_range_state")
+    if st is None or st.last_call is None or not enabled() or getattr(mod, "math", "f32") != "f16x3":
+        return
+    _tick(mod, *st.last_call, st.device)
+
+
+def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
     if torch.cuda.is_current_stream_capturing():
         return                                       # (a captured step is guarded by its replay wrapper: graph.py)
+    import time
+    t0 = time.perf_counter()
     from . import engine, engine_s16
-    if (not engine_s16.supported(mod, x3.shape[1], training, batch=x3.shape[0]) or
-            mod._plan.forward_flops(x3.shape[0], x3.shape[1]) < engine.S16_MIN_FORWARD_FLOPS[bool(training)]):
+    if (not engine_s16.supported(mod, t_in, training, batch=b) or
+            mod._plan.forward_flops(b, t_in) < engine.S16_MIN_FORWARD_FLOPS[bool(training)]):
         return                                       # this call runs on the fp32 kernels anyway
     st: _State = mod.__dict__.get("_range_state")
-    if st is None or st.device != x3.device:
-        st = mod.__dict__["_range_state"] = _State(x3.device, sum(c.weight.shape[0] for c in engine._convs(mod)))
+    if st is None or st.device != device:
+        st = mod.__dict__["_range_state"] = _State(device, sum(c.weight.shape[0] for c in engine._convs(mod)))
+    st.last_call = (training, b, t_in)
     epoch = mod.__dict__.get("_range_epoch", 0)
     m_rows = None
     if training:
         plan = mod._plan
-        t_len = plan.lengths(x3.shape[1])
-        b = x3.shape[0]
+        t_len = plan.lengths(t_in)
         m_rows = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, len(plan.convs))]
     if st.epoch != epoch:
         # abrupt change (construction, load_state_dict, .to()): measure NOW, before an engine is chosen for these parameters
-        st.tripped = False
-        _launch(mod, st, m_rows)
+        st.tripped = st.gram_off = False
+        st.out[2:].zero_()
+        _launch(mod, st, m_rows, x3)
         st.event.synchronize()
         st.sync_checks += 1
         _consume(mod, st, epoch)
+        st.calls = 0                                 # the first periodic measurement follows the first forward (its kappa)
+        st.tick_us += (time.perf_counter() - t0) * 1e6
         return
-    if st.pending and st.event.query():
-        _consume(mod, st, epoch)
     st.calls += 1
-    if not st.tripped and not st.pending and st.calls % CHECK_EVERY == 0:
-        _launch(mod, st, m_rows)
+    if st.pending and st.calls - st.launched_at >= CONSUME_AFTER:
+        st.event.synchronize()                       # recorded CONSUME_AFTER steps ago: complete, nothing to wait for
+        _consume(mod, st, epoch)
+    if not st.tripped and not st.pending and st.calls % CHECK_EVERY == 1:
+        _launch(mod, st, m_rows, x3)
+    st.tick_us += (time.perf_counter() - t0) * 1e6
