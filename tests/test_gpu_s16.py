@@ -7,6 +7,7 @@ import torch
 
 import videopose3d_amd as V
 from videopose3d_amd import ops, ops_s16 as S
+from videopose3d_amd._switches import SW
 from videopose3d_amd.plan import ConvSpec, ResSpec
 from tests.util import unpack_act_bits
 
@@ -471,8 +472,8 @@ def test_wgrad_from_rows_vs_fp64(b, t, c_out, c_in, taps):
 
 
 def test_model_gradients_with_rows_form_wgrad(monkeypatch):
-    """The default (VP3D_WGRAD_ROWS=1): the C x C weight gradients come from vp3d_wgrad_rows_s16 and no transposed copies
-    are written for them; every gradient matches the transposed-copy form (VP3D_WGRAD_ROWS=0) up to summation order."""
+    """The default (_switches.SW["wgrad_rows"]): the C x C weight gradients come from vp3d_wgrad_rows_s16 and no transposed copies
+    are written for them; every gradient matches the transposed-copy form (switch off) up to summation order."""
     import copy
     from videopose3d_amd import engine_s16
     torch.manual_seed(4)
@@ -483,10 +484,10 @@ def test_model_gradients_with_rows_form_wgrad(monkeypatch):
         m._drop_seed, m._drop_calls = 31, 0
     x = (torch.randn(48, 27, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
     tgt = torch.randn(48, 1, 17, 3, device=DEV) * 0.3
-    monkeypatch.setenv("VP3D_WGRAD_ROWS", "0")
+    monkeypatch.setitem(SW, "wgrad_rows", False)
     assert not engine_s16.wgrad_from_rows(256, 256)
     torch.mean(torch.norm(m_a(x) - tgt, dim=3)).backward()
-    monkeypatch.delenv("VP3D_WGRAD_ROWS")
+    monkeypatch.setitem(SW, "wgrad_rows", True)
     assert engine_s16.wgrad_from_rows(256, 256) and not engine_s16.wgrad_from_rows(128, 128)
     y_b = m_b(x)
     torch.mean(torch.norm(y_b - tgt, dim=3)).backward()
@@ -732,7 +733,7 @@ def test_fused_prologue_is_bit_identical(joints, c, arc, monkeypatch):
         sd0 = {k: v.clone() for k, v in m.state_dict().items()}
         res = []
         for fused in ("1", "0"):
-            monkeypatch.setenv("VP3D_PROLOGUE_FUSED", fused)
+            monkeypatch.setitem(SW, "prologue_fused", fused == "1")
             m.load_state_dict(sd0)
             m._drop_calls = 0
             m.zero_grad(set_to_none=True)

@@ -361,10 +361,11 @@ def test_engine_selection_rules(monkeypatch):
     assert engine.use_s16(m, 27, True, batch=1 << 20) and not engine.use_s16(m, 27, True, batch=1)
     # expand operand width and the 32-bit-offset guards
     assert [engine_s16.expand_kpad(ConvSpec(k, 64, 3, 1, 3)) for k in (34, 30, 10, 42)] == [128, 128, 64, 128]
-    monkeypatch.delenv("VP3D_WGRAD_ROWS", raising=False)
+    from videopose3d_amd._switches import SW
+    monkeypatch.setitem(SW, "wgrad_rows", True)
     assert engine_s16.wgrad_from_rows(1024, 1024, 1024 * 243) and not engine_s16.wgrad_from_rows(1024, 1024, 8192 * 243)
     assert not engine_s16.wgrad_from_rows(128, 128, 100)
-    monkeypatch.setenv("VP3D_WGRAD_ROWS", "0")
+    monkeypatch.setitem(SW, "wgrad_rows", False)
     assert not engine_s16.wgrad_from_rows(1024, 1024, 1024)
 
 
@@ -617,3 +618,19 @@ def test_range_guard_host_logic_without_gpu():
     finally:
         os.sched_setaffinity(0, cores)
         torch.set_num_threads(max(1, min(len(cores), 8)))
+
+
+def test_mixed_tilings_are_refused_for_operands_of_2_gib_and_more():
+    """ops_s16.plan(mix=True): the 224- / 160-row tilings address both operands through 32-bit buffer descriptors and have no
+    flat-address twin, so the planner must not hand them out when an operand reaches 2 GiB (round-4 advisor finding: the launch
+    then failed hard where configurations 20 / 22 fall back to 0 / 4) -- and the statistics buffers are sized from the same
+    answer (32- vs 64-row slabs), so the refusal happens at planning time."""
+    from videopose3d_amd import ops_s16 as S
+    from videopose3d_amd._switches import SW
+    assert SW["tile_mix"] == "1"
+    cfg, splits = S.plan(27648, 1024, 3072, mix=True)
+    assert cfg == 28 and splits == 1 and S.stat_slab_rows(cfg, splits) == 32
+    big_m = 8 * 27648                                        # B = 8192 on one GPU: 221,184 x 3072 x 4 B = 2.7 GB
+    cfg, splits = S.plan(big_m, 1024, 3072, mix=True)
+    assert cfg not in (28, 29) and S.stat_slab_rows(cfg, splits) == 64
+    assert S.plan(big_m, 1024, 3072, mix=True) == S.plan(big_m, 1024, 3072, mix=False)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the benchmark training step under an environment knob that the package / the HIP library reads at call
-time:   python tools/env_ab.py VP3D_SOME_KNOB 0 1 [reps] [steps]      (interleaved runs: box-to-box spread does not enter);
+"""Same-process A/B of the benchmark training step under an environment knob that the package reads at call time, or under one
+of its internal switches (videopose3d_amd/_switches.py: `SW:tile_mix`, `SW:wgrad_rows`, ...):
+    python tools/env_ab.py VP3D_SOME_KNOB 0 1 [reps] [steps]      (interleaved runs: box-to-box spread does not enter);
 more than two values: python tools/env_ab.py VP3D_SOME_KNOB 0,1,2,3 - [reps] [steps]."""
 import os
 import sys
@@ -11,6 +12,7 @@ import torch  # noqa: E402
 
 import videopose3d_amd as V  # noqa: E402
 from videopose3d_amd import dp, loss as vloss  # noqa: E402
+from tools.env_ab_lib import set_knob  # noqa: E402
 
 var, values = sys.argv[1], (sys.argv[2].split(",") if sys.argv[3] == "-" else sys.argv[2:4])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
@@ -21,6 +23,7 @@ x = (torch.randn(1024, 243, 17, 2, device=dev) * 0.5).clamp(-1, 1)
 tgt = torch.randn(1024, 1, 17, 3, device=dev) * 0.3
 m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], dropout=0.25, channels=1024).to(dev).train()
 sync = dp.FlatGradSync(m.parameters(), world=1, direct_module=m)
+
 
 
 def step():
@@ -47,7 +50,7 @@ for rep in range(reps):
     order = list(values)
     random.shuffle(order)                            # (no value always runs behind the same neighbour)
     for v in order:
-        os.environ[var] = v
+        set_knob(var, v)
         res[v].append(timed(steps))
 for v in values:
     print("%s=%s: %s  -> min %.3f median %.3f ms / step" % (var, v, " ".join("%.3f" % t for t in res[v]), min(res[v]),

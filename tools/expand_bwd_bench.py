@@ -7,7 +7,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["VP3D_EXPAND_ROWS"] = "1"            # (so that the rows-form P GEMM can be timed next to the default)
+from videopose3d_amd._switches import SW  # noqa: E402
+SW["expand_rows"] = True              # (so that the rows-form P GEMM can be timed next to the default)
 import torch  # noqa: E402
 
 from videopose3d_amd import ops, ops_s16 as S  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of the training-mode FORWARD alone (and of the whole step) of the benchmark configuration under an
-environment knob read at call time:   python tools/fwd_ab.py VP3D_TILE_224 0 1 [reps]"""
+environment knob read at call time or an internal switch:   python tools/fwd_ab.py SW:tile_mix 0 1 [reps]   (VP3D_TILE_224 in rounds 3-4)"""
 import os
 import sys
 import time
@@ -10,6 +10,7 @@ import torch  # noqa: E402
 
 import videopose3d_amd as V  # noqa: E402
 from videopose3d_amd import dp, loss as vloss  # noqa: E402
+from tools.env_ab_lib import set_knob  # noqa: E402
 
 var, values = sys.argv[1], sys.argv[2:4]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
@@ -50,7 +51,7 @@ for name, fn in (("forward only", fwd), ("whole step", step)):
         order = list(values)
         random.shuffle(order)                        # (fixed-order interleaving has position effects: DESIGN.md 4.9)
         for v in order:
-            os.environ[var] = v
+            set_knob(var, v)
             res[v].append(timed(fn))
     for v in values:
         print("%-12s %s=%s: %s  -> min %.3f median %.3f ms" % (name, var, v, " ".join("%.3f" % t for t in res[v]), min(res[v]),

@@ -1,0 +1,22 @@
+"""Internal A/B switches -- test and measurement hooks, not configuration.
+
+Every entry selects between two implementations that are BOTH live in the package (the non-default one serves other
+configurations: narrower models, synchronised BatchNorm, dilated convs, ...).  The parity suite flips them to hold the default
+path bit-for-bit (or to summation order) against its alternative on the same model; the A/B tools under tools/ flip them to time
+both.  They used to be VP3D_* environment variables read at call time (rounds 2-4); the settled ones moved here in round 5 so that
+the environment surface of the package is what a user may actually want to set (README: VP3D_MATH, VP3D_RANGE_GUARD,
+VP3D_OVERLAP, VP3D_S16_MIN_GFLOP, VP3D_FUSE_BN_RED, VP3D_GRAPH_PIECEWISE, VP3D_RCCL_CHANNELS, VP3D_TAIL).
+
+    from videopose3d_amd._switches import SW;  monkeypatch.setitem(SW, "wgrad_rows", False)
+"""
+
+SW = {
+    "wgrad_rows": True,        # C x C weight gradients from the S16 rows (vp3d_wgrad_rows_s16) instead of transposed copies
+    "prologue_fused": True,    # the split-fp16 forward's prologue as two launches (vp3d_prologue_a/b_s16) instead of seven
+    "expand_kernel": True,     # dedicated expand-layer kernels (one-pass input staging, vp3d_expand_fwd_s16, fused P GEMM)
+    "expand_fused": True,      # expand layer: BatchNorm + ReLU + dropout in the GEMM epilogue (its conv output never reaches HBM)
+    "act_bits": True,          # backward reads stored activation bits instead of regenerating the Philox masks
+    "expand_rows": False,      # expand backward's P = G^T X from the S16 rows (measured slower: tools/expand_bwd_bench.py)
+    "tile_mix": "1",           # 224- / 160-row tilings: "0" never, "1" planner decides, "2" / "3" only <= / > 16,384-row launches
+    "fuse_act_bwd": "0",       # fp32 engine: activation backward inside the dgrad epilogue ("1" wherever legal, "auto")
+}

@@ -1570,10 +1570,7 @@ void plan_nt_s16(int M, int N, int K, int allow_split, int raw, int* cfg_out, in
   // workgroups are one 94 %-full round where 192 tiles of 128 x 128 x 4 slices = 1.5 rounds of 512 slots (step 4.275-4.299 ->
   // 4.201-4.232 ms, alternating processes, a temporary knob)
   constexpr bool mix_splits = true;
-  static const bool allow_160 = [] {
-    const char* v = getenv("VP3D_TILE_160");
-    return !(v && v[0] == '0');
-  }();
+  constexpr bool allow_160 = true;
   if (allow_mix && !raw && N % 256 == 0) {
     const bool big = (int64_t)((M + 255) / 256) * (N / 256) >= min_tiles;      // eligibility of the one-slice launches
     static const int kSplits[] = {1, 2, 3, 4, 6, 8};

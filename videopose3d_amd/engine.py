@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from . import ops, range_guard
+from ._switches import SW
 from .plan import ConvSpec, StackPlan
 
 
@@ -244,13 +245,13 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     def sunk(value, out):
         return None if out is not None else value
 
-    # Optional (VP3D_FUSE_ACT_BWD=1 wherever legal, =auto on launches of >= 6 rounds of tiles): the dgrad epilogue that
+    # Optional (_switches.SW["fuse_act_bwd"] = "1" wherever legal, "auto" on launches of >= 6 rounds of tiles): the dgrad epilogue that
     # produces an activation's incoming gradient also runs that activation's backward reduction (vp3d_act_bwd):
     # g = go*keep*[z>0] and the per-slab sums of g / g*xhat come out of the GEMM and the separate HBM pass of
     # vp3d_bn_bwd_reduce disappears.  Measured on MI355X (B=1024 step): the pass it removes (0.27 ms) comes back as
     # epilogue time of the compute-bound GEMM (+0.21 ms everywhere, +0.10 / -0.11 ms in auto mode): 10.19 / 10.17 vs
     # 10.18 ms -- no gain, so the separate kernels stay the default.
-    fuse_mode = os.environ.get("VP3D_FUSE_ACT_BWD", "0")
+    fuse_mode = SW["fuse_act_bwd"]
     sync = mod.__dict__.get("_vp3d_sync_bn")
     if sync is not None or frozen:
         fuse_mode = "0"                              # the fused epilogue reduces with per-replica batch statistics

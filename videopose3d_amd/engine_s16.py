@@ -27,6 +27,7 @@ from typing import List
 import torch
 
 from . import engine, ops, ops_s16 as S, range_guard
+from ._switches import SW
 from ._lib import RowMap
 from .plan import ConvSpec, StackPlan
 
@@ -143,11 +144,11 @@ class _Saved:
 
 
 def wgrad_from_rows(c_out: int, c_in: int, in_rows: int = 0) -> bool:
-    """Default since round 2 (VP3D_WGRAD_ROWS=0 restores the transposed-copy form): the C x C weight gradients read the
+    """Default since round 2 (_switches.SW["wgrad_rows"] = False restores the transposed-copy form): the C x C weight gradients read the
     S16 rows of dy and of the layer input (vp3d_wgrad_rows_s16, channels % 256 == 0) and the producers write no
     transposed copies for them; the expand conv (K-padded im2row operand) and narrower models keep the transposed form."""
     # in_rows: rows of the conv's input (B * T_in): vp3d_wgrad_rows_s16 addresses both operands with 32-bit byte offsets
-    return (os.environ.get("VP3D_WGRAD_ROWS", "1") == "1" and S.wgrad_rows_supported(c_out, c_in) and
+    return (SW["wgrad_rows"] and S.wgrad_rows_supported(c_out, c_in) and
             in_rows * max(c_in, c_out) * 4 < 2 ** 31)
 
 
@@ -189,7 +190,7 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
 # its tail) costs what the 17-30 us pass it replaces does (tools/red_bench.py)
 FUSE_BN_RED_DEFAULT = "auto"
 FUSE_BN_RED_MIN_ROWS = 16384
-TAIL_MAX_ROWS = int(os.environ.get("VP3D_TAIL_MAX_ROWS", "3072"))     # B * T_out up to which a block runs in the persistent tail
+TAIL_MAX_ROWS = 3072     # B * T_out up to which a block runs in the persistent tail
 
 
 def tail_from(mod, plan: StackPlan, t_in0: int, batch: int, sync, save: bool) -> int:
@@ -267,22 +268,22 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         sync.begin_step(b, dev)
 
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
-    use_bits = save and os.environ.get("VP3D_ACT_BITS", "1") != "0"
+    use_bits = save and SW["act_bits"]
     # the trailing small-M blocks as ONE persistent launch per direction (tail_from); backward reads activation bits
     tail0 = tail_from(mod, plan, x3.shape[1], b, sync, save) if (use_bits or not save) else 0
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
-    fuse_expand = (os.environ.get("VP3D_EXPAND_FUSED", "1") != "0" and sync is None and not need_dx and
+    fuse_expand = (SW["expand_fused"] and sync is None and not need_dx and
                    (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1], x3.shape[0]) and
                    not (tail0 == 1 and save))           # (a tail that starts at conv 1 reads the expand output's transposed copy)
     kpad = expand_kpad(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
     t_in0 = x3.shape[1]
     rows0 = x3.shape[0] * plan.convs[0].t_out(t_in0)
-    one_pass_input = not (save and need_dx) and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and rows0 <= 65535 * 64
+    one_pass_input = not (save and need_dx) and SW["expand_kernel"] and rows0 <= 65535 * 64
     # The whole prologue as TWO launches (S.prologue_a: every maximum + the activation bounds; S.prologue_b: input staging +
     # all weight packs) instead of seven dependent ones: the benchmark configuration's shape of the stack (strided convs of
     # <= 3 taps) with the one-pass input staging, per-replica BatchNorm; everything else keeps the separate launches below
-    fused_prologue = (one_pass_input and os.environ.get("VP3D_PROLOGUE_FUSED", "1") != "0" and sync is None and n_layers > 1 and
+    fused_prologue = (one_pass_input and SW["prologue_fused"] and sync is None and n_layers > 1 and
                       n_layers <= 15 and kpad <= 128 and
                       all(sp.stride == sp.taps and sp.dil == 1 and sp.taps <= 3 for sp in plan.convs[1:]) and
                       all(c_.weight.shape[:2] == convs[1].weight.shape[:2] for c_ in convs[1:]))
@@ -367,7 +368,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
         # the conv output never goes to HBM (its backward, expand_bwd, needs no y either)
         fused0 = idx == 0 and fuse_expand and n_layers > 1
-        dedicated0 = (fused0 and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
+        dedicated0 = (fused0 and SW["expand_kernel"] and
                       m_rows * kpad * 4 < 2 ** 31)                                     # vp3d_expand_fwd_s16 (32-bit byte offsets)
         # expand layer statistics from the centred second-moment matrix of its 128-column input (S.expand_stats_gram: one MFMA
         # pass over the transposed copy + per-channel quadratic forms in fp64) instead of a statistics-only pass over the conv
@@ -512,7 +513,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     gram_xx, gram_ev = None, None
     # (with the dedicated kernel X^T X rides along in the P = G^T X launch at the end of backward: no GEMM of its own)
     # (vp3d_expand_bwd_p_s16 addresses go and the transposed X with 32-bit byte offsets: M * C * 4 and kpad * ld_t * 4 < 2 GiB)
-    fused_p = (L[0].one_col >= 0 and L[0].x_rows is None and os.environ.get("VP3D_EXPAND_KERNEL", "1") != "0" and
+    fused_p = (L[0].one_col >= 0 and L[0].x_rows is None and SW["expand_kernel"] and
                L[0].bits is not None and L[0].bits.numel() * 32 < 2 ** 31 and
                L[0].x_t is not None and L[0].x_t.data.numel() * 4 < 2 ** 31)
     if L[0].one_col >= 0 and not fused_p:

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import RowMap, S16Opts, check
+from ._switches import SW
 from .plan import ConvSpec, ResSpec
 
 
@@ -68,14 +69,17 @@ def split(t: torch.Tensor, bound: Optional[torch.Tensor] = None, measure: bool =
 
 
 _plan_cache = {}
-# VP3D_TILE_224=0: the planner never picks the 224 x 256 tiling (read per call: tools/env_ab.py interleaves both)
+# _switches.SW["tile_mix"] = "0": the planner never picks the 224- / 160-row tilings (read per call: tools/env_ab.py SW:tile_mix 0 1)
 
 
 def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False) -> Tuple[int, int]:
     """(tile configuration, K slices) of an [m, n, k] split-fp16 GEMM.  mix: configuration 28 (224 x 256 tiles: statistics in
     32-row slabs, no fused activation / BatchNorm-backward sums) may be chosen."""
-    mode = os.environ.get("VP3D_TILE_224", "1")       # (2 / 3: only launches of at most / more than 16,384 rows -- A/B runs)
+    mode = SW["tile_mix"]                             # (2 / 3: only launches of at most / more than 16,384 rows -- A/B runs)
     mix = bool(mix and mode != "0" and not (mode == "2" and m > 16384) and not (mode == "3" and m <= 16384))
+    # the mixed tilings address both operands through 32-bit buffer descriptors and have no flat-address twin: not for operands
+    # of 2 GiB and more (the statistics buffers are sized from this answer, so the refusal has to happen here, not at launch)
+    mix = mix and m * k * 4 < 2 ** 31 and n * k * 4 < 2 ** 31
     key = (m, n, k, raw, mix)
     hit = _plan_cache.get(key)
     if hit is None:
@@ -267,7 +271,7 @@ def red_cfg(m: int, n: int, k: int, c_up: int) -> int:
     """Tile configuration in which a dgrad launch [m, n, k] can carry the BatchNorm-backward column sums of its upstream
     activation (vp3d_s16_red), or 0: one K slice on the 128 x 128 / 256 x 256 / 224 x 256 buffer-descriptor tilings (20 / 22 /
     28), whole column tiles.  (Cached: asked per launch.)"""
-    key = (m, n, k, c_up, os.environ.get("VP3D_TILE_224", "1"))
+    key = (m, n, k, c_up, SW["tile_mix"])
     hit = _red_ok.get(key)
     if hit is None:
         hit = 0
@@ -404,10 +408,10 @@ def gram(x_t: S16) -> torch.Tensor:
 
 def expand_rows_form(c_out: int, kpad: int) -> bool:
     """P = G^T X straight from the S16 rows (k_tn_s16<1>, the narrow-B form of the rows-form weight gradient) instead of
-    from transposed copies.  Opt-in (VP3D_EXPAND_ROWS=1): measured SLOWER than the NT GEMM on transposed copies for this
+    from transposed copies.  Opt-in (_switches.SW["expand_rows"]): measured SLOWER than the NT GEMM on transposed copies for this
     shape (M 82,944 x 1024 x 128 stand-alone: 137 us vs 110 us, tools/expand_bwd_bench.py) -- with a 128-column B tile
     the kernel issues 20 transpose reads per 12 MFMAs and is LDS-bound."""
-    return os.environ.get("VP3D_EXPAND_ROWS", "0") == "1" and kpad == 128 and c_out % 256 == 0
+    return SW["expand_rows"] and kpad == 128 and c_out % 256 == 0
 
 
 def expand_p_from_go(go: torch.Tensor, go_bound: torch.Tensor, act_bits: torch.Tensor, p: float, x_t: S16, want_gram: bool = False):
