@@ -151,19 +151,28 @@ def mpjpe(pred, target):                                                        
     return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))
 
 
-PMC_JSON = {"f32": os.path.join(ROOT, "profiles", "r04f32_pmc_traffic.json"),
-            "f16x3": os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")}
+def _latest(*names):
+    """The newest committed collection of a profile that exists (tools/profile_round.sh <tag> writes <tag>_*)."""
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", names[-1])
+
+
+PMC_JSON = {"f32": _latest("r05f32_pmc_traffic.json", "r04f32_pmc_traffic.json"),
+            "f16x3": _latest("r05_pmc_traffic.json", "r04_pmc_traffic.json")}
 FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"},
                   # one kernel serves all three GEMM forms of the split-fp16 path (all are "NT")
                   "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
-STEP_TABLE_JSON = {"f16x3": os.path.join(ROOT, "profiles", "r04_step_table.json"),
-                   "f32": os.path.join(ROOT, "profiles", "r04f32_step_table.json")}
+STEP_TABLE_JSON = {"f16x3": _latest("r05_step_table.json", "r04_step_table.json"),
+                   "f32": _latest("r05f32_step_table.json", "r04f32_step_table.json")}
 
 
 def pmc_traffic(family, math):
-    """Per-launch table first (profiles/r04_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
+    """Per-launch table first (profiles/r05_step_table.json: every GEMM launch of the step with its own FETCH_SIZE x2 +
     WRITE_SIZE): the family's traffic is the mean over ITS launches, comparable with `algorithmic_bytes`; else the
     per-kernel-template means of the older profile."""
     path = STEP_TABLE_JSON.get(math)

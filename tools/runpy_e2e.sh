@@ -18,19 +18,24 @@ cd $W/VideoPose3D || exit 1
 sha256sum run.py common/model.py > "$OUT/reference_sha256.txt"
 python "$REPO/tools/make_synth_h36m.py" --reference . > "$OUT/make_synth.log" 2>&1 || { cat "$OUT/make_synth.log"; exit 1; }
 export MIOPEN_USER_DB_PATH=/tmp/miopen_db MIOPEN_LOG_LEVEL=1
+# run.py never seeds torch (its parameter init differs from process to process), so loss TRAJECTORIES of two executions only
+# compare when the seed comes from outside: a `usercustomize` module on PYTHONPATH (imported by `site` at interpreter start-up,
+# before run.py's first line) calls torch.manual_seed.  Only the runs that say SEEDHOOK=1 use it.
+mkdir -p $W/seedhook && printf 'import torch\ntorch.manual_seed(1234)\n' > $W/seedhook/usercustomize.py
 
 one() {   # one <who: ours|ref|refcpu> <name> <run.py args...>
     who=$1; name=$2; shift 2
     log="$OUT/${name}_${who}.log"
     echo "# python run.py $*   [$who]" > "$log"
     t0=$(date +%s.%N)
+    hook=""; [ "${SEEDHOOK:-0}" = 1 ] && hook=":$W/seedhook"
     if [ "$who" = ours ]; then
         # -X importtime: which file `common.model` came from is on record (stderr), nothing else changes
-        PYTHONPATH="$REPO/videopose3d_amd:$REPO" timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+        PYTHONPATH="$REPO/videopose3d_amd:$REPO$hook" timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
     elif [ "$who" = refcpu ]; then      # the reference classes on the host's cores (no device visible to torch)
-        CUDA_VISIBLE_DEVICES=-1 HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+        PYTHONPATH="${hook#:}" CUDA_VISIBLE_DEVICES=-1 HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
     else
-        timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
+        PYTHONPATH="${hook#:}" timeout 1500 python -X importtime run.py "$@" >> "$log" 2> "$OUT/${name}_${who}.err"
     fi
     rc=$?
     t1=$(date +%s.%N)
@@ -55,30 +60,40 @@ done; fi
 if has supdrop; then for who in ours ref; do
     one $who supdrop -k synth -arc 3,3,3,3,3 -e 2 -b 1024 --checkpoint-frequency 10 -c ck_supdrop_$who
 done; fi
-# --evaluate: each implementation evaluates BOTH checkpoints (state_dict interchange in both directions, run.py:203-210, 652-721).
-# run.py:207 calls torch.load() without weights_only=False on a checkpoint that holds a numpy RandomState (run.py:600-608): torch >= 2.6
-# refuses that for EITHER implementation; TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 is torch's own switch for such scripts.
+# --evaluate: each implementation evaluates BOTH implementations' checkpoints (state_dict interchange in both directions,
+# run.py:203-219, 652-721).  Two facts about the reference's own script on a current torch, the same for either implementation:
+# (1) run.py:207 calls torch.load() without weights_only=False on a checkpoint that holds a numpy RandomState (run.py:600-608):
+# torch >= 2.6 refuses; TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 is torch's own switch for such scripts.  (2) run.py:213 tests
+# `'model_traj' in checkpoint`, and a SUPERVISED checkpoint written by run.py:600-608 holds that key with value None, so run.py:219
+# raises for its own checkpoints (seen in gpurun_out/c62).  Hence: (a) the semi-supervised checkpoints (both models present) are
+# evaluated as they are; (b) the supervised ones in the published format (pretrained_h36m_cpn.bin: no 'model_traj' key).
 if has eval; then
+    export TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 MIOPEN_FIND_MODE=FAST
     for who in ours ref; do
         [ -f ck_sup_$who/epoch_1.bin ] || one $who evalprep -k synth -arc 3,3,3,3,3 -e 1 -b 1024 -drop 0 --checkpoint-frequency 1 -c ck_sup_$who
+        [ -f ck_semi_$who/epoch_1.bin ] || one $who evalprep_semi -k synth -arc 3,3,3 -e 1 -b 1024 -drop 0 -str S1 -sun S5,S6,S7,S8 --warmup 1 --checkpoint-frequency 1 -c ck_semi_$who
+        python -c "import torch; c = torch.load('ck_sup_$who/epoch_1.bin', weights_only=False); torch.save({k: c[k] for k in ('epoch', 'lr', 'model_pos')}, 'ck_sup_$who/published_format.bin')"
     done
-    export TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1
     for who in ours ref; do
         for ck in ours ref; do
-            one $who eval_ck${ck} -k synth -arc 3,3,3,3,3 -c ck_sup_$ck --evaluate epoch_1.bin
+            one $who eval_ck${ck} -k synth -arc 3,3,3,3,3 -c ck_sup_$ck --evaluate published_format.bin
+            one $who evalsemi_ck${ck} -k synth -arc 3,3,3 -c ck_semi_$ck --evaluate epoch_1.bin
         done
     done
-    unset TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD
+    unset TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD MIOPEN_FIND_MODE
 fi
 # per-STEP loss trajectories out of the unmodified script: one batch per epoch (--subset 0.008: 1,056 training windows, -b 1200), so
 # the `3d_train` figure run.py prints per epoch is the loss of ONE optimizer step; 12 steps with the lr / BatchNorm-momentum
 # schedules of run.py:583-593.  Three executions of the same command: this package, the reference classes on PyTorch-ROCm, the
-# reference classes on the CPU (the distance between the last two is the reference's own implementation-to-implementation noise).
+# reference classes on the CPU (the distance between the last two is the reference's own implementation-to-implementation noise;
+# RUNPY_CPU=1, or run that leg on any host: the data and the seed are deterministic).  Same torch seed for all three: see SEEDHOOK above.
 if has steps; then
     STEPS="-k synth -arc 3,3,3,3,3 -e 12 -b 1200 --subset 0.008 -drop 0 --no-eval --checkpoint-frequency 100"
+    export SEEDHOOK=1 MIOPEN_FIND_MODE=FAST
     one ours steps $STEPS -c ck_steps_ours
     one ref steps $STEPS -c ck_steps_ref
-    one refcpu steps $STEPS -c ck_steps_refcpu
+    [ "${RUNPY_CPU:-0}" = 1 ] && one refcpu steps $STEPS -c ck_steps_refcpu      # (also runs anywhere without a GPU: same data, same seed)
+    unset SEEDHOOK MIOPEN_FIND_MODE
 fi
 # what an epoch costs without run.py's evaluation passes, unmodified vs with the opt-in edits of INTEGRATION.md 3b (device
 # generators + fused loss + fused Adam: tools/runpy_optc_patch.py writes run_optc.py next to run.py)

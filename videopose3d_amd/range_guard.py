@@ -22,10 +22,13 @@ sooner from a factor 2^14 on.  The guard keeps the model out of that regime:
 * action: above a limit the model's calls run on the exact-fp32 engine (``engine.use_s16`` -> False, one warning), until its
   parameters are re-loaded (``load_state_dict`` / ``.to()``) and measure inside the limits again;
 * no host synchronisation in the steady state: the statistic is launched every ``CHECK_EVERY`` calls behind the step's other
-  work, its integers are copied to pinned host memory and looked at exactly ``CONSUME_AFTER`` calls LATER (the copy finished
-  a step ago, so waiting on its event costs nothing -- and, unlike polling the event, every rank of a data-parallel job acts
-  on a measurement at the same step).  Parameters move by an optimizer step at a time; the limits sit 2^5..2^8 below the
-  first measurable effect.  After ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call
+  work, its integers are copied to pinned host memory and looked at by a LATER call: only at calls that are a multiple of
+  ``CONSUME_AFTER`` behind the launch, and only when the copy's event has completed (never waited for: a host that enqueues
+  ahead of the GPU would stall; round 5 measured 1.2 ms per call for a blocking wait two calls after the launch).  Ranks of a
+  data-parallel job hold identical parameters and count the same calls, so they measure the same values at the same step and
+  -- host timing permitting -- act on them at the same step; a rank that is late acts ``CONSUME_AFTER`` calls later (the
+  collectives are the same on either engine).  Parameters move by an optimizer step at a time; the limits sit 2^5..2^8
+  below the first measurable effect.  After ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call
   measures synchronously (one read-back per load, not per step).
 * what it protects is "not worse than the exact-fp32 engine", not "accurate": where BOTH arithmetics lose precision (e.g. every
   layer's beta at 2^14: gmax ~ 0.1 on either engine, tools/range_edges.py) the model stays on split-fp16.
@@ -44,6 +47,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import time
 import warnings
 
 import torch
@@ -55,7 +59,7 @@ ACT_SPREAD_MAX = 12
 W_SPREAD_MAX = 16
 IO_SPREAD_MAX = 12       # columns of the input batch / of the loss gradient at the head: A operands like the activations
 CHECK_EVERY = 16
-CONSUME_AFTER = 2        # a measurement launched at call n is acted on at call n + CONSUME_AFTER (deterministic across ranks)
+CONSUME_AFTER = 8        # a measurement launched at call n is looked at at calls n + 8, n + 16, ... (once its copy has completed)
 GRAM_KAPPA_LOG2_MAX = 16  # include/vp3d.h: VP3D_GRAM_KAPPA_LOG2_MAX
 EVAL_KFAC = 4.0          # eval: |bn(y)_c| ~ |gamma_c| * |xhat| + |beta_c| with |xhat| of a few standard deviations
 
@@ -221,7 +225,6 @@ def tick_replay(mod) -> None:
 def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
     if torch.cuda.is_current_stream_capturing():
         return                                       # (a captured step is guarded by its replay wrapper: graph.py)
-    import time
     t0 = time.perf_counter()
     from . import engine, engine_s16
     if (not engine_s16.supported(mod, t_in, training, batch=b) or
@@ -249,8 +252,9 @@ def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
         st.tick_us += (time.perf_counter() - t0) * 1e6
         return
     st.calls += 1
-    if st.pending and st.calls - st.launched_at >= CONSUME_AFTER:
-        st.event.synchronize()                       # recorded CONSUME_AFTER steps ago: complete, nothing to wait for
+    behind = st.calls - st.launched_at
+    every = max(1, min(CONSUME_AFTER, CHECK_EVERY // 2))
+    if st.pending and behind > 0 and behind % every == 0 and st.event.query():
         _consume(mod, st, epoch)
     if not st.tripped and not st.pending and st.calls % CHECK_EVERY == 1:
         _launch(mod, st, m_rows, x3)
