@@ -124,7 +124,7 @@ def status(mod) -> dict:
         return dict(tripped=False, last=None, checks=0, sync_checks=0, gram_off=False, gram_log2_kappa=None)
     return dict(tripped=st.tripped, last=st.last, checks=st.checks, sync_checks=st.sync_checks,
                 limits=(ACT_SPREAD_MAX, W_SPREAD_MAX), io_last=st.io_last, gram_off=st.gram_off, gram_log2_kappa=st.gram_last,
-                tick_us_per_call=st.tick_us / max(1, st.calls + st.sync_checks))
+                tick_us_per_call=st.tick_us / max(1, st.calls))    # steady state: the synchronous measurements are not in it
 
 
 def _ptrs(ts):
@@ -249,8 +249,7 @@ def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
         st.sync_checks += 1
         _consume(mod, st, epoch)
         st.calls = 0                                 # the first periodic measurement follows the first forward (its kappa)
-        st.tick_us += (time.perf_counter() - t0) * 1e6
-        return
+        return                                       # (not in tick_us: a one-off that waits for the device and loads the kernels)
     st.calls += 1
     behind = st.calls - st.launched_at
     every = max(1, min(CONSUME_AFTER, CHECK_EVERY // 2))
