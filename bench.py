@@ -101,6 +101,8 @@ def final_line(out):
         line["cfg5_ms"] = pick(c5, ("ms_per_step", "graph_replay_ms_per_step"))
     if out.get("range_guard") is not None:
         line["range_guard"] = out["range_guard"]
+    if out.get("box") and "error" not in out["box"]:
+        line["box"] = pick(out["box"], ("power_w", "power_cap_w", "sclk_mhz", "temp_junction_c"))
     for k in ("value_path", "dry_run", "barrier_to_barrier_s"):
         if k in out:
             line[k] = _r(out[k])
@@ -115,7 +117,7 @@ def final_line(out):
         line["eager"] = pick(out["eager"], ("value", "ms_per_step"))
     line["detail"] = out.get("detail_file")
     s = json.dumps(line, separators=(",", ":"))
-    for k in ("launcher", "cfg5_ms", "rocm_reference", "cfg2_eval_fwd_f32_mfma", "range_guard", "step_frac_of_roofline"):   # never reached today:
+    for k in ("box", "launcher", "cfg5_ms", "rocm_reference", "cfg2_eval_fwd_f32_mfma", "range_guard", "step_frac_of_roofline"):   # never reached today:
         if len(s) <= FINAL_LINE_MAX:                                                                           # the contract's
             break                                                                                              # fields stay
         line.pop(k, None)
@@ -366,6 +368,47 @@ def rocm_reference_baseline(dev, x, tgt):
             "value": B / ms_train * 1e3, "unit": "frames/s", "train_ms_per_step": ms_train, "cfg2_eval_ms": ms_eval,
             "cfg2_eval_frames_per_s": B / ms_eval * 1e3, "torch": torch.__version__,
             "first_two_steps_s": t_find}
+
+
+def box_state(step, dev_index=0, n_steps=80, samples=12):
+    """Power / clock / temperature of THIS box's GPU while the step runs (sysfs hwmon of the amdgpu device; read-only, < 1 ms per
+    sample): `n_steps` steps are enqueued, the files are sampled while the GPU works through them.  Freshly leased MI355X boxes of
+    round 5 differed by 12 % on every split-fp16 number and 1.4 % on the exact-fp32 engine (profiles/r05_bench_lines.txt): the
+    sustained MFMA clock under the board's power limit is a property of the box, and this puts it on record next to `value`."""
+    import glob
+    cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    if not cands:
+        return {"error": "no amdgpu hwmon in sysfs"}
+    hw = cands[min(dev_index, len(cands) - 1)]
+
+    def rd(name):
+        try:
+            with open(os.path.join(hw, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+    for _ in range(n_steps):
+        step()
+    acc = {"power_w": [], "sclk_mhz": [], "temp_junction_c": []}
+    for _ in range(samples):
+        time.sleep(0.02)
+        p = rd("power1_average")
+        if p is None:
+            p = rd("power1_input")
+        f, t = rd("freq1_input"), rd("temp2_input")
+        if p is not None:
+            acc["power_w"].append(p / 1e6)
+        if f is not None:
+            acc["sclk_mhz"].append(f / 1e6)
+        if t is not None:
+            acc["temp_junction_c"].append(t / 1e3)
+    torch.cuda.synchronize()
+    out = {k: (round(sum(v) / len(v), 1) if v else None) for k, v in acc.items()}
+    cap = rd("power1_cap")
+    out["power_cap_w"] = round(cap / 1e6, 1) if cap is not None else None
+    out["hwmon"] = hw
+    out["what"] = "mean of %d sysfs samples taken while %d steps of the headline workload were executing" % (samples, n_steps)
+    return out
 
 
 def semi_supervised_step_latency(dev):
@@ -887,6 +930,11 @@ def main():
     from videopose3d_amd import range_guard
     out["range_guard"] = {k: v for k, v in range_guard.status(model).items() if k in ("tripped", "last", "io_last", "checks", "gram_off", "gram_log2_kappa")}
     out["range_guard"]["tick_us_per_call"] = round(range_guard.status(model).get("tick_us_per_call", 0.0), 1)
+    if world == 1:
+        try:
+            out["box"] = box_state(step, local)
+        except Exception as e:  # noqa: BLE001  (diagnostics never cost the run its result)
+            out["box"] = {"error": repr(e)[:200]}
     gemm_ms = sum(v["ms_per_step"] for v in out["kernels"].values())
     out["non_gemm_ms_per_step"] = ms_per_step - gemm_ms if world == 1 else None
 
