@@ -379,7 +379,16 @@ def box_state(step, dev_index=0, n_steps=80, samples=12):
     cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
     if not cands:
         return {"error": "no amdgpu hwmon in sysfs"}
-    hw = cands[min(dev_index, len(cands) - 1)]
+    # sysfs lists every GPU of the node, the process sees one: match by PCI address (card*/device -> .../<domain>:<bus>:<dev>.0)
+    hw, how = None, "pci address"
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for c in cands:
+            if want in os.path.realpath(os.path.join(c, "..", "..")):
+                hw = c
+    except Exception:  # noqa: BLE001
+        pass
 
     def rd(name):
         try:
@@ -389,6 +398,22 @@ def box_state(step, dev_index=0, n_steps=80, samples=12):
             return None
     for _ in range(n_steps):
         step()
+    if hw is None:                                   # no PCI match: the card that draws the most power right now
+        how = "highest power draw"
+        time.sleep(0.05)
+        best = -1.0
+        for c in cands:
+            for name in ("power1_average", "power1_input"):
+                try:
+                    with open(os.path.join(c, name)) as f:
+                        v = float(f.read().strip())
+                    if v > best:
+                        best, hw = v, c
+                    break
+                except (OSError, ValueError):
+                    continue
+        if hw is None:
+            hw = cands[0]
     acc = {"power_w": [], "sclk_mhz": [], "temp_junction_c": []}
     for _ in range(samples):
         time.sleep(0.02)
@@ -406,7 +431,7 @@ def box_state(step, dev_index=0, n_steps=80, samples=12):
     out = {k: (round(sum(v) / len(v), 1) if v else None) for k, v in acc.items()}
     cap = rd("power1_cap")
     out["power_cap_w"] = round(cap / 1e6, 1) if cap is not None else None
-    out["hwmon"] = hw
+    out["hwmon"], out["matched_by"] = hw, how
     out["what"] = "mean of %d sysfs samples taken while %d steps of the headline workload were executing" % (samples, n_steps)
     return out
 
