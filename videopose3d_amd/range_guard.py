@@ -155,8 +155,10 @@ def _launch(mod, st: _State, m_rows, x3=None) -> None:
     bns, convs = engine._bns(mod), engine._convs(mod)
     st.out[:2].zero_()                               # (out[2], out[4] accumulate over the steps since the last measurement)
     st.out[3:4].zero_()
-    if x3 is not None and x3.dtype == torch.float32 and x3.is_contiguous() and x3.shape[-1] <= 1024:
-        check(_lib.lib().vp3d_range_cols(ops._stream(), x3.numel() // x3.shape[-1], x3.shape[-1], x3.data_ptr(), x3.shape[-1],
+    # (the caller hands over [B, T, J * F] -- the engines -- or [B, T, J, F] -- graph.GraphedTrainStep: columns = J * F either way)
+    cols = int(getattr(mod, "num_joints_in", 0)) * int(getattr(mod, "in_features", 0))
+    if (x3 is not None and x3.dtype == torch.float32 and x3.is_contiguous() and 0 < cols <= 1024 and x3.numel() % cols == 0):
+        check(_lib.lib().vp3d_range_cols(ops._stream(), x3.numel() // cols, cols, x3.data_ptr(), cols,
                                          st.cols_ws.data_ptr(), st.out[3:].data_ptr()), "vp3d_range_cols")
         st.armed = True
     lim = int(_lib.lib().vp3d_range_max_tensors())
