@@ -81,6 +81,32 @@ def main():
     table("supervised, 129 steps per epoch (dropout 0), eval-mode loss on the training set", ["sup_ours", "sup_ref"], "3d_eval")
     table("semi-supervised (dropout 0)", ["semi_ours", "semi_ref"])
     table("default dropout 0.25 (different mask streams)", ["supdrop_ours", "supdrop_ref"])
+    # the SAME checkpoint evaluated by both implementations: per-action protocol-1 error at run.py's full print precision
+    def per_action(path):
+        out, act = {}, None
+        for ln in open(path, errors="replace"):
+            m = re.match(r"----(.+)----", ln.strip())
+            if m:
+                act = m.group(1)
+            m = re.match(r"Protocol #1 Error \(MPJPE\): ([\d.]+) mm", ln.strip())
+            if m and act:
+                out[act] = float(m.group(1))
+        return out
+    for title, a, b in (("supervised checkpoint written by this package", "eval_ckours_ours", "eval_ckours_ref"),
+                        ("supervised checkpoint written by the reference", "eval_ckref_ours", "eval_ckref_ref"),
+                        ("semi-supervised checkpoint written by this package", "evalsemi_ckours_ours", "evalsemi_ckours_ref"),
+                        ("semi-supervised checkpoint written by the reference", "evalsemi_ckref_ours", "evalsemi_ckref_ref")):
+        pa, pb = os.path.join(d, a + ".log"), os.path.join(d, b + ".log")
+        if not (os.path.exists(pa) and os.path.exists(pb)):
+            continue
+        ea, eb = per_action(pa), per_action(pb)
+        if not ea or set(ea) != set(eb):
+            continue
+        print("-- --evaluate, %s: protocol-1 MPJPE per action (mm), evaluated by ours / by the reference classes --" % title)
+        for k in ea:
+            print("   %-14s %.10f   %.10f   |diff| %.2e mm" % (k, ea[k], eb[k], abs(ea[k] - eb[k])))
+        print("   max |diff| %.2e mm (north_star: within 0.1 mm)" % max(abs(ea[k] - eb[k]) for k in ea))
+        print()
     print("-- seconds per epoch (run.py's own `time`, minutes x 60) --")
     for n, r in runs.items():
         if r["epochs"]:
