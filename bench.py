@@ -370,13 +370,13 @@ def rocm_reference_baseline(dev, x, tgt):
             "first_two_steps_s": t_find}
 
 
-def box_state(step, dev_index=0, n_steps=80, samples=12):
+def box_state(step, dev_index=0, n_steps=80, samples=12, sysfs="/sys"):
     """Power / clock / temperature of THIS box's GPU while the step runs (sysfs hwmon of the amdgpu device; read-only, < 1 ms per
     sample): `n_steps` steps are enqueued, the files are sampled while the GPU works through them.  Freshly leased MI355X boxes of
     round 5 differed by 12 % on every split-fp16 number and 1.4 % on the exact-fp32 engine (profiles/r05_bench_lines.txt): the
     sustained MFMA clock under the board's power limit is a property of the box, and this puts it on record next to `value`."""
     import glob
-    cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    cands = sorted(glob.glob(os.path.join(sysfs, "class/drm/card*/device/hwmon/hwmon*")))
     if not cands:
         return {"error": "no amdgpu hwmon in sysfs"}
     # sysfs lists every GPU of the node, the process sees one: match by PCI address (card*/device -> .../<domain>:<bus>:<dev>.0)
@@ -427,7 +427,8 @@ def box_state(step, dev_index=0, n_steps=80, samples=12):
             acc["sclk_mhz"].append(f / 1e6)
         if t is not None:
             acc["temp_junction_c"].append(t / 1e3)
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     out = {k: (round(sum(v) / len(v), 1) if v else None) for k, v in acc.items()}
     cap = rd("power1_cap")
     out["power_cap_w"] = round(cap / 1e6, 1) if cap is not None else None

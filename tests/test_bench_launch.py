@@ -98,3 +98,24 @@ def test_final_line_unit():
     o = json.loads(s)
     assert o["roofline"]["kernel"] == "k_nt_s16<Cfg<2,4,4,2,2,32,0,1,3>>" and "per_launch" not in o["roofline"]
     assert len(o["cpu_baseline"]["sample"]) <= 160 and o["value"] == pytest.approx(1.23456789e5, rel=1e-5)
+
+
+def test_box_state_reads_a_sysfs_tree_and_never_raises(tmp_path):
+    """bench.box_state: power / clock / temperature from the amdgpu hwmon files (here a fake sysfs tree with two cards: no PCI
+    match on a CPU host -> the card with the highest power draw), missing files -> None, no tree -> an error entry, never an
+    exception (the diagnostics must not cost the run its result)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for card, power in (("card0", 241e6), ("card8", 1000.2e6)):
+        hw = tmp_path / "class" / "drm" / card / "device" / "hwmon" / "hwmon4"
+        hw.mkdir(parents=True)
+        (hw / "power1_input").write_text("%d\n" % power)
+        (hw / "power1_cap").write_text("1400000000\n")
+        (hw / "freq1_input").write_text("2226900000\n")
+    steps = []
+    out = bench.box_state(lambda: steps.append(1), n_steps=3, samples=2, sysfs=str(tmp_path))
+    assert len(steps) == 3 and out["power_w"] == 1000.2 and out["power_cap_w"] == 1400.0 and out["sclk_mhz"] == 2226.9
+    assert out["temp_junction_c"] is None and out["matched_by"] == "highest power draw" and "card8" in out["hwmon"]
+    assert "error" in bench.box_state(lambda: None, n_steps=1, samples=1, sysfs=str(tmp_path / "nothing"))
+    line = json.loads(bench.final_line({"metric": "m", "box": out, "config": {}}))
+    assert line["box"] == {"power_w": 1000.2, "power_cap_w": 1400.0, "sclk_mhz": 2226.9, "temp_junction_c": None}

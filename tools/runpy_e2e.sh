@@ -7,7 +7,7 @@
 # as a git-ignored tarball (tools/runpy_stage.sh -> _ref_stage.tgz, deleted after the call); it is unpacked OUTSIDE the
 # repository (/tmp) and only read there.
 #
-#   gpurun -- 'bash tools/runpy_e2e.sh [phases]'   (sup semi supdrop eval steps optc prof; default all)  -> gpurun_out/runpy/*.log   (tools/runpy_summary.py turns them into profiles/r05_runpy_*)
+#   gpurun -- 'bash tools/runpy_e2e.sh [phases]'   (sup semi supdrop eval steps optc long prof; default all but long)  -> gpurun_out/runpy/*.log   (tools/runpy_summary.py turns them into profiles/r05_runpy_*)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/runpy
@@ -106,6 +106,19 @@ if has optc; then
     one ours optc_noeval $NOEV -c ck_ne_optc
     one ours optc_sup $SUP -c ck_sup_optc
     cp run_unmodified.py run.py
+fi
+# longer seeded pair: 8 epochs (1,032 optimizer steps) from identical weights, dropout 0 -- how far two implementations drift in
+# situ -- and 20 epochs of the opt-in path with the default dropout (what the fast path converges to on this data)
+if has long; then
+    export SEEDHOOK=1 MIOPEN_FIND_MODE=FAST
+    LONG="-k synth -arc 3,3,3,3,3 -e 8 -b 1024 -drop 0 --checkpoint-frequency 100"
+    one ours long $LONG -c ck_long_ours
+    one ref long $LONG -c ck_long_ref
+    python "$REPO/tools/runpy_optc_patch.py" . > "$OUT/optc_patch.log" 2>&1
+    cp run.py run_unmodified.py && cp run_optc.py run.py
+    one ours optc_long -k synth -arc 3,3,3,3,3 -e 20 -b 1024 --checkpoint-frequency 100 -c ck_long_optc
+    cp run_unmodified.py run.py
+    unset SEEDHOOK MIOPEN_FIND_MODE
 fi
 # kernel-level evidence that the shim run executes this package's HIP kernels: one short epoch under rocprofv3
 if has prof; then
