@@ -7,7 +7,7 @@
 # as a git-ignored tarball (tools/runpy_stage.sh -> _ref_stage.tgz, deleted after the call); it is unpacked OUTSIDE the
 # repository (/tmp) and only read there.
 #
-#   gpurun -- 'bash tools/runpy_e2e.sh [phases]'   (sup semi supdrop eval steps optc long prof; default all but long)  -> gpurun_out/runpy/*.log   (tools/runpy_summary.py turns them into profiles/r05_runpy_*)
+#   gpurun -- 'bash tools/runpy_e2e.sh [phases]'   (sup semi supdrop eval steps optc long flags prof; default all but long / flags)  -> gpurun_out/runpy/*.log   (tools/runpy_summary.py turns them into profiles/r05_runpy_*)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/runpy
@@ -110,7 +110,7 @@ fi
 # longer seeded pair: 8 epochs (1,032 optimizer steps) from identical weights, dropout 0 -- how far two implementations drift in
 # situ -- and 20 epochs of the opt-in path with the default dropout (what the fast path converges to on this data)
 if has long; then
-    export SEEDHOOK=1 MIOPEN_FIND_MODE=FAST
+    export SEEDHOOK=1 MIOPEN_FIND_MODE=FAST       # (FAST: no kernel search, but immediate-mode kernels -- the reference ran 103 s per epoch)
     LONG="-k synth -arc 3,3,3,3,3 -e 8 -b 1024 -drop 0 --checkpoint-frequency 100"
     one ours long $LONG -c ck_long_ours
     one ref long $LONG -c ck_long_ref
@@ -119,6 +119,24 @@ if has long; then
     one ours optc_long -k synth -arc 3,3,3,3,3 -e 20 -b 1024 --checkpoint-frequency 100 -c ck_long_optc
     cp run_unmodified.py run.py
     unset SEEDHOOK MIOPEN_FIND_MODE
+fi
+# run.py's other model-facing switches (run.py:171-184, arguments.py:46-59), two short seeded epochs each (--subset 0.1), both
+# implementations: causal convolutions, dense (non-dilated) convolutions, the un-optimised dilated class for training, chunked
+# training (--stride 9: TemporalModel with 9 output frames per window), no augmentation / no TTA, 17 -> 512 channels
+if has flags; then
+    # (no MIOPEN_FIND_MODE=FAST here: it skips the ~85-s kernel search per process but then runs the reference's convolutions on
+    #  MIOpen's immediate-mode kernels -- measured 103 s per epoch instead of 10 in the `long` phase)
+    export SEEDHOOK=1
+    FL="-k synth -arc 3,3,3 -e 2 -b 1024 -drop 0 --subset 0.1 --checkpoint-frequency 100"
+    one ours flag_causal $FL --causal -c ck_f1_ours
+    one ours flag_dense $FL --dense -c ck_f2_ours
+    one ours flag_noopt $FL --disable-optimizations -c ck_f3_ours
+    one ours flag_stride9 $FL --stride 9 -c ck_f4_ours
+    one ours flag_noaug $FL -no-da -no-tta -c ck_f5_ours
+    one ours flag_ch512 $FL -ch 512 -c ck_f6_ours
+    one ref flag_causal $FL --causal -c ck_f1_ref
+    one ref flag_stride9 $FL --stride 9 -c ck_f4_ref
+    unset SEEDHOOK
 fi
 # kernel-level evidence that the shim run executes this package's HIP kernels: one short epoch under rocprofv3
 if has prof; then

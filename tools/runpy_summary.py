@@ -81,6 +81,10 @@ def main():
     table("supervised, 129 steps per epoch (dropout 0), eval-mode loss on the training set", ["sup_ours", "sup_ref"], "3d_eval")
     table("semi-supervised (dropout 0)", ["semi_ours", "semi_ref"])
     table("default dropout 0.25 (different mask streams)", ["supdrop_ours", "supdrop_ref"])
+    table("8 epochs from identical weights (seed hook), dropout 0", ["long_ours", "long_ref"])
+    table("8 epochs from identical weights (seed hook), dropout 0, eval-mode loss on the test subjects", ["long_ours", "long_ref"], "3d_valid")
+    for flag in ("causal", "dense", "noopt", "stride9", "noaug", "ch512"):
+        table("run.py switch `%s`, two seeded epochs on a tenth of the data" % flag, ["flag_%s_ours" % flag, "flag_%s_ref" % flag])
     # the SAME checkpoint evaluated by both implementations: per-action protocol-1 error at run.py's full print precision
     def per_action(path):
         out, act = {}, None
