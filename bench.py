@@ -31,6 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Before the HIP runtime initialises (videopose3d_amd/__init__.py sets the same default; here it also covers every baseline leg of
+# this process): kernel arguments in device memory -- the step is a dependent chain of ~230 launches, -2.9 % step time
+# (profiles/r05_dev_kernarg_ab.txt).  A value already in the environment wins; the line reports what was in effect.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -115,6 +119,7 @@ def final_line(out):
             line["launcher"]["n_cores_of_rank0"] = len(la["cores_of_rank0"])
     if "eager" in out:
         line["eager"] = pick(out["eager"], ("value", "ms_per_step"))
+    line["env"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")}
     line["detail"] = out.get("detail_file")
     s = json.dumps(line, separators=(",", ":"))
     for k in ("box", "launcher", "cfg5_ms", "rocm_reference", "cfg2_eval_fwd_f32_mfma", "range_guard", "step_frac_of_roofline"):   # never reached today:
