@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 108
+#define VP3D_VERSION 109
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -210,6 +210,28 @@ typedef struct vp3d_s16_red {
  *                       The slices write raw scaled partial matrices [splits][M][N]; a finishing pass sums them and
  *                       applies the epilogue -- unless raw_partials, where the partials ARE the result (wgrad:
  *                       vp3d_wgrad_reduce sums them; y may be NULL). */
+/* BatchNorm finalize inside a K-SLICED launch's finishing pass (training forward of the small-M layers; model.py:32,117-119 in
+ * training mode): the pass already writes the 64-row-slab statistics; the LAST of its workgroups to finish a 64-column strip
+ * (one ticket per strip) merges the strip's slabs in fp64 -- the summation order of vp3d_bn_finalize, bit-identical outputs --
+ * and writes scale / shift / save_mean / save_invstd and the running statistics: no separate vp3d_bn_finalize launch between the
+ * GEMM and the activation pass.  tickets: (c_out + 63) / 64 zeroed int32 (zero again on exit).  momentum_dev != NULL is read at
+ * execution time instead of `momentum`.  Ignored (the caller must finalise itself) unless the launch runs with splits > 1:
+ * vp3d_nt_s16_plan says so beforehand. */
+typedef struct vp3d_s16_fin {
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float momentum;
+  const float* momentum_dev;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  float* scale;
+  float* shift;
+  float* save_mean;
+  float* save_invstd;
+  int32_t* tickets;
+} vp3d_s16_fin;
 typedef struct vp3d_s16 {
   const float* x_bound;
   const float* w_bound;
@@ -260,6 +282,8 @@ typedef struct vp3d_s16 {
    * multiples of 64 rows) and vp3d_bn_finalize_slab merges.  A launch whose configuration writes another slab size than the
    * caller announced is refused, never silently mis-indexed. */
   int32_t stat_slab_rows;
+  /* BatchNorm finalize in the finishing pass of a K-sliced launch, or NULL (vp3d_s16_fin above) */
+  const vp3d_s16_fin* fin;
 } vp3d_s16;
 /* Configuration 29: the same with wave rows of 3 + 2 row blocks = 160 x 256 tiles (the 9,216-row launches: 58 x 4 = 232 tiles = 91 %
  * of one round); both take K slices like 20 / 22 (their statistics then come from the finishing pass: 64-row slabs); the fused

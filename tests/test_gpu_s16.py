@@ -1210,3 +1210,72 @@ def test_range_cols_statistic_and_hot_input_joint_trips_the_guard():
             assert sum("dynamic range" in str(r.message) for r in rec) == 1
     finally:
         engine.S16_MIN_FORWARD_FLOPS.update(keep)
+
+
+@pytest.mark.parametrize("b,t_in,taps,c", [(1024, 3, 3, 1024), (1024, 1, 1, 1024), (1024, 9, 3, 1024), (37, 3, 3, 256)])
+def test_bn_finalize_inside_the_split_k_finishing_pass_is_bit_identical(b, t_in, taps, c):
+    """vp3d_s16_fin: a K-sliced forward launch whose finishing pass also finalises the BatchNorm statistics (the last workgroup
+    of a 64-column strip merges the strip's slabs: one ticket per strip) against the same launch + the separate
+    vp3d_bn_finalize it removes from the forward's dependent chain: coefficients, running statistics and num_batches_tracked
+    bit-identical, the conv output too; tickets left zero; a second launch on the same tickets works."""
+    g = torch.Generator().manual_seed(11)
+    spec = ConvSpec(c, c, taps, 1, taps)
+    x = S.split((torch.randn(b, t_in, c, generator=g) * 0.7 + 0.3).to(DEV))
+    w = torch.randn(c, c, taps, generator=g) * 0.03
+    wt = S.split(ops.pack_weight(w.to(DEV)))
+    m = b * spec.t_out(t_in)
+    cfg, splits = S.plan(m, c, taps * c, mix=True)
+    if splits <= 1:
+        splits = 2
+    outs = []
+    for use_fin in (False, True, True):
+        bn = torch.nn.BatchNorm1d(c).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-1, 1, c))
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, c))
+        slab = S.stat_slab_rows(cfg, splits)
+        st = ops.stat_buffers(m, c, DEV, slab)
+        if use_fin:
+            y, coef = S.conv_nt(x, wt, spec, stats=st, cfg=cfg, splits=splits, stat_slab=slab, fin=(bn, None))
+            assert coef is not None
+        else:
+            y = S.conv_nt(x, wt, spec, stats=st, cfg=cfg, splits=splits, stat_slab=slab)
+            coef = ops.bn_finalize(bn, m, st, slab_rows=slab)
+        outs.append((y, coef, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    assert int(S._fin_tickets(DEV, 1).abs().sum()) == 0
+    for other in outs[1:]:
+        assert torch.equal(outs[0][0], other[0])
+        assert torch.equal(outs[0][1], other[1]), float((outs[0][1] - other[1]).abs().max())
+        assert torch.equal(outs[0][2], other[2]) and torch.equal(outs[0][3], other[3]) and other[4] == 1
+    # against float64 from the conv output itself
+    yd = outs[0][0].double().reshape(m, c)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    assert torch.allclose(outs[1][1][2].double(), mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(outs[1][1][3].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5)
+
+
+def test_model_step_with_and_without_finalize_in_the_finishing_pass(monkeypatch):
+    """Model level (the benchmark's layer shapes at B = 1024: the M <= 3072 layers run K-sliced): output, every gradient and
+    every buffer bit-identical with SW["fin_in_finish"] on and off."""
+    torch.manual_seed(2)
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], dropout=0.25, channels=1024).to(DEV).train()
+    m.math = "f16x3"
+    x = (torch.randn(1024, 243, 17, 2, device=DEV) * 0.5).clamp(-1, 1)
+    tgt = torch.randn(1024, 1, 17, 3, device=DEV) * 0.3
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    res = []
+    for on in (True, False):
+        monkeypatch.setitem(SW, "fin_in_finish", on)
+        m.load_state_dict(sd0)
+        m._drop_calls = 0
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        torch.mean(torch.norm(y - tgt, dim=3)).backward()
+        res.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                    {k: v.clone() for k, v in m.state_dict().items()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k

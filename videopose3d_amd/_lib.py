@@ -46,7 +46,14 @@ class S16Opts(C.Structure):
                 ("l1", C.c_void_p), ("res_amax", C.c_void_p), ("out_wbound", C.c_void_p), ("no_output", C.c_int32),
                 ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("act_drop", C.POINTER(Dropout)),
                 ("act_bound", C.c_void_p), ("act_bits", C.c_void_p), ("tickets", C.c_void_p), ("red", C.c_void_p),
-                ("stat_slab_rows", C.c_int32)]
+                ("stat_slab_rows", C.c_int32), ("fin", C.c_void_p)]
+
+
+class S16Fin(C.Structure):                     # include/vp3d.h: vp3d_s16_fin
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("momentum_dev", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("tickets", C.c_void_p)]
 
 
 class S16Red(C.Structure):                     # include/vp3d.h: vp3d_s16_red
@@ -211,8 +218,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 108:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (108); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 109:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (109); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

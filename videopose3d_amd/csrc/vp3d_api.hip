@@ -54,6 +54,12 @@ static int fill_epi(Epi* e, const vp3d_epilogue* u, float* C, int64_t c_bpitch, 
   e->red_inv_keep = e->red_inv_m = e->red_sqrt_m1 = 0.f;
   e->red_cnt = nullptr;
   e->red_dgamma = e->red_dbeta = e->red_dy_bound = nullptr;
+  e->fin_tickets = nullptr;
+  e->fin_gamma = e->fin_beta = e->fin_momentum_dev = nullptr;
+  e->fin_eps = e->fin_momentum = 0.f;
+  e->fin_running_mean = e->fin_running_var = nullptr;
+  e->fin_nbt = nullptr;
+  e->fin_scale = e->fin_shift = e->fin_save_mean = e->fin_save_invstd = nullptr;
   if (u == nullptr) return VP3D_OK;
   e->bias = u->bias;
   e->relu = u->relu;
@@ -306,6 +312,26 @@ int vp3d_tconv_nt_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
     a.epi.red_dgamma = r->dgamma;
     a.epi.red_dbeta = r->dbeta;
     a.epi.red_dy_bound = r->dy_bound;
+  }
+  if (o->fin != nullptr) {
+    const vp3d_s16_fin* f = o->fin;
+    VP3D_REQUIRE(a.epi.stat_sum != nullptr && !o->raw_partials && !o->out_s16 && !o->no_output && o->act_scale == nullptr &&
+                     o->red == nullptr, "tconv_nt_s16: fin rides on a launch that writes BatchNorm statistics and an fp32 output");
+    VP3D_REQUIRE(f->gamma && f->beta && f->scale && f->shift && f->save_mean && f->save_invstd && f->tickets,
+                 "tconv_nt_s16: fin has a null pointer");
+    a.epi.fin_tickets = f->tickets;
+    a.epi.fin_gamma = f->gamma;
+    a.epi.fin_beta = f->beta;
+    a.epi.fin_eps = f->eps;
+    a.epi.fin_momentum = f->momentum;
+    a.epi.fin_momentum_dev = f->momentum_dev;
+    a.epi.fin_running_mean = f->running_mean;
+    a.epi.fin_running_var = f->running_var;
+    a.epi.fin_nbt = f->num_batches_tracked;
+    a.epi.fin_scale = f->scale;
+    a.epi.fin_shift = f->shift;
+    a.epi.fin_save_mean = f->save_mean;
+    a.epi.fin_save_invstd = f->save_invstd;
   }
   set_splits(&a, nullptr, 0);
   const bool single = o->out_s16 || o->res_s16 || o->no_output || o->act_scale != nullptr || o->red != nullptr;

@@ -1041,7 +1041,11 @@ __global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ pa
       for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
       mean_s[threadIdx.x] = t / (float)cnt;
       const int nn = blockIdx.y * 64 + threadIdx.x;
-      if (nn < N) e.stat_sum[(int64_t)blockIdx.x * N + nn] = t;
+      // (fin: the strip's last workgroup reads every slab's statistics -- agent-scope stores go straight past this XCD's L2)
+      if (nn < N) {
+        if (e.fin_tickets != nullptr) __hip_atomic_store(e.stat_sum + (int64_t)blockIdx.x * N + nn, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else e.stat_sum[(int64_t)blockIdx.x * N + nn] = t;
+      }
     }
     __syncthreads();
     f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
@@ -1064,7 +1068,87 @@ __global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ pa
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
       const int nn = blockIdx.y * 64 + threadIdx.x;
-      if (nn < N) e.stat_m2[(int64_t)blockIdx.x * N + nn] = t;
+      if (nn < N) {
+        if (e.fin_tickets != nullptr) __hip_atomic_store(e.stat_m2 + (int64_t)blockIdx.x * N + nn, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else e.stat_m2[(int64_t)blockIdx.x * N + nn] = t;
+      }
+    }
+    // ---- BatchNorm finalize folded into this pass (vp3d_s16_fin): the LAST workgroup of a 64-column strip to get here merges
+    // the strip's slabs in fp64 and writes the coefficients + running statistics -- vp3d_bn_finalize's arithmetic in its
+    // summation order (slab s belongs to group s % FIN_GROUPS = 64; groups folded by the same tree), so the outputs are
+    // bit-identical to the separate launch this removes from the forward's dependent chain.  The hand-over is the RED
+    // instance's: statistics published with agent-scope stores (acknowledged = visible), one ticket per strip, the last arriver
+    // acquires.
+    if (e.fin_tickets != nullptr) {
+      __shared__ int fin_last;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(e.fin_tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == (int)gridDim.x - 1 ? 1 : 0;
+        if (last) {
+          __hip_atomic_store(e.fin_tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        fin_last = last;
+      }
+      __syncthreads();
+      if (fin_last) {                                  // (workgroup-uniform)
+        constexpr int FG = 64;                         // vp3d_elementwise.hip: FIN_GROUPS
+        // 16 columns per round (4 rounds): thread -> (column, 4 of the 64 groups); a group sums its slabs s = g, g + 64, ... in
+        // order, then the 64 group sums of a column are folded by the tree
+        __shared__ double g1[FG][17], g2[FG][17];      // (17: padded)
+        const int nslab = (int)gridDim.x;
+        const float momentum = e.fin_momentum_dev != nullptr ? e.fin_momentum_dev[0] : e.fin_momentum;
+        for (int c0 = 0; c0 < 64; c0 += 16) {          // 16 columns per round: thread -> (column c0 + (tid & 15), groups (tid >> 4) * 4 .. + 3)
+          const int cl = threadIdx.x & 15, gq = threadIdx.x >> 4;      // gq in 0..15: groups gq * 4 .. gq * 4 + 3
+          const int nn = blockIdx.y * 64 + c0 + cl;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = gq * 4 + u;
+            double a1 = 0.0, a2 = 0.0;
+            if (nn < N) {
+              for (int s = g; s < nslab; s += FG) {
+                const int64_t left = (int64_t)M - (int64_t)s * 64;
+                const double cn = (double)(left < 64 ? left : 64);
+                const double sum = (double)e.stat_sum[(int64_t)s * N + nn];
+                a1 += sum;
+                a2 += (double)e.stat_m2[(int64_t)s * N + nn] + sum * sum / cn;
+              }
+            }
+            g1[g][cl] = a1;
+            g2[g][cl] = a2;
+          }
+          __syncthreads();
+          for (int o = FG / 2; o >= 1; o >>= 1) {      // the fixed-shape tree of k_bn_finalize
+            for (int i = threadIdx.x; i < o * 16; i += 256) {
+              const int g = i >> 4, c = i & 15;
+              g1[g][c] += g1[g + o][c];
+              g2[g][c] += g2[g + o][c];
+            }
+            __syncthreads();
+          }
+          if (threadIdx.x < 16 && nn < N) {
+            const double S1 = g1[0][cl], S2 = g2[0][cl];
+            const double mean = S1 / (double)M;
+            double var = (S2 - S1 * mean) / (double)M;
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)e.fin_eps);
+            const float sc = (float)((double)e.fin_gamma[nn] * invstd);
+            e.fin_save_mean[nn] = (float)mean;
+            e.fin_save_invstd[nn] = (float)invstd;
+            e.fin_scale[nn] = sc;
+            e.fin_shift[nn] = e.fin_beta[nn] - (float)mean * sc;
+            if (e.fin_running_mean != nullptr) e.fin_running_mean[nn] = (1.f - momentum) * e.fin_running_mean[nn] + momentum * (float)mean;
+            if (e.fin_running_var != nullptr) {
+              const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+              e.fin_running_var[nn] = (1.f - momentum) * e.fin_running_var[nn] + momentum * (float)unbiased;
+            }
+          }
+          __syncthreads();
+        }
+        if (blockIdx.y == 0 && threadIdx.x == 0 && e.fin_nbt != nullptr) e.fin_nbt[0] += 1;
+      }
     }
   }
   float amax = 0.f;

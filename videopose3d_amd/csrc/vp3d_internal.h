@@ -82,6 +82,19 @@ struct Epi {
   float* red_dgamma;
   float* red_dbeta;
   float* red_dy_bound;
+  // BatchNorm finalize inside the split-K finishing pass (vp3d_s16_fin; fin_tickets == nullptr: off)
+  int32_t* fin_tickets;
+  const float* fin_gamma;
+  const float* fin_beta;
+  const float* fin_momentum_dev;
+  float fin_eps, fin_momentum;
+  float* fin_running_mean;
+  float* fin_running_var;
+  int64_t* fin_nbt;
+  float* fin_scale;
+  float* fin_shift;
+  float* fin_save_mean;
+  float* fin_save_invstd;
 };
 
 // GEMM over gathered rows: C[m][n] = sum_k A[row(m,k)][.] * B   (forward conv: B k-contiguous "NT";

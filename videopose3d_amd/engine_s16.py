@@ -380,9 +380,16 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
             coef, gram_fwd = S.expand_stats_gram(a_t, w0_packed, bns[0], m_rows, plan.convs[0].taps * plan.convs[0].c_in, one_col,
                                                  mod._momentum_dev_ptr(), want_gram=True, illcond=range_guard.gram_flag(mod))
         else:
-            y = S.expand_fwd(a, wf, stats=stats) if dedicated0 else S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix,
-                                                                              stat_slab=slab)
-            coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr(), slab_rows=slab)
+            coef = None
+            if dedicated0:
+                y = S.expand_fwd(a, wf, stats=stats)
+            elif idx > 0 and sync is None and SW["fin_in_finish"]:
+                # K-sliced launches (the M <= 3072 layers): the finishing pass finalises the statistics itself (vp3d_s16_fin)
+                y, coef = S.conv_nt(a, wf, spec, stats=stats, mix=mix, stat_slab=slab, fin=(bns[idx], mod._momentum_dev_ptr()))
+            else:
+                y = S.conv_nt(a, wf, spec, stats=stats, no_output=fused0, mix=mix, stat_slab=slab)
+            if coef is None:
+                coef = ops.bn_finalize(bns[idx], m_rows, stats, sync=sync, momentum_dev=mod._momentum_dev_ptr(), slab_rows=slab)
         drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
         residual = None
         if idx >= 2 and idx % 2 == 0:

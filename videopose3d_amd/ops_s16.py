@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib, ops
-from ._lib import RowMap, S16Opts, check
+from ._lib import RowMap, S16Fin, S16Opts, check
 from ._switches import SW
 from .plan import ConvSpec, ResSpec
 
@@ -123,7 +123,7 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
 
 def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=None, stats=None, amax_out=None,
             cfg: int = -1, splits: int = 0, out: Optional[torch.Tensor] = None, s16_out=None, no_output: bool = False,
-            act=None, mix: bool = False, stat_slab: int = 64):
+            act=None, mix: bool = False, stat_slab: int = 64, fin=None):
     """y = conv(x) with the fused epilogue of ops.conv_fwd; x [B,T_in,C_in] and wt [C_out, taps*C_in] in S16.
 
     residual = (tensor, ResSpec): fp32 tensor or S16 (decoded with its own bound).
@@ -133,7 +133,11 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
     (plan(..., mix=True) + stat_slab_rows(cfg) tell before the buffers are made; a mismatch is refused by the library).
     no_output: only the BatchNorm slab statistics (`stats`) are produced (returns None).
     act = (coef, drop, out_bound, act_bits or None): fused BatchNorm + ReLU + dropout epilogue -- returns the S16 rows of
-    dropout(relu(y*coef[0] + coef[1])) under out_bound (and fills act_bits) without ever storing y."""
+    dropout(relu(y*coef[0] + coef[1])) under out_bound (and fills act_bits) without ever storing y.
+    fin = (bn, momentum_dev or None): returns (y, coef) -- when the launch runs K-sliced, its finishing pass also finalises the
+    BatchNorm statistics (vp3d_s16_fin: the last workgroup of a 64-column strip merges the slabs; coef = [4, C] scale, shift,
+    mean, invstd, running statistics updated: bit-identical to ops.bn_finalize); coef is None when the launch ran in one slice
+    (the caller finalises `stats` itself)."""
     xd, wd = x.data, wt.data
     b, t_in, c_in = xd.shape
     assert c_in == spec.c_in and wd.shape == (spec.c_out, spec.taps * spec.c_in), (xd.shape, wd.shape, spec)
@@ -166,6 +170,20 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
     o, ws = _opts(x, wt, m, spec.c_out, k, xd.device, amax_out, cfg, splits, mix=mix and act is None)
     o.stat_slab_rows = stat_slab
     keep = None
+    coef_fin = fin_s = None
+    if fin is not None and o.splits > 1 and stats is not None and not no_output and act is None and s16_out is None:
+        bn, momentum_dev = fin
+        track = bn.track_running_stats and bn.running_mean is not None
+        if bn.momentum is not None and b * t_out > 1:
+            coef_fin = torch.empty((4, spec.c_out), dtype=torch.float32, device=xd.device)
+            use_dev = momentum_dev is not None and track
+            fin_s = S16Fin(bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), 0.0 if use_dev else float(bn.momentum),
+                           momentum_dev if use_dev else None, bn.running_mean.data_ptr() if track else None,
+                           bn.running_var.data_ptr() if track else None,
+                           bn.num_batches_tracked.data_ptr() if (track and bn.num_batches_tracked is not None) else None,
+                           coef_fin[0].data_ptr(), coef_fin[1].data_ptr(), coef_fin[2].data_ptr(), coef_fin[3].data_ptr(),
+                           _fin_tickets(xd.device, (spec.c_out + 63) // 64).data_ptr())
+            o.fin = C.addressof(fin_s)
     if no_output:
         o.no_output = 1
     if act is not None:
@@ -191,11 +209,13 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
                     nbytes=4.0 * (xd.numel() + wd.numel() + (0 if out is None else out.numel()) +
                                   (out.numel() if residual is not None else 0)),
                     shape=(m, spec.c_out, k, o.cfg, o.splits, 2 if o.cfg == 30 else 1))
-    del keep
+    del keep, fin_s
     if no_output:
         return None
     if act is not None:
         return S16(out, act[2])
+    if fin is not None:
+        return out, coef_fin
     return out if s16_out is None else S16(out, wbound)
 
 
@@ -614,6 +634,17 @@ def bn_act_fwd(y: torch.Tensor, coef: torch.Tensor, drop, residual: Optional[Tup
 
 
 _ticket_pool = {}
+_fin_ticket_pool = {}
+
+
+def _fin_tickets(device, n: int) -> torch.Tensor:
+    """Zeroed int32 tickets of the finalize-in-the-finishing-pass hand-over (vp3d_s16_fin): as _tickets, its own buffer."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    t = _fin_ticket_pool.get(key)
+    if t is None or t.numel() < n:
+        t = _fin_ticket_pool[key] = torch.zeros(max(n, 64), dtype=torch.int32, device=device)
+    return t
+
 
 
 def _tickets(device, n: int) -> torch.Tensor:
