@@ -18,6 +18,7 @@ SW = {
     "act_bits": True,          # backward reads stored activation bits instead of regenerating the Philox masks
     "expand_rows": False,      # expand backward's P = G^T X from the S16 rows (measured slower: tools/expand_bwd_bench.py)
     "tile_mix": "1",           # 224- / 160-row tilings: "0" never, "1" planner decides, "2" / "3" only <= / > 16,384-row launches
-    "fin_in_finish": True,     # K-sliced forward launches finalise their BatchNorm statistics in the finishing pass (vp3d_s16_fin)
+    "fin_in_finish": False,    # K-sliced forward launches finalise their BatchNorm statistics in the finishing pass (vp3d_s16_fin):
+                               # bit-identical, three launches fewer, and 0.8 % SLOWER (profiles/r05_fin_in_finish_ab.txt): off
     "fuse_act_bwd": "0",       # fp32 engine: activation backward inside the dgrad epilogue ("1" wherever legal, "auto")
 }
