@@ -32,7 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Before the HIP runtime initialises (videopose3d_amd/__init__.py sets the same default; here it also covers every baseline leg of
-# this process): kernel arguments in device memory -- the step is a dependent chain of ~230 launches, -2.9 % step time
+# this process): kernel arguments in device memory -- the step is a dependent chain of ~110 launches, -2.6 ... -3.9 % step time
 # (profiles/r05_dev_kernarg_ab.txt).  A value already in the environment wins; the line reports what was in effect.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
