@@ -31,9 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Before the HIP runtime initialises (videopose3d_amd/__init__.py sets the same default; here it also covers every baseline leg of
-# this process): kernel arguments in device memory -- the step is a dependent chain of ~110 launches, -2.6 ... -3.9 % step time
-# (profiles/r05_dev_kernarg_ab.txt).  A value already in the environment wins; the line reports what was in effect.
+# Before the HIP runtime initialises: kernel arguments in device memory -- the step is a dependent chain of ~200 launches,
+# -2.6 ... -3.9 % step time (profiles/r05_dev_kernarg_ab.txt).  Set HERE, in the launcher, not by importing the package (round 6:
+# a library must not change its host process's environment); it also covers every baseline leg of this process, and the ranks
+# that relaunch_under_torchrun starts inherit it.  A value already in the environment wins; the line reports what was in effect.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402

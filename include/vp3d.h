@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VP3D_VERSION 109
+#define VP3D_VERSION 110
 #define VP3D_BOUND_SLOTS 32
 
 #define VP3D_OK 0
@@ -667,6 +667,26 @@ int64_t vp3d_act_bwd_parts(int64_t M, int32_t N, int32_t c_stat);
 
 /* out[n] = sum_m g[m*ld + n]   (bias gradient of the shrink conv) */
 int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int32_t ld, float* out);
+
+/* The head of the model at small row counts: the 3*J_out-column shrink conv (reference common/model.py:33, applied at :137 /
+ * :196) and its whole backward, as dedicated kernels (csrc/vp3d_head.hip) -- fp32 FMAs, the reference's own weight layout
+ * w[N][K] (a 1-tap Conv1d weight is its own pack), deterministic sums.  M = B * T_out rows, K = channels, N = 3 * J_out.
+ *   vp3d_head_supported: 1 when (M, K, N) is served (M <= VP3D_HEAD_MAX_ROWS, K % 4 == 0, K <= 4096, N <= 128); callers keep the
+ *                        general GEMM entry points (vp3d_tconv_fwd / _dgrad / _wgrad + vp3d_colsum) for everything else
+ *   vp3d_head_fwd : out[m][n] = bias[n] + sum_k h[m][k] * w[n][k]                         (bias may be NULL)
+ *   vp3d_head_bwd : dh[m][k] = sum_n dy[m][n] * w[n][k];  dh_bound (32 zeroed slots, or NULL) receives max|dh| (the split-fp16
+ *                   engine's bound of its first backward operand);  ws (vp3d_head_bwd_ws_floats floats, or NULL: no weight /
+ *                   bias gradient) receives the per-32-row-slice partials of dw / db in the SAME launch
+ *   vp3d_head_fold: dw[n][k] = sum_slices, db[n] = sum_slices (slice order; db may be NULL) -- nothing in backward reads them,
+ *                   so the caller may enqueue this on another stream behind vp3d_head_bwd */
+#define VP3D_HEAD_MAX_ROWS 4096
+int vp3d_head_supported(int64_t M, int32_t K, int32_t N);
+int64_t vp3d_head_bwd_ws_floats(int64_t M, int32_t K, int32_t N);
+int vp3d_head_fwd(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const float* h, const float* w, const float* bias,
+                  float* out);
+int vp3d_head_bwd(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const float* dy, const float* h, const float* w,
+                  float* dh, float* dh_bound, float* ws);
+int vp3d_head_fold(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const float* ws, float* dw, float* db);
 
 /* materialise the dropout keep*scale mask of a layer as floats (tests / debugging only) */
 int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out);

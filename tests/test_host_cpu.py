@@ -29,7 +29,7 @@ def test_abi_exports_every_declared_symbol():
     h = _lib.lib()                                   # loads libvp3d.so; raises if any symbol is missing
     for name in declared:
         assert hasattr(h, name)
-    assert h.vp3d_version() == 109
+    assert h.vp3d_version() == 110
     assert h.vp3d_stat_slabs(129) == 3
 
 

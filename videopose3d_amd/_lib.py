@@ -179,6 +179,11 @@ SIGNATURES = {
     "vp3d_bn_bwd_apply_g": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vp3d_act_bwd_parts": (_i64, [_i64, _i32, _i32]),
     "vp3d_colsum": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
+    "vp3d_head_supported": (C.c_int, [_i64, _i32, _i32]),
+    "vp3d_head_bwd_ws_floats": (_i64, [_i64, _i32, _i32]),
+    "vp3d_head_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vp3d_head_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vp3d_head_fold": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vp3d_dropout_mask": (C.c_int, [_vp, _i64, _P(Dropout), _vp]),
     "vp3d_project_to_2d_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "vp3d_project_to_2d_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
@@ -218,8 +223,8 @@ def lib():
             raise Vp3dError("libvp3d.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vp3d_version() != 109:
-        raise Vp3dError("libvp3d.so version %d does not match the Python host (109); rebuild" % h.vp3d_version())
+    if h.vp3d_version() != 110:
+        raise Vp3dError("libvp3d.so version %d does not match the Python host (110); rebuild" % h.vp3d_version())
     _lib = h
     return h
 

@@ -1084,16 +1084,16 @@ __global__ void __launch_bounds__(256) k_s16_finish(const float* __restrict__ pa
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
-        const int tk = __hip_atomic_fetch_add(e.fin_tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a formal release / acquire pair since round 6: the ticket is a RELEASE at agent scope -- cumulative over the
+        //  workgroup's statistics stores through the barrier above -- and every thread of the last arriver acquires below)
+        const int tk = __hip_atomic_fetch_add(e.fin_tickets + blockIdx.y, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int last = tk == (int)gridDim.x - 1 ? 1 : 0;
-        if (last) {
-          __hip_atomic_store(e.fin_tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        if (last) __hip_atomic_store(e.fin_tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         fin_last = last;
       }
       __syncthreads();
       if (fin_last) {                                  // (workgroup-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // all threads: the plain loads of the other slabs' statistics follow
         constexpr int FG = 64;                         // vp3d_elementwise.hip: FIN_GROUPS
         // 16 columns per round (4 rounds): thread -> (column, 4 of the 64 groups); a group sums its slabs s = g, g + 64, ... in
         // order, then the 64 group sums of a column are folded by the tree

@@ -78,6 +78,10 @@ def _expand_input(plan: StackPlan, x3: torch.Tensor, one_col: int = -1):
 
 
 def _shrink(mod, h: torch.Tensor) -> torch.Tensor:
+    w = mod.shrink.weight.detach()
+    if h.is_contiguous() and ops.head_supported(h.shape[0] * h.shape[1], h.shape[2], w.shape[0]):
+        # training windows (T_out = 1) and short sequences: one dedicated launch, bias included (csrc/vp3d_head.hip)
+        return ops.head_fwd(h, w, mod.shrink.bias.detach())
     # N = 3*J_out (51) columns: weight rows beyond N come from the zero page, K is sliced (split-K) to fill the GPU
     return ops.conv_fwd(h, ops.pack_weight(mod.shrink.weight.detach()), mod._plan.shrink,
                         bias=mod.shrink.bias.detach())
@@ -202,6 +206,16 @@ def join_side(main, side) -> None:
         main.wait_stream(side)
 
 
+def join_side_now(main, side) -> None:
+    """A join in the MIDDLE of a step: what is queued on `main` from here on waits for everything `side` has been given so far
+    (the forward's weight packs, engine_s16.forward_train).  Piecewise graph capture: the piece being captured ends here and
+    the replay waits for the second stream before it launches the next one."""
+    if _segmenter is not None:
+        _segmenter.join()
+    else:
+        main.wait_stream(side)
+
+
 _fork_events = {}
 
 
@@ -270,10 +284,17 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
         return ops.conv_dgrad(dy, wt, spec, t_in, residual=residual), None
 
     o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
-    d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
-    d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
     last = 2 * plan.n_blocks if plan.n_blocks else 0             # layer whose activation is the stack output
-    dh, f_dh = dgrad(gout3, saved["wts"], plan.shrink, t_out, last, need_raw=plan.n_blocks > 0)
+    w_sh = mod.shrink.weight.detach()
+    if fuse_mode == "0" and h_last.is_contiguous() and ops.head_supported(b * t_out, h_last.shape[2], w_sh.shape[0]):
+        # the whole backward of the shrink conv as one launch + the fold of its weight / bias partials (csrc/vp3d_head.hip)
+        dh, ws_h = ops.head_bwd(gout3, h_last, w_sh)
+        d_sw, d_sb = ops.head_fold(ws_h, b * t_out, w_sh, out_dw=o_w, out_db=o_b)
+        d_sw, d_sb, f_dh = sunk(d_sw, o_w), sunk(d_sb, o_b), None
+    else:
+        d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
+        d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
+        dh, f_dh = dgrad(gout3, saved["wts"], plan.shrink, t_out, last, need_raw=plan.n_blocks > 0)
     grads = [None] * (3 * len(L))
     n_done = [0]
 

@@ -331,12 +331,37 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     ws = [c.weight.detach() for c in convs]
     m_all = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, n_layers)]
     res_from = [idx - 2 if (idx >= 2 and idx % 2 == 0) else -1 for idx in range(n_layers)]
+    packs_pending = None   # (main stream, second stream) while the C x C weight packs are still running on the second stream
     if fused_prologue:
         xb = bounds[2 * n_layers]
         S.prologue_a([x3] + ws, [xb] + [bounds[n_layers + i] for i in range(n_layers)],
                      [1.0 if one_col >= 0 else 0.0] + [0.0] * n_layers, bns, m_all, res_from, p, bounds)
-        x_rows, x_t, w0_packed, w0_s16, packs_cc = S.prologue_b(x3, plan.convs[0], kpad, one_col, xb, save, ws[0], bounds[n_layers],
-                                                                ws[1:], bounds[n_layers + 1:], save)
+        # The C x C weight packs (204 MB of traffic at B-independent cost: 68 MB of weights read, forward + dgrad packs written)
+        # depend on the maxima only, and nothing before the first C x C conv reads them: they run on the second stream beside
+        # the input staging, the expand layer's statistics and its fused conv (all HBM-bound below the achievable rate), and
+        # the main stream joins in front of conv 1 (round 6: -70 us of a 310-us serial head of the forward).
+        side = engine._wgrad_stream(dev, default_on=True) if SW["prologue_overlap"] else None
+        if side is not None and n_layers > 1:
+            main = torch.cuda.current_stream()
+
+            class _OnSide:
+                def __enter__(self_):
+                    engine.fork_to_side(main, side, engine._fork_event(dev, -3))
+                    self_.ctx = torch.cuda.stream(side)
+                    self_.ctx.__enter__()
+
+                def __exit__(self_, *exc):
+                    self_.ctx.__exit__(*exc)
+                    engine.fork_back()
+                    return False
+
+            packs_cc = S.pack_weights_multi(ws[1:], bounds[n_layers + 1:], want_dgrad=save, launch_ctx=_OnSide)
+            x_rows, x_t, w0_packed, w0_s16, _ = S.prologue_b(x3, plan.convs[0], kpad, one_col, xb, save, ws[0], bounds[n_layers],
+                                                             [], None, save)
+            packs_pending = (main, side)
+        else:
+            x_rows, x_t, w0_packed, w0_s16, packs_cc = S.prologue_b(x3, plan.convs[0], kpad, one_col, xb, save, ws[0],
+                                                                    bounds[n_layers], ws[1:], bounds[n_layers + 1:], save)
         packs = [(w0_s16, None)] + packs_cc
         m0 = x_rows.data.shape[0] * x_rows.data.shape[1]
     else:
@@ -355,6 +380,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     a_t = x_t
     for idx in range(tail0 if tail0 else n_layers):
         spec = spec0 if idx == 0 else plan.convs[idx]
+        if idx >= 1 and packs_pending is not None:     # the first consumer of the C x C packs: wait for the second stream
+            engine.join_side_now(*packs_pending)
+            packs_pending = None
         wf, wd = packs[idx]
         t_cur = a.data.shape[1]
         m_rows = b * spec.t_out(t_cur)
@@ -362,7 +390,8 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         # 224 x 256 tiles (tile configuration 28) where the 256-row tiling strands most of its last round: their statistics
         # come in 32-row slabs; not for the launches that carry a fused activation, nor under synchronised BatchNorm
         mix = idx > 0 and sync is None
-        slab = S.stat_slab_rows(*S.plan(m_rows, spec.c_out, spec.taps * spec.c_in, mix=True)) if mix else 64
+        slab = (S.stat_slab_rows(*S.plan(m_rows, spec.c_out, spec.taps * spec.c_in, mix=True, a_numel=a.data.numel(),
+                                             b_numel=wf.data.numel())) if mix else 64)
         stats = ops.stat_buffers(m_rows, spec.c_out, dev, slab)
         # expand layer, fused: its GEMM (K = 128) is cheap enough to run twice -- pass 1 only produces the BatchNorm
         # statistics, pass 2 applies BatchNorm + ReLU + dropout in its epilogue and writes the S16 activation (+ bits):
@@ -420,6 +449,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
                                   act_bits=bits)
         if idx % 2 == 0:
             h_prev = a
+    if packs_pending is not None:
+        engine.join_side_now(*packs_pending)
+        packs_pending = None
     if tail0:
         h_last = _tail_forward(mod, plan, tail0, a, a_t, packs, bounds, bits_all, bits_at, m_all, seed, offset, p, save, saved)
     out = engine._shrink(mod, h_last)
@@ -535,7 +567,28 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
             gram_xx = S.gram(L[0].x_t)
 
     o_b, o_w = view(mod.shrink.bias), view(mod.shrink.weight)
-    if side is not None:          # nothing in backward reads the shrink gradients: off the dependent chain as well (-0.7 %)
+    last = n_layers - 1
+    w_sh = mod.shrink.weight.detach()
+    use_head = h_last.is_contiguous() and ops.head_supported(b * t_out, h_last.shape[2], w_sh.shape[0])
+    if use_head:
+        # The shrink conv's whole backward as ONE launch on the dependent chain (dh, its maximum = the bound of the first
+        # BatchNorm backward's operand, and the row-sliced partials of dW / dbias: csrc/vp3d_head.hip) + the fold of the partials
+        # beside it -- was dgrad + amax on the chain and colsum + wgrad + slice reduction on the second stream (round 6)
+        dh, ws_h = ops.head_bwd(gout3, h_last, w_sh, dh_bound=bounds[last])
+        if side is not None:
+            engine.fork_to_side(main, side, engine._fork_event(dev, -2))
+            with torch.cuda.stream(side):
+                d_sw, d_sb = ops.head_fold(ws_h, b * t_out, w_sh, out_dw=o_w, out_db=o_b)
+            engine.fork_back()
+            if o_w is None:
+                d_sw.record_stream(main)             # (allocated on the second stream, handed to autograd on `main`)
+            if o_b is None:
+                d_sb.record_stream(main)
+            keep.append((gout3, h_last, ws_h))
+        else:
+            d_sw, d_sb = ops.head_fold(ws_h, b * t_out, w_sh, out_dw=o_w, out_db=o_b)
+        d_sw, d_sb = sunk(d_sw, o_w), sunk(d_sb, o_b)
+    elif side is not None:        # nothing in backward reads the shrink gradients: off the dependent chain as well (-0.7 %)
         engine.fork_to_side(main, side, engine._fork_event(dev, -2))
         with torch.cuda.stream(side):
             d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
@@ -548,9 +601,9 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     else:
         d_sb = sunk(ops.colsum(g2, out=o_b), o_b)
         d_sw = sunk(ops.conv_wgrad(gout3, h_last, plan.shrink, out=o_w), o_w)
-    dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
-    last = n_layers - 1
-    S.amax(dh, out=bounds[last])
+    if not use_head:
+        dh = ops.conv_dgrad(gout3, saved["wts"], plan.shrink, t_out)
+        S.amax(dh, out=bounds[last])
     group_done()                                     # shrink
 
     # BatchNorm-backward column sums inside the dgrad launch that writes the activation's incoming gradient (vp3d_s16_red;

@@ -74,6 +74,7 @@ class _Segments:
         # (that safety was implicit in the engine's `keep` list; now it does not depend on it).
         self.pool, self.side_pool, self.main, self.side = pool, torch.cuda.graph_pool_handle(), main, side
         self.graphs = []
+        self.joins = set()        # indices (in self.graphs) of main pieces that wait for the second stream before they launch
         self._cur = None
 
     def _begin(self, kind):
@@ -113,10 +114,18 @@ class _Segments:
         self._end()
         self._begin("main")
 
+    def join(self):
+        """Mid-step join (engine.join_side_now): the main piece that starts here waits for the second stream's pieces so far."""
+        self._end()
+        self.joins.add(len(self.graphs))
+        self._begin("main")
+
     def replay(self, fork_event):
         main = torch.cuda.current_stream()
-        for kind, g in self.graphs:
+        for i, (kind, g) in enumerate(self.graphs):
             if kind == "main":
+                if i in self.joins:
+                    main.wait_stream(self.side)
                 g.replay()
             else:
                 fork_event.record(main)

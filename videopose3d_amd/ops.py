@@ -391,6 +391,59 @@ def colsum(g2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
 
 
 # --------------------------------------------------------------------------------------------------------
+# the head: the 3*J_out-column shrink conv at small row counts (csrc/vp3d_head.hip; reference common/model.py:33,137,196)
+# --------------------------------------------------------------------------------------------------------
+def head_supported(m_rows: int, k: int, n: int) -> bool:
+    """The dedicated head kernels serve this shrink conv ([m_rows, k] x [n, k]^T); else the general GEMM entry points do."""
+    from ._switches import SW
+    return bool(SW["head_kernels"]) and bool(_lib.lib().vp3d_head_supported(int(m_rows), int(k), int(n)))
+
+
+def head_fwd(h: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[B, T, N] = h[B, T, K] @ w[N, K, 1]^T + bias: one launch (vp3d_head_fwd)."""
+    _chk(h, "h")
+    _chk(w, "weight")
+    b, t, k = h.shape
+    n = w.shape[0]
+    assert h.is_contiguous() and w.is_contiguous() and w.shape[1] == k and w.shape[2] == 1
+    out = torch.empty((b, t, n), dtype=torch.float32, device=h.device)
+    m = b * t
+    _timed_call("tconv_fwd", 2.0 * m * n * k, _lib.lib().vp3d_head_fwd, _stream(), m, k, n, h.data_ptr(), w.data_ptr(), _p(bias),
+                out.data_ptr(), nbytes=4.0 * (m * k + n * k + m * n), shape=(m, n, k, "head", 1, 1))
+    return out
+
+
+def head_bwd(gout: torch.Tensor, h: torch.Tensor, w: torch.Tensor, dh_bound: Optional[torch.Tensor] = None, want_dw: bool = True):
+    """(dh [B, T, K], ws) of the shrink conv: ONE launch (vp3d_head_bwd) that also leaves max|dh| in dh_bound (32 zeroed slots)
+    and the row-sliced partials of dW / dbias in the workspace ws, for head_fold."""
+    _chk(gout, "gout")
+    _chk(h, "h")
+    b, t, k = h.shape
+    n = w.shape[0]
+    m = b * t
+    assert gout.is_contiguous() and h.is_contiguous() and w.is_contiguous() and gout.numel() == m * n
+    dh = torch.empty_like(h)
+    ws = None
+    if want_dw:
+        ws = torch.empty((int(_lib.lib().vp3d_head_bwd_ws_floats(m, k, n)),), dtype=torch.float32, device=h.device)
+    _timed_call("tconv_dgrad", 2.0 * m * n * k * (2 if want_dw else 1), _lib.lib().vp3d_head_bwd, _stream(), m, k, n,
+                gout.data_ptr(), h.data_ptr(), w.data_ptr(), dh.data_ptr(), _p(dh_bound), _p(ws),
+                nbytes=4.0 * (2 * m * k + n * k + m * n), shape=(m, n, k, "head", 1, 1))
+    return dh, ws
+
+
+def head_fold(ws: torch.Tensor, m_rows: int, w: torch.Tensor, out_dw: Optional[torch.Tensor] = None,
+              out_db: Optional[torch.Tensor] = None):
+    """(dW [N, K, 1], dbias [N]) from head_bwd's partials, summed in slice order (vp3d_head_fold)."""
+    n, k = w.shape[0], w.shape[1]
+    dw = out_dw if out_dw is not None else torch.empty_like(w)
+    db = out_db if out_db is not None else torch.empty((n,), dtype=torch.float32, device=w.device)
+    assert dw.is_contiguous() and db.is_contiguous() and dw.numel() == n * k and db.numel() == n
+    check(_lib.lib().vp3d_head_fold(_stream(), int(m_rows), k, n, ws.data_ptr(), dw.data_ptr(), db.data_ptr()), "vp3d_head_fold")
+    return dw, db
+
+
+# --------------------------------------------------------------------------------------------------------
 # batch norm / activation
 # --------------------------------------------------------------------------------------------------------
 def bn_fold(bn: torch.nn.BatchNorm1d) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -72,14 +72,16 @@ _plan_cache = {}
 # _switches.SW["tile_mix"] = "0": the planner never picks the 224- / 160-row tilings (read per call: tools/env_ab.py SW:tile_mix 0 1)
 
 
-def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False) -> Tuple[int, int]:
+def plan(m: int, n: int, k: int, raw: bool = False, mix: bool = False, a_numel: int = 0, b_numel: int = 0) -> Tuple[int, int]:
     """(tile configuration, K slices) of an [m, n, k] split-fp16 GEMM.  mix: configuration 28 (224 x 256 tiles: statistics in
-    32-row slabs, no fused activation / BatchNorm-backward sums) may be chosen."""
+    32-row slabs, no fused activation / BatchNorm-backward sums) may be chosen.  a_numel / b_numel: elements of the tensors the
+    operands are gathered from (a dilated conv's input is larger than m x k / taps; padded leading dimensions) -- the launcher's
+    2-GiB test is on those extents, and the answer here must be the one the launch will accept."""
     mode = SW["tile_mix"]                             # (2 / 3: only launches of at most / more than 16,384 rows -- A/B runs)
     mix = bool(mix and mode != "0" and not (mode == "2" and m > 16384) and not (mode == "3" and m <= 16384))
     # the mixed tilings address both operands through 32-bit buffer descriptors and have no flat-address twin: not for operands
     # of 2 GiB and more (the statistics buffers are sized from this answer, so the refusal has to happen here, not at launch)
-    mix = mix and m * k * 4 < 2 ** 31 and n * k * 4 < 2 ** 31
+    mix = mix and max(m * k, a_numel) * 4 < 2 ** 31 and max(n * k, b_numel) * 4 < 2 ** 31
     key = (m, n, k, raw, mix)
     hit = _plan_cache.get(key)
     if hit is None:
@@ -102,7 +104,7 @@ def _opts(x: S16, w: S16, m, n, k, device, amax_out=None, cfg=-1, splits=0, raw=
     o.w_bound = w.bound_ptr()
     o.amax_out = None if amax_out is None else amax_out.data_ptr()
     if cfg < 0 or splits <= 0:
-        pc, ps = plan(m, n, k, raw, mix)
+        pc, ps = plan(m, n, k, raw, mix, a_numel=x.data.numel(), b_numel=w.data.numel())
         cfg = pc if cfg < 0 else cfg
         splits = ps if splits <= 0 else splits
     o.cfg, o.splits = cfg, splits
@@ -171,7 +173,8 @@ def conv_nt(x: S16, wt: S16, spec: ConvSpec, *, bias=None, relu=False, residual=
     o.stat_slab_rows = stat_slab
     keep = None
     coef_fin = fin_s = None
-    if fin is not None and o.splits > 1 and stats is not None and not no_output and act is None and s16_out is None:
+    if (fin is not None and o.splits > 1 and stats is not None and not no_output and act is None and s16_out is None and
+            res_s16 is None):       # (vp3d_tconv_nt_s16 runs an S16 residual in ONE slice: no finishing pass to finalise in)
         bn, momentum_dev = fin
         track = bn.track_running_stats and bn.running_mean is not None
         if bn.momentum is not None and b * t_out > 1:
@@ -776,8 +779,10 @@ def amax_multi(tensors, bounds: torch.Tensor):
           "vp3d_amax_multi")
 
 
-def pack_weights_multi(weights, bounds: torch.Tensor, want_dgrad=True):
-    """[(S16 fwd pack, S16 dgrad pack or None)] for same-shaped-channel conv weights, one launch; layer i uses bounds[i]."""
+def pack_weights_multi(weights, bounds: torch.Tensor, want_dgrad=True, launch_ctx=None):
+    """[(S16 fwd pack, S16 dgrad pack or None)] for same-shaped-channel conv weights, one launch; layer i uses bounds[i].
+    launch_ctx: a callable returning a context manager the LAUNCH runs under (the outputs are allocated before it is entered,
+    i.e. on the caller's stream: engine_s16.forward_train hands the launch to the second stream beside the expand layer)."""
     c_out, c_in = weights[0].shape[0], weights[0].shape[1]
     dev = weights[0].device
     wfs, wds, taps = [], [], []
@@ -788,9 +793,15 @@ def pack_weights_multi(weights, bounds: torch.Tensor, want_dgrad=True):
         taps.append(k)
         wfs.append(torch.empty((c_out, k * c_in), dtype=torch.float32, device=dev))
         wds.append(torch.empty((k * c_in, c_out), dtype=torch.float32, device=dev) if want_dgrad else None)
-    check(_lib.lib().vp3d_pack_weight_s16_multi(ops._stream(), len(weights), _ptr_array(weights),
-                                                (C.c_int32 * len(taps))(*taps), c_out, c_in, bounds.data_ptr(),
-                                                _ptr_array(wfs), _ptr_array(wds)), "vp3d_pack_weight_s16_multi")
+    def launch():
+        check(_lib.lib().vp3d_pack_weight_s16_multi(ops._stream(), len(weights), _ptr_array(weights),
+                                                    (C.c_int32 * len(taps))(*taps), c_out, c_in, bounds.data_ptr(),
+                                                    _ptr_array(wfs), _ptr_array(wds)), "vp3d_pack_weight_s16_multi")
+    if launch_ctx is None:
+        launch()
+    else:
+        with launch_ctx():
+            launch()
     return [(S16(wf, bounds[i]), S16(wd, bounds[i]) if wd is not None else None)
             for i, (wf, wd) in enumerate(zip(wfs, wds))]
 
