@@ -106,7 +106,7 @@ def _train_step(model, x, tgt):
 
 @pytest.mark.parametrize("switch", ["head_kernels", "prologue_overlap"])
 def test_step_with_and_without_the_round6_paths(switch, math_mode, monkeypatch):
-    """The whole training step with the switch on (default) and off: the head kernels against the GEMM path they replace
+    """The whole training step with the switch on and off: the head kernels against the GEMM path they replace
     (summation order differs: 1e-5 of each tensor's maximum), the second-stream weight packs against the one-launch prologue
     (the same kernels on another stream: bit-identical)."""
     if switch == "prologue_overlap" and math_mode != "f16x3":
@@ -119,6 +119,7 @@ def test_step_with_and_without_the_round6_paths(switch, math_mode, monkeypatch):
     tgt = (torch.randn(96, 1, 17, 3, generator=g) * 0.3).to(DEV)
     state = {k_: v.clone() for k_, v in m.state_dict().items()}
     calls = m._drop_calls
+    monkeypatch.setitem(SW, switch, True)
     y1, g1 = _train_step(m, x, tgt)
     m.load_state_dict(state)
     m._drop_calls = calls                                  # the same dropout stream

@@ -13,7 +13,9 @@ VP3D_OVERLAP, VP3D_S16_MIN_GFLOP, VP3D_FUSE_BN_RED, VP3D_GRAPH_PIECEWISE, VP3D_R
 SW = {
     "wgrad_rows": True,        # C x C weight gradients from the S16 rows (vp3d_wgrad_rows_s16) instead of transposed copies
     "prologue_fused": True,    # the split-fp16 forward's prologue as two launches (vp3d_prologue_a/b_s16) instead of seven
-    "prologue_overlap": True,  # the C x C weight packs of the fused prologue on the second stream, beside the expand layer (round 6)
+    "prologue_overlap": False, # the C x C weight packs of the fused prologue on the second stream, beside the expand layer's statistics
+                               # (round 6): bit-identical and NO gain (4.140 vs 4.149 ms, 6 randomised pairs) -- the pack launch takes every
+                               # CU slot, the statistics kernel beside it stretches from 26 to 47-78 us (profiles/r06_prologue_overlap.txt)
     "head_kernels": True,      # the shrink conv + its backward on the dedicated head kernels (csrc/vp3d_head.hip) up to 4096 rows (round 6)
     "expand_kernel": True,     # dedicated expand-layer kernels (one-pass input staging, vp3d_expand_fwd_s16, fused P GEMM)
     "expand_fused": True,      # expand layer: BatchNorm + ReLU + dropout in the GEMM epilogue (its conv output never reaches HBM)

@@ -45,25 +45,64 @@ __global__ void __launch_bounds__(256) k_head_fwd(int M, int K, int N, const flo
   }
   __syncthreads();
   const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
-  for (int n = q; n < N; n += 4) {
-    float acc[HEAD_RT];
+  // ALL columns of the wave (HEAD_NC = 13 for N <= 52; a second round beyond) advance together along K: per 256-float4 chunk of K
+  // one batch of HEAD_NC weight loads, the next chunk's batch already in flight (register double buffer) -- one column or four
+  // at a time left 13 / 4 dependent L2 round trips + as many butterfly phases in a row (18-20 us for the launch); one butterfly
+  // phase over the HEAD_NC x HEAD_RT partial sums at the end
+  constexpr int HEAD_NC = 13;
+  for (int nbase = 0; nbase < N; nbase += 4 * HEAD_NC) {
+    float acc[HEAD_NC][HEAD_RT];
 #pragma unroll
-    for (int r = 0; r < HEAD_RT; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int c = lane; c < k4n; c += 64) {
-      const f32x4 wv = w4[(int64_t)n * k4n + c];
+    for (int j = 0; j < HEAD_NC; ++j)
 #pragma unroll
-      for (int r = 0; r < HEAD_RT; ++r) acc[r] = dot4(wv, hs4[r * k4n + c], acc[r]);
+      for (int r = 0; r < HEAD_RT; ++r) acc[j][r] = 0.f;
+    f32x4 wv[2][HEAD_NC];
+    auto fetch = [&](int c, int buf) {
+#pragma unroll
+      for (int j = 0; j < HEAD_NC; ++j) {
+        const int n = nbase + q + 4 * j;
+        wv[buf][j] = (n < N && c < k4n) ? w4[(int64_t)n * k4n + c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    fetch(lane, 0);
+    int it = 0;
+    for (int c = lane; c < k4n; c += 64, ++it) {
+      // (two explicit copies of the body: the buffer index must be a compile-time constant for wv to stay in registers)
+      if ((it & 1) == 0) {
+        fetch(c + 64, 1);
+        f32x4 hv[HEAD_RT];
+#pragma unroll
+        for (int r = 0; r < HEAD_RT; ++r) hv[r] = hs4[r * k4n + c];
+#pragma unroll
+        for (int j = 0; j < HEAD_NC; ++j)
+#pragma unroll
+          for (int r = 0; r < HEAD_RT; ++r) acc[j][r] = dot4(wv[0][j], hv[r], acc[j][r]);
+      } else {
+        fetch(c + 64, 0);
+        f32x4 hv[HEAD_RT];
+#pragma unroll
+        for (int r = 0; r < HEAD_RT; ++r) hv[r] = hs4[r * k4n + c];
+#pragma unroll
+        for (int j = 0; j < HEAD_NC; ++j)
+#pragma unroll
+          for (int r = 0; r < HEAD_RT; ++r) acc[j][r] = dot4(wv[1][j], hv[r], acc[j][r]);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < HEAD_RT; ++r)
+    for (int j = 0; j < HEAD_NC; ++j)
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
-    if (lane < rows) {
-      float v = acc[0];
+      for (int r = 0; r < HEAD_RT; ++r)
 #pragma unroll
-      for (int r = 1; r < HEAD_RT; ++r) v = lane == r ? acc[r] : v;
-      out[(int64_t)(m0 + lane) * N + n] = v + (bias != nullptr ? bias[n] : 0.f);
+        for (int o = 32; o > 0; o >>= 1) acc[j][r] += __shfl_xor(acc[j][r], o);
+#pragma unroll
+    for (int j = 0; j < HEAD_NC; ++j) {
+      const int n = nbase + q + 4 * j;
+      if (lane < rows && n < N) {
+        float v = acc[j][0];
+#pragma unroll
+        for (int r = 1; r < HEAD_RT; ++r) v = lane == r ? acc[j][r] : v;
+        out[(int64_t)(m0 + lane) * N + n] = v + (bias != nullptr ? bias[n] : 0.f);
+      }
     }
   }
 }
@@ -85,7 +124,7 @@ struct HeadBwd {
 // blocks behind:      part[s][n][k] = sum_{m in slice s} dy[m][n] * h[m][k] (thread = one k; the slice's h column in registers),
 //                     chunk 0 also the slice's column sums of dy
 __global__ void __launch_bounds__(256) k_head_bwd(const HeadBwd a) {
-  __shared__ float dys[HEAD_RS * HEAD_MAX_N];
+  __shared__ __attribute__((aligned(16))) float dys[HEAD_RS * HEAD_MAX_N];
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int N = a.N, K = a.K;
@@ -104,14 +143,21 @@ __global__ void __launch_bounds__(256) k_head_bwd(const HeadBwd a) {
       f32x4 acc[HEAD_RT];
 #pragma unroll
       for (int r = 0; r < HEAD_RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int n = 0; n < N; ++n) {
-        const f32x4 wv = w4[(int64_t)n * k4n + c];
+      // (16 weight rows in flight per thread: with 4 the 51 dependent-issue L2 round trips were the launch's duration)
+      for (int nb = 0; nb < N; nb += 16) {
+        f32x4 wv[16];
 #pragma unroll
-        for (int r = 0; r < HEAD_RT; ++r) {
-          const float g = dys[r * N + n];
+        for (int u = 0; u < 16; ++u) wv[u] = nb + u < N ? w4[(int64_t)(nb + u) * k4n + c] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(g, wv[e], acc[r][e]);
+        for (int u = 0; u < 16; ++u) {
+          if (nb + u < N) {
+#pragma unroll
+            for (int r = 0; r < HEAD_RT; ++r) {
+              const float g = dys[r * N + nb + u];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(g, wv[u][e], acc[r][e]);
+            }
+          }
         }
       }
 #pragma unroll
@@ -134,9 +180,13 @@ __global__ void __launch_bounds__(256) k_head_bwd(const HeadBwd a) {
   b -= a.n_dh;
   const int s = b / a.kchunks, kc = b - s * a.kchunks;
   const int m0 = s * HEAD_RS, rows = min(HEAD_RS, a.M - m0);
-  for (int i = tid; i < HEAD_RS * N; i += 256) {
-    const int r = i / N;
-    dys[i] = r < rows ? a.dy[(int64_t)m0 * N + i] : 0.f;
+  // the slice's dy rows at a pitch of NP = N rounded up to 4 floats (zero padded): every thread reads the SAME address (an LDS
+  // broadcast), so four columns per ds_read_b128 instead of one per ds_read_b32 -- the scalar form issued 32 x N LDS reads per
+  // thread and was the launch's duration
+  const int NP = (N + 3) & ~3;
+  for (int i = tid; i < HEAD_RS * NP; i += 256) {
+    const int r = i / NP, n = i - r * NP;
+    dys[i] = (r < rows && n < N) ? a.dy[(int64_t)(m0 + r) * N + n] : 0.f;
   }
   const int k = kc * 256 + tid;
   float hv[HEAD_RS];
@@ -145,17 +195,25 @@ __global__ void __launch_bounds__(256) k_head_bwd(const HeadBwd a) {
   __syncthreads();
   if (k < K) {
     float* prow = a.part + (int64_t)s * N * K + k;
-    for (int n = 0; n < N; ++n) {
-      float acc = 0.f;
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dys);
+    const int np4 = NP >> 2;
+    for (int n4 = 0; n4 < np4; ++n4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < HEAD_RS; ++r) acc = fmaf(dys[r * N + n], hv[r], acc);
-      prow[(int64_t)n * K] = acc;
+      for (int r = 0; r < HEAD_RS; ++r) {
+        const f32x4 g = d4[r * np4 + n4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], hv[r], acc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n4 * 4 + e < N) prow[(int64_t)(n4 * 4 + e) * K] = acc[e];
     }
   }
   if (kc == 0 && tid < N) {
     float acc = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < HEAD_RS; ++r) acc += dys[r * N + tid];
+    for (int r = 0; r < HEAD_RS; ++r) acc += dys[r * NP + tid];
     a.part[(int64_t)a.slices * N * K + (int64_t)s * N + tid] = acc;
   }
 }

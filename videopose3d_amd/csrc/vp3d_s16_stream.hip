@@ -413,6 +413,38 @@ struct PackMulti {
   int c_out, c_in;
 };
 
+// load phase of the pack: the block's 64 co rows of 64 * TAPS contiguous floats each, as 16-byte loads (a row starts at a
+// multiple of 256 * TAPS bytes: c_in % 64 == 0), FOUR in flight per thread -- the scalar form (48 dependent-issue 4-byte loads per
+// thread for 3 taps) left the kernel at 2.3 TB/s with every CU slot taken: latency-bound, and a bad neighbour for whatever the
+// other stream runs beside it (round 6: profiles/r06_prologue_overlap.txt)
+template <int TAPS>
+__device__ __forceinline__ void pack_load_tile(const float* __restrict__ w, int c_in, int co0, int ci0, float inv, float* tile) {
+  constexpr int ROW4 = 16 * TAPS;                   // float4 per co row
+  constexpr int N4 = 64 * ROW4;                     // float4 per block: 1024 * TAPS = 4 * TAPS per thread
+  typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int b0 = 0; b0 < N4; b0 += 4 * 256) {
+    f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = b0 + u * 256 + threadIdx.x;
+      const int co = f / ROW4, q4 = f - co * ROW4;
+      v[u] = *reinterpret_cast<const f4*>(w + ((int64_t)(co0 + co) * c_in + ci0) * TAPS + q4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = b0 + u * 256 + threadIdx.x;
+      const int co = f / ROW4, q4 = f - co * ROW4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q4 * 4 + e;
+        const int ci = q / TAPS, k = q - ci * TAPS;
+        tile[(k * 64 + co) * TPITCH + ci] = v[u][e] * inv;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void pack_weight_s16_multi_body(const PackMulti& a, float* tile, int bx, int by, int li) {
   const int taps = a.taps[li], c_in = a.c_in, c_out = a.c_out;
   const float* __restrict__ w = a.w[li];
@@ -420,11 +452,19 @@ __device__ __forceinline__ void pack_weight_s16_multi_body(const PackMulti& a, f
   float* __restrict__ wd = a.wd[li];
   const int co0 = by * 64, ci0 = bx * 64;
   const float inv = s16_pow2(-s16_exp_of(a.bounds + li * kBoundSlots));
-  const int row_f = 64 * taps;
-  for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
-    const int co = idx / row_f, q = idx - co * row_f;
-    const int ci = q / taps, k = q - ci * taps;
-    tile[(k * 64 + co) * TPITCH + ci] = w[((int64_t)(co0 + co) * c_in + ci0) * taps + q] * inv;
+  if ((reinterpret_cast<uintptr_t>(w) & 15u) == 0 && taps == 3) {
+    pack_load_tile<3>(w, c_in, co0, ci0, inv, tile);
+  } else if ((reinterpret_cast<uintptr_t>(w) & 15u) == 0 && taps == 1) {
+    pack_load_tile<1>(w, c_in, co0, ci0, inv, tile);
+  } else if ((reinterpret_cast<uintptr_t>(w) & 15u) == 0 && taps == 2) {
+    pack_load_tile<2>(w, c_in, co0, ci0, inv, tile);
+  } else {
+    const int row_f = 64 * taps;
+    for (int idx = threadIdx.x; idx < 64 * row_f; idx += 256) {
+      const int co = idx / row_f, q = idx - co * row_f;
+      const int ci = q / taps, k = q - ci * taps;
+      tile[(k * 64 + co) * TPITCH + ci] = w[((int64_t)(co0 + co) * c_in + ci0) * taps + q] * inv;
+    }
   }
   __syncthreads();
   const int64_t ld_f = (int64_t)taps * c_in, ld_d = c_out;

@@ -175,6 +175,8 @@ def _wgrad_stream(device, default_on: bool = False) -> Optional[torch.cuda.Strea
     key = torch.device(device).index
     st = _side_streams.get(key)
     if st is None:
+        # (same priority as the caller's stream: this runtime's range is (0, -1) -- there is no level BELOW the default that
+        #  would let the second stream's workgroups only fill the slots the dependent chain leaves; round 6)
         st = torch.cuda.Stream(device=device)
         _side_streams[key] = st
     return st

@@ -336,10 +336,12 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         xb = bounds[2 * n_layers]
         S.prologue_a([x3] + ws, [xb] + [bounds[n_layers + i] for i in range(n_layers)],
                      [1.0 if one_col >= 0 else 0.0] + [0.0] * n_layers, bns, m_all, res_from, p, bounds)
-        # The C x C weight packs (204 MB of traffic at B-independent cost: 68 MB of weights read, forward + dgrad packs written)
-        # depend on the maxima only, and nothing before the first C x C conv reads them: they run on the second stream beside
-        # the input staging, the expand layer's statistics and its fused conv (all HBM-bound below the achievable rate), and
-        # the main stream joins in front of conv 1 (round 6: -70 us of a 310-us serial head of the forward).
+        # The C x C weight packs (204 MB of traffic: 68 MB of weights read, forward + dgrad packs written) depend on the maxima
+        # only, and nothing before the first C x C conv reads them: optionally (SW["prologue_overlap"], default off) they run
+        # on the second stream beside the input staging and the expand layer's statistics, the main stream joining in front of
+        # conv 1.  Built and measured in round 6: bit-identical, and worth nothing (the pack launch occupies every CU slot;
+        # the statistics kernel beside it runs 2-3x longer; first C x C GEMM at +279 us either way) -- what did help was the pack
+        # kernel itself (16-byte loads, four in flight: 83 -> 54 us).
         side = engine._wgrad_stream(dev, default_on=True) if SW["prologue_overlap"] else None
         if side is not None and n_layers > 1:
             main = torch.cuda.current_stream()
