@@ -90,6 +90,8 @@ def final_line(out):
     if out.get("mpjpe_vs_ref"):
         line["mpjpe_vs_ref"] = pick(out["mpjpe_vs_ref"], ("value", "tolerance", "sample_b"))
     line["step_frac_of_roofline"] = _r(out.get("step_frac_of_roofline"))
+    if out.get("launches_per_step"):
+        line["launches_per_step"] = out["launches_per_step"]["libvp3d"]
     if out.get("f32_mfma"):
         line["f32_mfma"] = pick(out["f32_mfma"], ("value", "ms_per_step", "step_frac_of_fp32_mfma_peak"))
     ev = out.get("cfg2_eval_fwd")
@@ -711,6 +713,70 @@ def dropin_steps(dev, x, tgt, math, headline_ms):
                           "torch Adam and the per-step loss.item() of run.py:414"}
 
 
+def shape_sweep(dev, steps=20):
+    """The reference's OWN default configuration and its neighbour (run.py defaults: `-arc 3,3,3 -b 1024`, reference
+    common/arguments.py:37,45; and arc 3,3,3,3) at C = 1024: training step on both engines, eager and as a hipGraph replay.
+    36.4 / 109 GFLOP of forward work per call sit either side of engine.S16_MIN_FORWARD_FLOPS (40 GFLOP): the table says which
+    engine each lands on by default and what the other one would have cost."""
+    import videopose3d_amd as V
+    from videopose3d_amd import TemporalModelOptimized1f, dp, engine
+    from videopose3d_amd import loss as vloss
+    from videopose3d_amd.graph import GraphedTrainStep
+    rows = []
+    keep = dict(engine.S16_MIN_FORWARD_FLOPS)
+    for fw in ([3, 3, 3], [3, 3, 3, 3]):
+        rf = 1
+        for f in fw:
+            rf *= f
+        g = torch.Generator().manual_seed(4321)
+        xs = (torch.randn(B, rf, 17, 2, generator=g) * 0.5).clamp(-1, 1).to(dev)
+        ts = (torch.randn(B, 1, 17, 3, generator=g) * 0.3).to(dev)
+        row = {"arc": ",".join(map(str, fw)), "batch": B, "channels": C, "receptive_field": rf}
+        for mth in ("f32", "f16x3"):
+            torch.manual_seed(0)
+            m = TemporalModelOptimized1f(17, 2, 17, fw, causal=False, dropout=0.25, channels=C).to(dev).train()
+            m.math = mth
+            row["forward_gflop"] = m._plan.forward_flops(B, rf) / 1e9
+            row["default_engine"] = "f16x3" if m._plan.forward_flops(B, rf) >= keep[True] else "f32"
+            engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})     # f16x3 rows: the split-fp16 engine whatever the size
+            try:
+                sync = dp.FlatGradSync(m.parameters(), world=1, direct_module=m)
+
+                def step():
+                    sync.zero_grad()
+                    vloss.mpjpe(m(xs), ts).backward()
+                    sync.sync()
+
+                def timed(fn):
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    best = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(steps):
+                            fn()
+                        torch.cuda.synchronize()
+                        best.append((time.perf_counter() - t0) / steps * 1e3)
+                    return sorted(best)[1]
+                row[mth + "_eager_ms"] = timed(step)
+                try:
+                    gs = GraphedTrainStep(m, sync)
+                    row[mth + "_replay_ms"] = timed(lambda: gs(xs, ts))
+                    del gs
+                except Exception as e:  # noqa: BLE001
+                    row[mth + "_replay_error"] = repr(e)[:160]
+            finally:
+                engine.S16_MIN_FORWARD_FLOPS.update(keep)
+            del m, sync
+            torch.cuda.empty_cache()
+        row["faster_eager"] = "f16x3" if row["f16x3_eager_ms"] < row["f32_eager_ms"] else "f32"
+        rows.append(row)
+    return {"what": "train step fwd+bwd (dropout 0.25) at B=1024, C=1024 for run.py's default arc 3,3,3 and for 3,3,3,3: both "
+                    "engines, eager module call and hipGraph replay; default_engine = what engine.S16_MIN_FORWARD_FLOPS "
+                    "(%.0f GFLOP of forward work) selects" % (keep[True] / 1e9), "rows": rows}
+
+
 def relaunch_under_torchrun(n_gpus):
     """`python bench.py --gpus N` without an external launcher: start N ranks of this script through
     torch.distributed.run on one node (rendezvous on 127.0.0.1, a free port) and hand back its exit code; rank 0 of the
@@ -789,6 +855,7 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 MFMA comparison sections")
     ap.add_argument("--math", default=None, help="arithmetic of the headline: f16x3 (default) or f32")
     ap.add_argument("--no-rocm-ref", action="store_true", help="skip the PyTorch-ROCm (MIOpen) reference-path baseline (~75 s)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the shape sweep (run.py's default arc 3,3,3 / 3,3,3,3 on both engines)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / barrier control flow only, no GPU work (CPU test hook)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -958,6 +1025,14 @@ def main():
 
     # Everything below that runs training steps is executed by EVERY rank: a step contains collectives (the bucketed
     # all-reduces launched from inside backward and the final wait), so a rank-0-only step would deadlock for N > 1.
+    # Kernel launches of one eager step: the library counts its own (vp3d_launch_count); torch adds the flat buffer's zero_() and
+    # the three elementwise kernels of loss.backward() (ones_like, grad * gout, the view's copy) -- the step is ONE dependent chain,
+    # so the count is a lever of its own (round 5: ~0.5 us of argument fetch per launch before device kernargs)
+    from videopose3d_amd import _lib as _vl
+    n0_l = _vl.lib().vp3d_launch_count()
+    step()
+    torch.cuda.synchronize()
+    out["launches_per_step"] = {"libvp3d": int(_vl.lib().vp3d_launch_count() - n0_l), "torch_elementwise": 4}
     out["roofline"], out["kernels"] = instrumented(step, ops, 3, math)
     from videopose3d_amd import range_guard
     out["range_guard"] = {k: v for k, v in range_guard.status(model).items() if k in ("tripped", "last", "io_last", "checks", "gram_off", "gram_log2_kappa")}
@@ -1075,6 +1150,11 @@ def main():
 
     if rank == 0 and world == 1:
         out["cfg5_semi_supervised_step"] = semi_supervised_step_latency(dev)
+        if not args.no_sweep:
+            try:
+                out["shape_sweep"] = shape_sweep(dev)
+            except Exception as ex:  # noqa: BLE001  (informational)
+                out["shape_sweep"] = {"error": repr(ex)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["mpjpe_vs_ref"] = cpu_baseline(dev)
     if rank == 0 and world == 1 and not args.no_rocm_ref:

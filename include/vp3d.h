@@ -132,6 +132,9 @@ typedef struct vp3d_epilogue {
 } vp3d_epilogue;
 
 int vp3d_version(void);
+/* kernel launches this library has issued in this process so far (every entry point counts the kernels it enqueues; launches
+ * inside a hipGraph capture count once, at capture): what bench.py reports as launches per step */
+int64_t vp3d_launch_count(void);
 const char* vp3d_last_error(void);
 
 /* number of 64-row statistic slabs a [M, *] output produces (size stat_sum / stat_m2 as slabs*N floats) */

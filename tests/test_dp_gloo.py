@@ -128,6 +128,83 @@ def test_dp_world2_gloo(tmp_path):
     assert abs(len(parts[0]) - len(parts[1])) <= 1
 
 
+def _guard_worker(rank, world, port, out_dir):
+    """The dynamic-range guard's decisions under data parallelism (videopose3d_amd/range_guard.py, round 6): two ranks whose
+    MEASUREMENTS differ -- the device kernels are replaced by a per-rank script, everything else (MAX-exchange over the gradient
+    exchange's group, training-call cadence, fixed-distance consumption, sticky parameter trips / re-evaluated input trips,
+    engine choice) is the shipped code on CPU tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dp.init_from_env("gloo")
+    from videopose3d_amd import engine, range_guard as G
+    engine.S16_MIN_FORWARD_FLOPS.update({True: 0.0, False: 0.0})
+    cpu = torch.device("cpu")
+    torch.manual_seed(7)
+    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=64).train()
+    m.math = "f16x3"
+    sync = dp.FlatGradSync(m.parameters(), direct_module=m)
+    assert G.dp_sink(m) is sync
+    script = {}            # measurement index of THIS rank -> (act, weight, kappa, input, head-gradient) spreads
+    n_meas = [0]
+
+    def fake_measure(mod, st, m_rows, x3=None):
+        v = script.get(n_meas[0], (3, 4, 0, 1, 1))
+        n_meas[0] += 1
+        st.out.copy_(torch.tensor(v, dtype=torch.int32))
+
+    G._measure = fake_measure
+    x = torch.zeros(4, 27, 34)
+
+    def run(n_calls, batches, eval_extra=()):
+        trace = []
+        for i in range(n_calls):
+            if rank == 0 and i in eval_extra:          # evaluation calls that only ONE rank makes: no collective, no cadence shift
+                G._tick(m, False, 2, 27, cpu, x)
+            G._tick(m, True, batches[rank], 27, cpu, x)
+            trace.append((G.tripped(m), engine.use_s16(m, 27, True, batch=batches[rank])))
+        return trace
+
+    # (A) rank 1 alone measures a hot input column in the second periodic measurement, and a normal one in the third
+    # measurement 0 = the synchronous one at the first call, 1.. = the periodic ones launched at training calls 1, 17, 33, ...
+    if rank == 1:
+        script[2] = (3, 4, 0, 20, 1)
+    trace = run(60, (4, 4), eval_extra=(3, 18, 19, 40))
+    st = G.status(m)
+    assert st["exchanges"] == n_meas[0] == 5, (st, n_meas)              # call 0 (sync) + training calls 1, 17, 33, 49
+    gathered = [None] * world
+    dist.all_gather_object(gathered, trace)
+    assert gathered[0] == gathered[1], "the ranks switched engines on different steps"
+    # call index i = training call i (the synchronous call 0 resets the counter): launched at 17, consumed at 17 + 8; re-evaluated
+    # from the measurement launched at 33, consumed at 41
+    expect = [(False, True)] * 25 + [(True, False)] * 16 + [(False, True)] * 19
+    assert trace == expect, [i for i, (a, b) in enumerate(zip(trace, expect)) if a != b]
+    assert st["io_last"] == (1, 1) and not st["trip_param"]
+
+    # (B) the short last batch (ranks hold 5 and 3 samples: their BatchNorm-bound statistics differ through sqrt(M - 1)); rank 0
+    # alone measures a parameter spread beyond the limit: both ranks leave the split-fp16 engine on the same step, for good
+    G.invalidate(m)
+    n_meas[0] = 0
+    script.clear()
+    if rank == 0:
+        script[1] = (13, 4, 0, 1, 1)
+    trace = run(30, (5, 3))
+    dist.all_gather_object(gathered, trace)
+    assert gathered[0] == gathered[1]
+    assert trace == [(False, True)] * 9 + [(True, False)] * 21          # launched at training call 1, consumed at 9, sticky
+    st = G.status(m)
+    assert st["trip_param"] and st["checks"] >= 2
+    n_before = n_meas[0]
+    run(20, (5, 3))
+    assert n_meas[0] == n_before                                         # a parameter trip stops the periodic measurements
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_guard_switches_every_rank_on_the_same_step(tmp_path):
+    world = 2
+    mp.spawn(_guard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
 def test_shard_bounds_cover_everything():
     for n in (1, 7, 8, 1024, 1031):
         for world in (1, 2, 4, 8):

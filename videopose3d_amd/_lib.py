@@ -110,6 +110,7 @@ _P = C.POINTER
 # name -> (restype, argtypes); every symbol declared in include/vp3d.h must appear here
 SIGNATURES = {
     "vp3d_version": (C.c_int, []),
+    "vp3d_launch_count": (_i64, []),
     "vp3d_last_error": (C.c_char_p, []),
     "vp3d_stat_slabs": (_i64, [_i64]),
     "vp3d_rows_gemm_splits": (C.c_int, [_i64, _i32, _i32]),

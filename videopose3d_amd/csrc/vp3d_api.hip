@@ -1,4 +1,5 @@
 // C ABI entry points for the temporal-convolution GEMMs + error plumbing (see include/vp3d.h).
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -14,6 +15,10 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static std::atomic<int64_t> g_launches{0};     // kernel launches issued by this library in this process (vp3d_launch_count)
+
+void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -129,6 +134,7 @@ using namespace vp3d;
 extern "C" {
 
 int vp3d_version(void) { return VP3D_VERSION; }
+int64_t vp3d_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 const char* vp3d_last_error(void) { return g_err; }
 int64_t vp3d_stat_slabs(int64_t M) { return (M + 63) / 64; }
 int vp3d_rows_gemm_splits(int64_t M, int32_t N, int32_t K) {

@@ -605,10 +605,10 @@ static void launch_bn_finalize(hipStream_t st, int C, int64_t M, int nslab, int 
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
                                float* save_invstd) {
   if (C % 16 == 0 && aligned16(stat_sum) && aligned16(stat_m2) && nslab >= 64)
-    hipLaunchKernelGGL(k_bn_finalize_v4, dim3(C / 16), dim3(4 * FIN4_GROUPS), 0, st, C, M, nslab, slab_rows, stat_sum, stat_m2, gamma,
+    VP3D_LAUNCH(k_bn_finalize_v4, dim3(C / 16), dim3(4 * FIN4_GROUPS), 0, st, C, M, nslab, slab_rows, stat_sum, stat_m2, gamma,
                        beta, eps, momentum, momentum_dev, running_mean, running_var, nbt, scale, shift, save_mean, save_invstd);
   else
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, st, C, M, nslab, slab_rows,
+    VP3D_LAUNCH(k_bn_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, st, C, M, nslab, slab_rows,
                        stat_sum, stat_m2, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var, nbt, scale, shift,
                        save_mean, save_invstd);
 }
@@ -655,7 +655,7 @@ int vp3d_bn_finalize_slab(vp3d_stream_t stream, int32_t C, int64_t M, int32_t sl
 int vp3d_bn_fold(vp3d_stream_t stream, int32_t C, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift) {
   VP3D_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_fold: bad argument");
-  hipLaunchKernelGGL(k_bn_fold, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+  VP3D_LAUNCH(k_bn_fold, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
                      running_mean, running_var, eps, scale, shift);
   return check_launch("bn_fold");
 }
@@ -691,10 +691,10 @@ int vp3d_bn_act_fwd(vp3d_stream_t stream, int64_t M, int32_t C, const float* y, 
   int lpr, rpb, gx, gy;
   col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
   if (vec)
-    hipLaunchKernelGGL((k_bn_act_fwd<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
+    VP3D_LAUNCH((k_bn_act_fwd<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
                        rm, out, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_act_fwd<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
+    VP3D_LAUNCH((k_bn_act_fwd<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, y, scale, shift, d,
                        rm, out, lpr, rpb);
   return check_launch("bn_act_fwd");
 }
@@ -713,10 +713,10 @@ int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* 
   VP3D_REQUIRE(!vec || (aligned16(go) && aligned16(y)), "bn_bwd_reduce: go / y must be 16-byte aligned");
   const DropP d = make_drop(drop);
   if (vec)
-    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+    VP3D_LAUNCH((k_bn_bwd_reduce<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, partials, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+    VP3D_LAUNCH((k_bn_bwd_reduce<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, partials, lpr, rpb);
   return check_launch("bn_bwd_reduce");
 }
@@ -724,7 +724,7 @@ int vp3d_bn_bwd_reduce(vp3d_stream_t stream, int64_t M, int32_t C, const float* 
 int vp3d_bn_bwd_finalize(vp3d_stream_t stream, int32_t C, const float* partials, int32_t nparts, float* dgamma,
                          float* dbeta) {
   VP3D_REQUIRE(C > 0 && nparts > 0 && partials && dgamma && dbeta, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, partials, nparts,
+  VP3D_LAUNCH(k_bn_bwd_finalize, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C, partials, nparts,
                      dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
 }
@@ -740,10 +740,10 @@ int vp3d_bn_bwd_apply(vp3d_stream_t stream, int64_t M, int32_t C, const float* g
   int lpr, rpb, gx, gy;
   col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
   if (vec)
-    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+    VP3D_LAUNCH((k_bn_bwd_apply<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, dgamma, dbeta, dy, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
+    VP3D_LAUNCH((k_bn_bwd_apply<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, dgamma, dbeta, dy, lpr, rpb);
   return check_launch("bn_bwd_apply");
 }
@@ -757,10 +757,10 @@ int vp3d_bn_bwd_apply_g(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   int lpr, rpb, gx, gy;
   col_geometry(M, C, vec, 2048, 1, &lpr, &rpb, &gx, &gy);
   if (vec)
-    hipLaunchKernelGGL((k_bn_bwd_apply_g<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
+    VP3D_LAUNCH((k_bn_bwd_apply_g<4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
                        invstd, dgamma, dbeta, dy, lpr, rpb);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply_g<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
+    VP3D_LAUNCH((k_bn_bwd_apply_g<1>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, g, y, scale, mean,
                        invstd, dgamma, dbeta, dy, lpr, rpb);
   return check_launch("bn_bwd_apply_g");
 }
@@ -768,7 +768,7 @@ int vp3d_bn_bwd_apply_g(vp3d_stream_t stream, int64_t M, int32_t C, const float*
 int vp3d_pack_weight(vp3d_stream_t stream, const float* w, int32_t c_out, int32_t c_in, int32_t taps,
                      const float* scale, float* out, int32_t ld_out) {
   VP3D_REQUIRE(w && out && c_out > 0 && c_in > 0 && taps > 0 && ld_out >= taps * c_in, "pack_weight: bad argument");
-  hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream, c_out,
+  VP3D_LAUNCH(k_pack_weight, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream, c_out,
                      c_in, taps, w, scale, out, ld_out);
   return check_launch("pack_weight");
 }
@@ -779,20 +779,20 @@ int vp3d_wgrad_reduce(vp3d_stream_t stream, const float* partials, int32_t ld_pa
                "wgrad_reduce: bad argument");
   const bool vec = c_in % 4 == 0 && ld_part % 4 == 0 && aligned16(partials) && aligned16(dw) && (taps == 1 || taps == 3);
   if (vec && taps == 3)
-    hipLaunchKernelGGL((k_wgrad_reduce_v4<3>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
+    VP3D_LAUNCH((k_wgrad_reduce_v4<3>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
                        splits, c_out, c_in, partials, ld_part, dw);
   else if (vec)
-    hipLaunchKernelGGL((k_wgrad_reduce_v4<1>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
+    VP3D_LAUNCH((k_wgrad_reduce_v4<1>), dim3(stream_grid((int64_t)c_out * c_in / 4)), dim3(256), 0, (hipStream_t)stream,
                        splits, c_out, c_in, partials, ld_part, dw);
   else
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
+    VP3D_LAUNCH(k_wgrad_reduce, dim3(stream_grid((int64_t)c_out * c_in)), dim3(256), 0, (hipStream_t)stream,
                        splits, c_out, c_in, taps, partials, ld_part, dw);
   return check_launch("wgrad_reduce");
 }
 
 int vp3d_colsum(vp3d_stream_t stream, int64_t M, int32_t N, const float* g, int32_t ld, float* out) {
   VP3D_REQUIRE(M > 0 && N > 0 && g && out && ld >= N, "colsum: bad argument");
-  hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, (hipStream_t)stream, M, N, g, ld, out);
+  VP3D_LAUNCH(k_colsum, dim3(N), dim3(256), 0, (hipStream_t)stream, M, N, g, ld, out);
   return check_launch("colsum");
 }
 
@@ -806,21 +806,21 @@ int vp3d_im2row(vp3d_stream_t stream, const vp3d_rowmap* map, const float* x, in
                "im2row: rows run past the end of a sample");
   const int64_t M = (int64_t)map->batch * map->t_dst;
   VP3D_REQUIRE(M < ((int64_t)1 << 31), "im2row: more than 2^31 rows");
-  hipLaunchKernelGGL(k_im2row, dim3(stream_grid(M * (kpad / 4))), dim3(256), 0, (hipStream_t)stream, (int)M, map->t_dst,
+  VP3D_LAUNCH(k_im2row, dim3(stream_grid(M * (kpad / 4))), dim3(256), 0, (hipStream_t)stream, (int)M, map->t_dst,
                      map->t_src, map->t_stride, ldx, k_valid, kpad, one_col < 0 ? -1 : one_col, x, out);
   return check_launch("im2row");
 }
 
 int vp3d_dropout_mask(vp3d_stream_t stream, int64_t n, const vp3d_dropout* drop, float* out) {
   VP3D_REQUIRE(n > 0 && out, "dropout_mask: bad argument");
-  hipLaunchKernelGGL(k_dropout_mask, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, make_drop(drop), out);
+  VP3D_LAUNCH(k_dropout_mask, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, make_drop(drop), out);
   return check_launch("dropout_mask");
 }
 
 int vp3d_project_to_2d_fwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
                            const float* cam, int32_t linear, float* out) {
   VP3D_REQUIRE(n_cam > 0 && pts_per_cam > 0 && X && cam && out, "project_to_2d_fwd: bad argument");
-  hipLaunchKernelGGL(k_project_fwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
+  VP3D_LAUNCH(k_project_fwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
                      pts_per_cam, X, cam, linear, out);
   return check_launch("project_to_2d_fwd");
 }
@@ -828,7 +828,7 @@ int vp3d_project_to_2d_fwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_
 int vp3d_project_to_2d_bwd(vp3d_stream_t stream, int64_t n_cam, int64_t pts_per_cam, const float* X,
                            const float* cam, const float* gout, int32_t linear, float* dX) {
   VP3D_REQUIRE(n_cam > 0 && pts_per_cam > 0 && X && cam && gout && dX, "project_to_2d_bwd: bad argument");
-  hipLaunchKernelGGL(k_project_bwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
+  VP3D_LAUNCH(k_project_bwd, dim3(stream_grid(n_cam * pts_per_cam)), dim3(256), 0, (hipStream_t)stream, n_cam,
                      pts_per_cam, X, cam, gout, linear, dX);
   return check_launch("project_to_2d_bwd");
 }

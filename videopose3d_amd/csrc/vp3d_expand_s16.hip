@@ -697,8 +697,8 @@ int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, con
   a.bits = bits;
   a.drop = drop;
   const dim3 grid(a.n_slices * a.row_groups), block(EX_NT);
-  if (out != nullptr) hipLaunchKernelGGL(k_expand_fwd_s16<true>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(k_expand_fwd_s16<false>, grid, block, 0, s, a);
+  if (out != nullptr) VP3D_LAUNCH(k_expand_fwd_s16<true>, grid, block, 0, s, a);
+  else VP3D_LAUNCH(k_expand_fwd_s16<false>, grid, block, 0, s, a);
   return check_launch("expand_fwd_s16");
 }
 
@@ -730,10 +730,10 @@ int launch_expand_bwd_p_s16(hipStream_t s, int64_t M, int32_t C, int32_t kpad, c
   a.inv_keep = 1.0f / (1.0f - p);
   const dim3 grid(a.n_slices * groups), block(EB_NT);
   switch (kpad / 32) {
-    case 1: hipLaunchKernelGGL(k_expand_bwd_p_s16<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_expand_bwd_p_s16<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_expand_bwd_p_s16<3>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_expand_bwd_p_s16<4>, grid, block, 0, s, a); break;
+    case 1: VP3D_LAUNCH(k_expand_bwd_p_s16<1>, grid, block, 0, s, a); break;
+    case 2: VP3D_LAUNCH(k_expand_bwd_p_s16<2>, grid, block, 0, s, a); break;
+    case 3: VP3D_LAUNCH(k_expand_bwd_p_s16<3>, grid, block, 0, s, a); break;
+    default: VP3D_LAUNCH(k_expand_bwd_p_s16<4>, grid, block, 0, s, a); break;
   }
   return check_launch("expand_bwd_p_s16");
 }
@@ -773,10 +773,10 @@ int launch_expand_gram_s16(hipStream_t s, int64_t M, int32_t kpad, const float* 
   a.rows_per = (int32_t)((slabs + groups - 1) / groups) * EB_SLAB;
   const dim3 grid(groups), block(EB_NT);
   switch (kpad / 32) {
-    case 1: hipLaunchKernelGGL(k_expand_gram_s16<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_expand_gram_s16<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_expand_gram_s16<3>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_expand_gram_s16<4>, grid, block, 0, s, a); break;
+    case 1: VP3D_LAUNCH(k_expand_gram_s16<1>, grid, block, 0, s, a); break;
+    case 2: VP3D_LAUNCH(k_expand_gram_s16<2>, grid, block, 0, s, a); break;
+    case 3: VP3D_LAUNCH(k_expand_gram_s16<3>, grid, block, 0, s, a); break;
+    default: VP3D_LAUNCH(k_expand_gram_s16<4>, grid, block, 0, s, a); break;
   }
   return check_launch("expand_gram_s16");
 }

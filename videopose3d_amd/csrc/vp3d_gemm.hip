@@ -994,15 +994,15 @@ int launch_rows_gemm(hipStream_t s, const RowsGemmArgs& a_in, bool b_kcontig) {
               aligned16(a.zeros);
   if (!b_kcontig) fast = fast && (a.N % BN == 0) && (a.b_tap_stride % 4 == 0);
   if (b_kcontig) {
-    if (fast) hipLaunchKernelGGL((k_rows_gemm<true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_rows_gemm<true, false>), grid, block, 0, s, a);
+    if (fast) VP3D_LAUNCH((k_rows_gemm<true, true>), grid, block, 0, s, a);
+    else VP3D_LAUNCH((k_rows_gemm<true, false>), grid, block, 0, s, a);
   } else {
-    if (fast) hipLaunchKernelGGL((k_rows_gemm<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_rows_gemm<false, false>), grid, block, 0, s, a);
+    if (fast) VP3D_LAUNCH((k_rows_gemm<false, true>), grid, block, 0, s, a);
+    else VP3D_LAUNCH((k_rows_gemm<false, false>), grid, block, 0, s, a);
   }
   int rc = check_launch("rows_gemm");
   if (rc != VP3D_OK || a.splits == 1) return rc;
-  hipLaunchKernelGGL(k_splitk_finish, dim3(a.tail_pos, 4), dim3(256), 0, s, a.part, a.splits, a.pos_full, a.tail_pos,
+  VP3D_LAUNCH(k_splitk_finish, dim3(a.tail_pos, 4), dim3(256), 0, s, a.part, a.splits, a.pos_full, a.tail_pos,
                      a.m_tiles, a.n_tiles, a.M, a.N, a.epi.vec, a.t_dst, a.epi);
   return check_launch("splitk_finish");
 }
@@ -1011,8 +1011,8 @@ int launch_red_gemm(hipStream_t s, const RedGemmArgs& a) {
   const dim3 grid(a.m_tiles * a.n_tiles * a.splits), block(NTHREADS);
   const bool fast = (a.Mo % BM == 0) && (a.c_x % BN == 0) && (a.ldg % 4 == 0) && (a.ldx % 4 == 0) &&
                     aligned16(a.G) && aligned16(a.X) && aligned16(a.zeros);
-  if (fast) hipLaunchKernelGGL((k_red_gemm<true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_red_gemm<false>), grid, block, 0, s, a);
+  if (fast) VP3D_LAUNCH((k_red_gemm<true>), grid, block, 0, s, a);
+  else VP3D_LAUNCH((k_red_gemm<false>), grid, block, 0, s, a);
   return check_launch("red_gemm");
 }
 

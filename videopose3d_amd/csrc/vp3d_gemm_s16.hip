@@ -1449,7 +1449,7 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
   a.kt_per_split = (nkt + splits - 1) / splits;
   if (a.epi.act_scale != nullptr) {
     if constexpr (C::BUF && !C::PIPE && C::BKE == 32 && !C::MIX) {          // (instantiated for the planner's configurations only)
-      hipLaunchKernelGGL((k_nt_s16<C, true>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
+      VP3D_LAUNCH((k_nt_s16<C, true>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
       return check_launch("nt_s16(act)");
     } else {
       set_error("nt_s16: the fused activation epilogue exists for tile configurations 20 / 22 / 30 only");
@@ -1461,14 +1461,14 @@ int launch_cfg(hipStream_t s, RowsGemmArgs a, int splits, int m_begin = 0, int m
       VP3D_REQUIRE(splits == 1 && a.epi.vec && a.N % C::BN == 0 && a.epi.ab_c % C::BN == 0 && a.m_begin == 0 && a.m_end == a.M,
                    "nt_s16: the fused BatchNorm-backward sums need one K slice, 16-byte aligned fp32 output and c_out, c_up "
                    "multiples of the %d-column tile", C::BN);
-      hipLaunchKernelGGL((k_nt_s16<C, false, false, true>), dim3(positions), dim3(C::NT), 0, s, a);
+      VP3D_LAUNCH((k_nt_s16<C, false, false, true>), dim3(positions), dim3(C::NT), 0, s, a);
       return check_launch("nt_s16(red)");
     } else {
       set_error("nt_s16: the fused BatchNorm-backward sums exist for tile configurations 20 / 22 / 28 only (operands below 2 GiB)");
       return VP3D_E_INVALID;
     }
   }
-  hipLaunchKernelGGL((k_nt_s16<C>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
+  VP3D_LAUNCH((k_nt_s16<C>), dim3(a.pos_full), dim3(C::NT), 0, s, a);
   return check_launch("nt_s16");
 }
 
@@ -1522,7 +1522,7 @@ int launch_cfg_sk(hipStream_t s, RowsGemmArgs a, float* ws, int64_t ws_floats, i
   a.sk_max_seg = g.max_seg;
   a.sk_ws = ws;
   a.sk_cnt = tickets;
-  hipLaunchKernelGGL((k_nt_s16<C, false, true>), dim3(g.t_dp + g.blocks), dim3(C::NT), 0, s, a);
+  VP3D_LAUNCH((k_nt_s16<C, false, true>), dim3(g.t_dp + g.blocks), dim3(C::NT), 0, s, a);
   return check_launch("nt_s16(stream-K)");
 }
 
@@ -1790,7 +1790,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
       return VP3D_E_INVALID;
   }
   if (rc != VP3D_OK || splits == 1 || raw_partials) return rc;
-  hipLaunchKernelGGL(k_s16_finish, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(256), 0, s, ws, splits, a.part_floats, a.M,
+  VP3D_LAUNCH(k_s16_finish, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(256), 0, s, ws, splits, a.part_floats, a.M,
                      a.N, (int)(a.epi.vec && a.N % 4 == 0), a.t_dst, a.epi);
   return check_launch("s16_finish");
 }
@@ -1798,7 +1798,7 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a_in, int cfg, int splits, 
 int launch_split_rows(hipStream_t s, int64_t M, int32_t C, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
                       const float* bound) {
   const int64_t groups = M * (C / 8);
-  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, groups, C / 8, src, ld_src,
+  VP3D_LAUNCH(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, groups, C / 8, src, ld_src,
                      dst, ld_dst, bound);
   return check_launch("split_rows");
 }
@@ -1825,14 +1825,14 @@ int launch_wgrad_rows_s16(hipStream_t s, int64_t Mk, const float* dy, int64_t ld
   a.kt_per_split = (nkt + splits - 1) / splits;
   a.per_xcd = (a.m_tiles * a.n_tiles * splits + 7) / 8;            // 8 equal XCD shares of the (slice, tile) units
   const unsigned grid = 8u * a.per_xcd;
-  if (narrow) hipLaunchKernelGGL(k_tn_s16<1>, dim3(grid), dim3(TN_NT), 0, s, a);
-  else hipLaunchKernelGGL(k_tn_s16<2>, dim3(grid), dim3(TN_NT), 0, s, a);
+  if (narrow) VP3D_LAUNCH(k_tn_s16<1>, dim3(grid), dim3(TN_NT), 0, s, a);
+  else VP3D_LAUNCH(k_tn_s16<2>, dim3(grid), dim3(TN_NT), 0, s, a);
   return check_launch("wgrad_rows_s16");
 }
 
 int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound, float floor_) {
   const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);        // >= 4 float4 per thread
-  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, src, bound, floor_);
+  VP3D_LAUNCH(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, src, bound, floor_);
   return check_launch("amax");
 }
 

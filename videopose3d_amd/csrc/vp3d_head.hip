@@ -271,7 +271,7 @@ int vp3d_head_fwd(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const f
                   float* out) {
   VP3D_REQUIRE(head_shape_ok(M, K, N), "head_fwd: unsupported shape (M=%lld K=%d N=%d; vp3d_head_supported)", (long long)M, K, N);
   VP3D_REQUIRE(h && w && out && aligned16(h) && aligned16(w), "head_fwd: null or misaligned pointer");
-  hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)((M + HEAD_RT - 1) / HEAD_RT)), dim3(256), (size_t)HEAD_RT * K * 4,
+  VP3D_LAUNCH(k_head_fwd, dim3((unsigned)((M + HEAD_RT - 1) / HEAD_RT)), dim3(256), (size_t)HEAD_RT * K * 4,
                      (hipStream_t)stream, (int)M, K, N, h, w, bias, out);
   return check_launch("head_fwd");
 }
@@ -288,7 +288,7 @@ int vp3d_head_bwd(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const f
   a.kchunks = (K + 255) / 256;
   a.slices = (int)((M + HEAD_RS - 1) / HEAD_RS);
   const int n_dw = ws != nullptr ? a.slices * a.kchunks : 0;
-  hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)(a.n_dh + n_dw)), dim3(256), 0, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_head_bwd, dim3((unsigned)(a.n_dh + n_dw)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("head_bwd");
 }
 
@@ -297,7 +297,7 @@ int vp3d_head_fold(vp3d_stream_t stream, int64_t M, int32_t K, int32_t N, const 
   VP3D_REQUIRE(ws && dw && aligned16(ws) && aligned16(dw), "head_fold: null or misaligned pointer");
   const int slices = (int)((M + HEAD_RS - 1) / HEAD_RS);
   const int64_t nk4 = (int64_t)N * (K / 4);
-  hipLaunchKernelGGL(k_head_fold, dim3((unsigned)((nk4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, K, N, slices, ws, dw,
+  VP3D_LAUNCH(k_head_fold, dim3((unsigned)((nk4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, K, N, slices, ws, dw,
                      db);
   return check_launch("head_fold");
 }

@@ -11,6 +11,14 @@ namespace vp3d {
 // thread-local last-error string
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void count_launch();      // vp3d_launch_count(): one per kernel enqueued
+// every kernel launch of the library goes through this (bench.py reports launches per step: the step is a dependent chain of
+// ~200 launches and their count is a lever of its own)
+#define VP3D_LAUNCH(...)               \
+  do {                                 \
+    ::vp3d::count_launch();            \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
 
 #define VP3D_REQUIRE(cond, ...)              \
   do {                                       \

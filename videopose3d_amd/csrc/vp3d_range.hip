@@ -181,9 +181,9 @@ int vp3d_range_cols(vp3d_stream_t stream, int64_t M, int32_t C, const float* x, 
   if (blocks > 2048) blocks = 2048;
   const int rows_per_block = (int)((M + blocks - 1) / blocks);
   blocks = (M + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(k_range_cols, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, M, (int)C, ld, rows_per_block, ws);
+  VP3D_LAUNCH(k_range_cols, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, M, (int)C, ld, rows_per_block, ws);
   if (int rc = check_launch("range_cols")) return rc;
-  hipLaunchKernelGGL(k_range_cols_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)C, ws, out);
+  VP3D_LAUNCH(k_range_cols_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)C, ws, out);
   return check_launch("range_cols_finish");
 }
 
@@ -203,7 +203,7 @@ int vp3d_range_stats(vp3d_stream_t stream, int32_t n_layers, int32_t C, const fl
     }
     a.C = C;
     a.out = out;
-    hipLaunchKernelGGL(k_range_affine, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    VP3D_LAUNCH(k_range_affine, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, a);
     if (int rc = check_launch("range_affine")) return rc;
   }
   if (n_tensors > 0) {
@@ -222,9 +222,9 @@ int vp3d_range_stats(vp3d_stream_t stream, int32_t n_layers, int32_t C, const fl
     VP3D_REQUIRE((max_rows + 3) / 4 <= 0x7fffffff, "range_stats: too many rows");
     r.ws = ws;
     r.out = out;
-    hipLaunchKernelGGL(k_range_rows, dim3((unsigned)((max_rows + 3) / 4), n_tensors), dim3(256), 0, (hipStream_t)stream, r);
+    VP3D_LAUNCH(k_range_rows, dim3((unsigned)((max_rows + 3) / 4), n_tensors), dim3(256), 0, (hipStream_t)stream, r);
     if (int rc = check_launch("range_rows")) return rc;
-    hipLaunchKernelGGL(k_range_rows_finish, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, r);
+    VP3D_LAUNCH(k_range_rows_finish, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, r);
     if (int rc = check_launch("range_rows_finish")) return rc;
   }
   return 0;

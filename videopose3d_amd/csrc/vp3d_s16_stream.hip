@@ -904,7 +904,7 @@ int vp3d_bn_act_fwd_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float*
   const int R = 64 * t.taps;
   VP3D_REQUIRE((M + R - 1) / R <= 65535, "bn_act_fwd_s16: more than 65535 row tiles (M=%lld)", (long long)M);
   const size_t lds = t_out ? (size_t)R * TPITCH * 4 : 0;
-  hipLaunchKernelGGL(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
+  VP3D_LAUNCH(k_bn_act_fwd_s16, dim3(C / 64, (unsigned)((M + R - 1) / R)), dim3(256), lds, (hipStream_t)stream,
                      (int)M, C, y, scale, shift, d, rm, out_bound, (float*)out, out_f32, t, act_bits);
   return check_launch("bn_act_fwd_s16");
 }
@@ -930,10 +930,10 @@ int vp3d_bn_bwd_apply_s16(vp3d_stream_t stream, int64_t M, int32_t C, const floa
   gy = gy > 65535 ? 65535 : gy;                 // (the kernel strides over the tiles)
   const dim3 grid((unsigned)gx, (unsigned)gy);
   if (act_bits != nullptr)
-    hipLaunchKernelGGL((k_bn_bwd_apply_s16<true>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale, shift,
+    VP3D_LAUNCH((k_bn_bwd_apply_s16<true>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale, shift,
                        mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t, (float*)nullptr);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply_s16<false>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale,
+    VP3D_LAUNCH((k_bn_bwd_apply_s16<false>), grid, dim3(256), lds, (hipStream_t)stream, (int)M, C, go, y, scale,
                        shift, mean, invstd, d, act_bits, d.inv_keep, dgamma, dbeta, out_bound, (float*)dy, t, (float*)nullptr);
   return check_launch("bn_bwd_apply_s16");
 }
@@ -953,7 +953,7 @@ int vp3d_act_mask_s16(vp3d_stream_t stream, int64_t M, int32_t C, const float* g
   int64_t gy = (ntiles + per_block - 1) / per_block;
   gy = gy > 65535 ? 65535 : gy;
   DropP d{};
-  hipLaunchKernelGGL((k_bn_bwd_apply_s16<true, true>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, (int)M,
+  VP3D_LAUNCH((k_bn_bwd_apply_s16<true, true>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, (int)M,
                      C, go, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, d, act_bits, 1.0f / (1.0f - p), (const float*)nullptr, (const float*)nullptr, go_bound,
                      (float*)rows_out, t, g_bound);
@@ -973,7 +973,7 @@ int vp3d_gather_t_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
   TOut t{(float*)t_out, ld_t, 1};
   const int64_t tiles = (M + 63) / 64;
   VP3D_REQUIRE(tiles <= 65535, "gather_t_s16: more than 65535 row tiles (M=%lld)", (long long)M);
-  hipLaunchKernelGGL(k_gather_t_s16, dim3(C / 64, (unsigned)tiles, map->taps), dim3(256), (size_t)64 * TPITCH * 4,
+  VP3D_LAUNCH(k_gather_t_s16, dim3(C / 64, (unsigned)tiles, map->taps), dim3(256), (size_t)64 * TPITCH * 4,
                      (hipStream_t)stream, (int)M, C, map->t_dst, map->t_src, map->t_stride, map->tap_step, map->t_off,
                      (const float*)x, t);
   return check_launch("gather_t_s16");
@@ -981,7 +981,7 @@ int vp3d_gather_t_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const void* 
 
 int vp3d_sum_slices(vp3d_stream_t stream, int64_t n, int32_t splits, const float* ws, double* out) {
   VP3D_REQUIRE(n > 0 && splits > 0 && ws && out, "sum_slices: bad argument");
-  hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n, splits, ws, out);
+  VP3D_LAUNCH(k_sum_slices, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n, splits, ws, out);
   return check_launch("sum_slices");
 }
 
@@ -1142,7 +1142,7 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
   int rc = launch_expand_gram_s16((hipStream_t)stream, M, kpad, (const float*)xt, ld_t, x_bound, one_col, groups, part);
   if (rc != VP3D_OK) return rc;
   const int64_t n = (int64_t)kpad * kpad;
-  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (int)n, groups, part, gram);
+  VP3D_LAUNCH(k_gram_reduce, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (int)n, groups, part, gram);
   rc = check_launch("expand_stats_gram(sum)");
   if (rc != VP3D_OK) return rc;
   const size_t lds = ((size_t)kv * kpad + 2 * kpad) * sizeof(double) + (size_t)8 * kpad * sizeof(float);
@@ -1156,7 +1156,7 @@ int vp3d_expand_stats_gram_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32
     VP3D_REQUIRE(st == hipSuccess, "expand_stats_gram_s16: cannot opt in to %zu B of dynamic LDS (%s)", lds, hipGetErrorString(st));
     attr_set[dev_id] = true;
   }
-  hipLaunchKernelGGL(k_expand_stats_fin, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, (double)M,
+  VP3D_LAUNCH(k_expand_stats_fin, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, (double)M,
                      gram, (const float*)xt, ld_t, x_bound, w_packed, gamma, beta, eps, momentum, momentum_dev, running_mean,
                      running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, illcond);
   return check_launch("expand_stats_gram(fin)");
@@ -1186,7 +1186,7 @@ int vp3d_expand_bwd_gram_s16(vp3d_stream_t stream, int32_t C, int32_t c_in, int3
     VP3D_REQUIRE(st == hipSuccess, "expand_bwd_s16: cannot opt in to %zu B of dynamic LDS (%s)", lds, hipGetErrorString(st));
     attr_set[dev_id] = true;
   }
-  hipLaunchKernelGGL(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
+  VP3D_LAUNCH(k_expand_bwd_post, dim3((C + 7) / 8), dim3(256), lds, (hipStream_t)stream, C, kpad, kv, one_col, c_in, taps,
                      splits, p_partials, gram, w_packed, scale, mean, invstd, 1.0 / (double)M, dgamma, dbeta, dw,
                      (const float*)x_t, ld_t, x_bound);
   return check_launch("expand_bwd_s16");
@@ -1215,7 +1215,7 @@ int vp3d_bn_bwd_reduce_bits(vp3d_stream_t stream, int64_t M, int32_t C, const fl
   if (partials == nullptr) return VP3D_OK;      // size query
   VP3D_REQUIRE(go && y && mean && invstd && act_bits && aligned16(go) && aligned16(y) && aligned16(partials),
                "bn_bwd_reduce_bits: null or unaligned pointer");
-  hipLaunchKernelGGL(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
+  VP3D_LAUNCH(k_bn_bwd_reduce_bits, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (int)M, C, go, y, mean,
                      invstd, act_bits, keep_scale, partials, lpr, rpb);
   return check_launch("bn_bwd_reduce_bits");
 }
@@ -1253,7 +1253,7 @@ int vp3d_bn_bwd_reduce_fin_s16(vp3d_stream_t stream, int64_t M, int32_t C, const
   fin.inv_keep = 1.0f / (1.0f - p);
   fin.inv_m = 1.0f / (float)M;
   fin.sqrt_m1 = sqrtf((float)(M > 1 ? M - 1 : 1));
-  hipLaunchKernelGGL(k_bn_bwd_reduce_strips, dim3(strips, (unsigned)R), dim3(256), 0, (hipStream_t)stream, (int)M, C, rows_per,
+  VP3D_LAUNCH(k_bn_bwd_reduce_strips, dim3(strips, (unsigned)R), dim3(256), 0, (hipStream_t)stream, (int)M, C, rows_per,
                      go, y, mean, invstd, act_bits, partials, fin);
   return check_launch("bn_bwd_reduce_fin_s16");
 }
@@ -1268,7 +1268,7 @@ int vp3d_split_t(vp3d_stream_t stream, int64_t M, int32_t C, const float* src, i
   TOut t{(float*)t_out, ld_t, 1};
   VP3D_REQUIRE((M + 63) / 64 <= 65535, "split_t: more than 65535 row tiles (M=%lld)", (long long)M);
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
-  hipLaunchKernelGGL(k_split_t<false>, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
+  VP3D_LAUNCH(k_split_t<false>, dim3(C / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, C,
                      src, ld_src, bound, (float*)out, ld_out, t, Im2Row{});
   return check_launch("split_t");
 }
@@ -1289,7 +1289,7 @@ int vp3d_im2row_split_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const fl
   TOut t{(float*)t_out, ld_t, 1};
   const size_t lds = t_out ? (size_t)64 * TPITCH * 4 : 0;
   const Im2Row g{map->t_dst, map->t_src, map->t_stride, ldx, k_valid, one_col < 0 ? -1 : one_col, make_fastdiv(map->t_dst)};
-  hipLaunchKernelGGL(k_split_t<true>, dim3(kpad / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, kpad,
+  VP3D_LAUNCH(k_split_t<true>, dim3(kpad / 64, (unsigned)((M + 63) / 64)), dim3(256), lds, (hipStream_t)stream, (int)M, kpad,
                      x, (int64_t)0, bound, (float*)out, (int64_t)kpad, t, g);
   return check_launch("im2row_split_s16");
 }
@@ -1302,7 +1302,7 @@ int vp3d_pack_weight_s16(vp3d_stream_t stream, const float* w, int32_t c_out, in
                    (wd == nullptr || (aligned16(wd) && ld_d % 8 == 0 && ld_d >= (dilated_form ? (int64_t)taps * c_out : c_out))),
                "pack_weight_s16: bad pitches");
   const size_t lds = (size_t)taps * 64 * TPITCH * 4;
-  hipLaunchKernelGGL(k_pack_weight_s16, dim3(c_in / 64, c_out / 64), dim3(256), lds, (hipStream_t)stream, c_out, c_in, taps,
+  VP3D_LAUNCH(k_pack_weight_s16, dim3(c_in / 64, c_out / 64), dim3(256), lds, (hipStream_t)stream, c_out, c_in, taps,
                      w, bound, (float*)wf, ld_f, (float*)wd, ld_d, dilated_form);
   return check_launch("pack_weight_s16");
 }
@@ -1310,7 +1310,7 @@ int vp3d_pack_weight_s16(vp3d_stream_t stream, const float* w, int32_t c_out, in
 int vp3d_act_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* gamma, const float* beta, float p,
                    const float* res_bound, float* out) {
   VP3D_REQUIRE(C > 0 && M > 0 && gamma && beta && out && p >= 0.f && p < 1.f, "act_bound: bad argument");
-  hipLaunchKernelGGL(k_act_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, sqrtf((float)(M > 1 ? M - 1 : 1)), gamma,
+  VP3D_LAUNCH(k_act_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, sqrtf((float)(M > 1 ? M - 1 : 1)), gamma,
                      beta, 1.0f / (1.0f - p), res_bound, out);
   return check_launch("act_bound");
 }
@@ -1318,7 +1318,7 @@ int vp3d_act_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* gamm
 int vp3d_dy_bound(vp3d_stream_t stream, int32_t C, int64_t M, const float* scale, const float* dgamma,
                   const float* dbeta, const float* go_bound, float p, float* out) {
   VP3D_REQUIRE(C > 0 && M > 0 && scale && dgamma && dbeta && go_bound && out && p >= 0.f && p < 1.f, "dy_bound: bad argument");
-  hipLaunchKernelGGL(k_dy_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, 1.0f / (float)M,
+  VP3D_LAUNCH(k_dy_bound, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, 1.0f / (float)M,
                      sqrtf((float)(M > 1 ? M - 1 : 1)), scale, dgamma, dbeta, go_bound, 1.0f / (1.0f - p), out);
   return check_launch("dy_bound");
 }
@@ -1339,7 +1339,7 @@ int vp3d_amax_multi(vp3d_stream_t stream, int32_t n_tensors, const float* const*
   a.bounds = bounds;
   int64_t blocks = (nmax + 256 * 32 - 1) / (256 * 32);           // >= 8 float4 per thread of the largest tensor
   blocks = blocks < 512 ? blocks : 512;
-  hipLaunchKernelGGL(k_amax_multi, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_amax_multi, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("amax_multi");
 }
 
@@ -1364,7 +1364,7 @@ int vp3d_pack_weight_s16_multi(vp3d_stream_t stream, int32_t n_layers, const flo
   a.bounds = bounds;
   a.c_out = c_out;
   a.c_in = c_in;
-  hipLaunchKernelGGL(k_pack_weight_s16_multi, dim3(c_in / 64, c_out / 64, n_layers), dim3(256), (size_t)tmax * 64 * TPITCH * 4,
+  VP3D_LAUNCH(k_pack_weight_s16_multi, dim3(c_in / 64, c_out / 64, n_layers), dim3(256), (size_t)tmax * 64 * TPITCH * 4,
                      (hipStream_t)stream, a);
   return check_launch("pack_weight_s16_multi");
 }
@@ -1385,7 +1385,7 @@ int vp3d_act_bounds_multi(vp3d_stream_t stream, int32_t n_layers, int32_t C, con
   a.n_layers = n_layers;
   a.C = C;
   a.inv_keep = 1.0f / (1.0f - p);
-  hipLaunchKernelGGL(k_act_bounds_multi, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_act_bounds_multi, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return check_launch("act_bounds_multi");
 }
 
@@ -1419,7 +1419,7 @@ int vp3d_prologue_a_s16(vp3d_stream_t stream, int32_t n_tensors, const float* co
   a.ab.inv_keep = 1.0f / (1.0f - p);
   int64_t blocks = (nmax + 256 * 32 - 1) / (256 * 32);
   blocks = blocks < 512 ? blocks : 512;
-  hipLaunchKernelGGL(k_prologue_a, dim3((unsigned)blocks, n_tensors + 1), dim3(256), 0, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_prologue_a, dim3((unsigned)blocks, n_tensors + 1), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("prologue_a_s16");
 }
 
@@ -1467,7 +1467,7 @@ int vp3d_prologue_b_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const floa
   a.pk_layers = n_layers;
   const int n_pk = n_layers ? (c_in / 64) * (c_out / 64) * n_layers : 0;
   const size_t lds = (size_t)(n_layers ? tmax : 1) * 64 * TPITCH * 4;
-  hipLaunchKernelGGL(k_prologue_b, dim3((unsigned)(a.n_in + a.n_w0 + n_pk)), dim3(256), lds, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_prologue_b, dim3((unsigned)(a.n_in + a.n_w0 + n_pk)), dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("prologue_b_s16");
 }
 
@@ -1476,7 +1476,7 @@ int vp3d_bn_bwd_finalize_s16(vp3d_stream_t stream, int32_t C, int64_t M, const f
                              float* dy_bound) {
   VP3D_REQUIRE(C > 0 && M > 0 && nparts > 0 && partials && dgamma && dbeta && scale && go_bound && dy_bound && p >= 0.f && p < 1.f,
                "bn_bwd_finalize_s16: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize_bound, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C,
+  VP3D_LAUNCH(k_bn_bwd_finalize_bound, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_GROUPS), 0, (hipStream_t)stream, C,
                      partials, nparts, dgamma, dbeta, scale, go_bound, 1.0f / (1.0f - p), 1.0f / (float)M,
                      sqrtf((float)(M > 1 ? M - 1 : 1)), dy_bound);
   return check_launch("bn_bwd_finalize_s16");

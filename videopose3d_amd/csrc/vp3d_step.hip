@@ -256,14 +256,14 @@ int vp3d_gather_chunks(vp3d_stream_t stream, const vp3d_gather* g) {
   a.len2 = g->chunk_length + 2 * g->pad;
   const int64_t total = (int64_t)a.n * a.len2 * a.j2 * a.f2 + (a.p3 ? (int64_t)a.n * a.chunk_len * a.j3 * a.f3 : 0) +
                         (a.cams ? (int64_t)a.n * a.cam_dim : 0);
-  hipLaunchKernelGGL(k_gather_chunks, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
+  VP3D_LAUNCH(k_gather_chunks, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("gather_chunks");
 }
 
 int vp3d_tta_fold(vp3d_stream_t stream, int64_t n_frames, int32_t n_joints, int32_t dim, const float* pred,
                   const int32_t* joints_perm, float* out) {
   VP3D_REQUIRE(n_frames > 0 && n_joints > 0 && dim > 0 && pred && out, "tta_fold: bad argument");
-  hipLaunchKernelGGL(k_tta_fold, dim3(grid_for(n_frames * n_joints * dim, 256, 256 * 8)), dim3(256), 0,
+  VP3D_LAUNCH(k_tta_fold, dim3(grid_for(n_frames * n_joints * dim, 256, 256 * 8)), dim3(256), 0,
                      (hipStream_t)stream, n_frames, n_joints, dim, pred, joints_perm, out);
   return check_launch("tta_fold");
 }
@@ -283,17 +283,17 @@ int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pr
   const float inv_n = (float)(1.0 / (double)n_pts);
   double* part = reinterpret_cast<double*>(ws);
   if (dim == 3)
-    hipLaunchKernelGGL((k_mpjpe<3>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
+    VP3D_LAUNCH((k_mpjpe<3>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
                        w, inv_n, grad, part, loss);
   else if (dim == 2)
-    hipLaunchKernelGGL((k_mpjpe<2>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
+    VP3D_LAUNCH((k_mpjpe<2>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
                        w, inv_n, grad, part, loss);
   else
-    hipLaunchKernelGGL((k_mpjpe<0>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
+    VP3D_LAUNCH((k_mpjpe<0>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
                        w, inv_n, grad, part, loss);
   int rc = check_launch("mpjpe");
   if (rc != VP3D_OK || blocks == 1) return rc;
-  hipLaunchKernelGGL(k_mpjpe_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, blocks, part, inv_n, loss);
+  VP3D_LAUNCH(k_mpjpe_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, blocks, part, inv_n, loss);
   return check_launch("mpjpe_finish");
 }
 
@@ -320,10 +320,10 @@ int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* g
   const int64_t n4 = (n + 3) / 4;
   const int blocks = grid_for(n4, 256, 256 * 8);
   if (h->amsgrad)
-    hipLaunchKernelGGL((k_adam<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg,
+    VP3D_LAUNCH((k_adam<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg,
                        exp_avg_sq, max_exp_avg_sq, k);
   else
-    hipLaunchKernelGGL((k_adam<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg,
+    VP3D_LAUNCH((k_adam<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg,
                        exp_avg_sq, max_exp_avg_sq, k);
   return check_launch("adam_step");
 }

@@ -739,7 +739,7 @@ int tail_grid(bool fwd, int* wgs) {
     int* d_ids = nullptr;
     if (hipMalloc((void**)&d_ids, wg * sizeof(int)) == hipSuccess) {
       std::vector<int> ids(wg, -1);
-      hipLaunchKernelGGL(k_xcc_probe, dim3(wg), dim3(T_NT), 0, 0, d_ids);
+      VP3D_LAUNCH(k_xcc_probe, dim3(wg), dim3(T_NT), 0, 0, d_ids);
       if (hipMemcpy(ids.data(), d_ids, wg * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
         grouped = 1;
         for (int b = 0; b < wg; ++b)
@@ -846,7 +846,7 @@ int launch_tail_fwd(hipStream_t s, const vp3d_tail_fwd* d) {
     set_error("tail_fwd: hipMemsetAsync failed");
     return VP3D_E_INVALID;
   }
-  hipLaunchKernelGGL(k_tail_fwd, dim3(wgs), dim3(T_NT), 0, s, a);
+  VP3D_LAUNCH(k_tail_fwd, dim3(wgs), dim3(T_NT), 0, s, a);
   return check_launch("tail_fwd");
 }
 
@@ -907,7 +907,7 @@ int launch_tail_bwd(hipStream_t s, const vp3d_tail_bwd* d) {
     set_error("tail_bwd: hipMemsetAsync failed");
     return VP3D_E_INVALID;
   }
-  hipLaunchKernelGGL(k_tail_bwd, dim3(wgs), dim3(T_NT), 0, s, a);
+  VP3D_LAUNCH(k_tail_bwd, dim3(wgs), dim3(T_NT), 0, s, a);
   return check_launch("tail_bwd");
 }
 

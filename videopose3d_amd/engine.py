@@ -425,9 +425,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
 
 
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
-    if saved.get("s16"):
+    range_guard.measure_head_gradient(mod, gout3)     # (armed by the forward of a measured step only; either engine: an
+    if saved.get("s16"):                             #  input / head-gradient trip is re-evaluated from the exact-fp32 engine too)
         from . import engine_s16
-        range_guard.measure_head_gradient(mod, gout3)
         return engine_s16.backward_train(mod, saved, gout3, need_dx)
     return _backward_train_f32(mod, saved, gout3, need_dx)
 

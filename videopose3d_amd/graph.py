@@ -42,7 +42,7 @@ DEBUG_DOT_PATH = None      # tools/graph_branches.py: write hipGraphDebugDotPrin
 
 
 class _Entry:
-    __slots__ = ("graph", "x", "t", "loss", "keep", "guard", "grads", "segments", "fork_event")
+    __slots__ = ("graph", "x", "t", "loss", "keep", "guard", "grads", "segments", "fork_event", "gout")
 
 
 def _momentum_guard(m):
@@ -168,6 +168,7 @@ class GraphedTrainStep:
         out3, saved = engine.forward_train(m, x.view(b, tt, -1), save=True)
         pred = out3.view(b, -1, m.num_joints_out, 3)
         lval, gout = vloss._mpjpe_call(pred, t, None, True)
+        self._last_gout3 = gout.view_as(out3)         # (the captured step's head gradient: measured behind a replay by the guard)
         self.sync._seen.clear()                       # every (captured) step overwrites the flat gradients: its own zero_grad
         reduce = self.sync._reduce
         self.sync._reduce = False                     # no collectives inside the step: sync.sync() exchanges afterwards
@@ -263,6 +264,7 @@ class GraphedTrainStep:
         if e.graph is not None:
             _dump_dot(e.graph)
         m._drop_calls, m._stats_epoch = counters[0], counters[1]   # capture executes nothing: host-side counters as before
+        e.gout, self._last_gout3 = self._last_gout3, None         # (no second reference into the capture's memory pool)
         return e
 
     def __call__(self, inputs_2d: torch.Tensor, inputs_3d: torch.Tensor) -> torch.Tensor:
@@ -288,6 +290,7 @@ class GraphedTrainStep:
             e.segments.replay(e.fork_event)
         else:
             e.graph.replay()
+        range_guard.measure_head_gradient(self.model, e.gout)    # (a no-op unless this replay's tick launched a measurement)
         if self.sync._reduce:
             self.sync.sync()
         return e.loss

@@ -21,15 +21,26 @@ sooner from a factor 2^14 on.  The guard keeps the model out of that regime:
   measured: 16 < 17);
 * action: above a limit the model's calls run on the exact-fp32 engine (``engine.use_s16`` -> False, one warning), until its
   parameters are re-loaded (``load_state_dict`` / ``.to()``) and measure inside the limits again;
-* no host synchronisation in the steady state: the statistic is launched every ``CHECK_EVERY`` calls behind the step's other
-  work, its integers are copied to pinned host memory and looked at by a LATER call: only at calls that are a multiple of
-  ``CONSUME_AFTER`` behind the launch, and only when the copy's event has completed (never waited for: a host that enqueues
-  ahead of the GPU would stall; round 5 measured 1.2 ms per call for a blocking wait two calls after the launch).  Ranks of a
-  data-parallel job hold identical parameters and count the same calls, so they measure the same values at the same step and
-  -- host timing permitting -- act on them at the same step; a rank that is late acts ``CONSUME_AFTER`` calls later (the
-  collectives are the same on either engine).  Parameters move by an optimizer step at a time; the limits sit 2^5..2^8
-  below the first measurable effect.  After ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call
-  measures synchronously (one read-back per load, not per step).
+* no host synchronisation in the steady state of a SINGLE process: the statistic is launched every ``CHECK_EVERY`` calls behind
+  the step's other work, its integers are copied to pinned host memory and looked at by a LATER call: only at calls that are a
+  multiple of ``CONSUME_AFTER`` behind the launch, and only when the copy's event has completed (never waited for: a host that
+  enqueues ahead of the GPU would stall; round 5 measured 1.2 ms per call for a blocking wait two calls after the launch).
+  After ``load_state_dict`` / ``.to()`` / construction -- the abrupt changes -- the first call measures synchronously (one read-back
+  per load, not per step);
+* **data parallelism (round 6)**: for the TRAINING calls of a model whose gradients are exchanged across ranks
+  (``dp.FlatGradSync(direct_module=model)``, world > 1) the decision is rank-consistent by construction instead of "host timing
+  permitting": the five integers are MAX-all-reduced over the gradient exchange's process group before they are copied to the
+  host (the parameter statistics are identical on every rank anyway; the input / head-gradient column spreads are rank-local
+  data), launches and consumption count TRAINING calls only (evaluation calls, which one rank may run alone, neither launch
+  nor consume nor take part in a collective), and a measurement launched at training call n is consumed at training call
+  n + ``CONSUME_AFTER`` exactly -- waiting for the copy if it has to, which at eight steps behind costs a host that runs ahead
+  nothing and a host that does not run ahead nothing either.  Every rank therefore switches engines (and re-captures a hipGraph)
+  on the same step; ``tests/test_dp_gloo.py`` runs two ranks of which one measures a hot input column;
+* parameter trips are sticky until the parameters are re-loaded; the input / head-gradient trips are SAMPLED checks (every
+  ``CHECK_EVERY``-th batch is measured, non-contiguous inputs are not) and are re-evaluated at every later measurement: one
+  outlier batch moves the model to the exact-fp32 engine until the next measured batch is inside the limit again, not for good.
+  Under ``graph.GraphedTrainStep`` the head gradient of a replay is measured behind the replay (the captured backward cannot
+  launch it); ``graph.GraphedStep`` (arbitrary step functions) has no handle on that tensor and leaves it unmeasured;
 * what it protects is "not worse than the exact-fp32 engine", not "accurate": where BOTH arithmetics lose precision (e.g. every
   layer's beta at 2^14: gmax ~ 0.1 on either engine, tools/range_edges.py) the model stays on split-fp16.
 
@@ -70,13 +81,15 @@ def enabled() -> bool:
 
 class _State:
     __slots__ = ("device", "out", "host", "event", "ws", "pending", "calls", "epoch", "tripped", "last", "checks", "sync_checks",
-                 "launched_at", "gram_off", "gram_last", "last_call", "tick_us", "cols_ws", "armed", "io_last")
+                 "launched_at", "gram_off", "gram_last", "last_call", "tick_us", "cols_ws", "armed", "io_last", "trip_param", "trip_io",
+                 "warned", "dp_calls", "dp_epoch", "exchanges")
 
     def __init__(self, device, ws_ints):
         self.device = device
+        cuda = torch.device(device).type == "cuda"   # (CPU: the decision logic alone, tests/test_dp_gloo.py)
         # [activation spread, weight-row spread, gram log2 kappa, input-column spread, head-gradient-column spread]
         self.out = torch.zeros(5, dtype=torch.int32, device=device)
-        self.host = torch.zeros(5, dtype=torch.int32).pin_memory()
+        self.host = torch.zeros(5, dtype=torch.int32).pin_memory() if cuda else torch.zeros(5, dtype=torch.int32)
         self.cols_ws = torch.zeros(1024, dtype=torch.int32, device=device)
         self.armed = False           # the backward of the measured step adds the head gradient's column spread (out[4])
         self.io_last = None          # (input, head gradient) column spreads of the last consumed measurement
@@ -85,15 +98,21 @@ class _State:
         self.gram_last = None        # max floor(log2 kappa) seen by the last consumed measurement
         self.last_call = None        # (training, batch, frames) of the last eager tick: what a graph replay ticks with
         self.tick_us = 0.0           # host time spent in tick(), accumulated (bench.py reports it per call)
-        self.event = torch.cuda.Event()
+        self.event = torch.cuda.Event() if cuda else None
         self.ws = torch.empty(max(1, ws_ints), dtype=torch.int32, device=device)
         self.pending = False
         self.calls = 0
         self.epoch = -1          # the model's _range_epoch at the last completed measurement
-        self.tripped = False
+        self.tripped = False     # trip_param or trip_io
+        self.trip_param = False  # BatchNorm-bound / weight-row spread outside the limits: sticky until the parameters are re-loaded
+        self.trip_io = False     # input / head-gradient column spread outside the limit at the LAST consumed measurement
+        self.warned = False      # one warning per parameter epoch
         self.last = None         # (activation spread, weight-row spread) of the last completed measurement
         self.checks = 0
         self.sync_checks = 0
+        self.dp_calls = 0        # TRAINING calls under data parallelism (what the rank-consistent cadence counts)
+        self.dp_epoch = -1       # the parameter epoch of the last measurement that was exchanged across ranks
+        self.exchanges = 0       # measurements that were MAX-reduced over the gradient exchange's process group
 
 
 def invalidate(mod) -> None:
@@ -124,7 +143,8 @@ def status(mod) -> dict:
         return dict(tripped=False, last=None, checks=0, sync_checks=0, gram_off=False, gram_log2_kappa=None)
     return dict(tripped=st.tripped, last=st.last, checks=st.checks, sync_checks=st.sync_checks,
                 limits=(ACT_SPREAD_MAX, W_SPREAD_MAX), io_last=st.io_last, gram_off=st.gram_off, gram_log2_kappa=st.gram_last,
-                tick_us_per_call=st.tick_us / max(1, st.calls))    # steady state: the synchronous measurements are not in it
+                trip_param=st.trip_param, trip_io=st.trip_io, exchanges=st.exchanges,
+                tick_us_per_call=st.tick_us / max(1, st.calls + st.dp_calls))   # steady state: the synchronous measurements are not in it
 
 
 def _ptrs(ts):
@@ -149,8 +169,10 @@ def measure_head_gradient(mod, gout3: torch.Tensor) -> None:
                                      st.cols_ws.data_ptr(), st.out[4:].data_ptr()), "vp3d_range_cols")
 
 
-def _launch(mod, st: _State, m_rows, x3=None) -> None:
-    """Enqueue one measurement on the current stream: zero, statistics, copy to pinned memory, event."""
+def _measure(mod, st: _State, m_rows, x3=None) -> None:
+    """Enqueue the statistics kernels of one measurement on the current stream (st.out[0, 1, 3]; out[2] and out[4] have been
+    accumulating since the last measurement).  The only part of the guard that touches the device kernels: tests of the
+    decision logic replace it."""
     from . import engine, ops
     bns, convs = engine._bns(mod), engine._convs(mod)
     st.out[:2].zero_()                               # (out[2], out[4] accumulate over the steps since the last measurement)
@@ -177,26 +199,52 @@ def _launch(mod, st: _State, m_rows, x3=None) -> None:
                                           _ptrs(ws_), (C.c_int64 * max(1, len(rows)))(*rows),
                                           (C.c_int64 * max(1, len(rlen)))(*rlen), st.ws.data_ptr(), st.ws.numel(),
                                           st.out.data_ptr()), "vp3d_range_stats")
+
+
+def dp_sink(mod):
+    """The model's gradient exchange (dp.FlatGradSync(direct_module=model)) when it spans more than one rank, else None."""
+    sink = mod.__dict__.get("_vp3d_grad_sink")
+    if sink is None or getattr(sink, "world", 1) <= 1:
+        return None
+    import torch.distributed as dist
+    return sink if dist.is_initialized() else None
+
+
+def _launch(mod, st: _State, m_rows, x3=None, sink=None) -> None:
+    """Enqueue one measurement on the current stream: zero, statistics, (data parallel: MAX over the ranks,) copy to pinned
+    memory, event."""
+    _measure(mod, st, m_rows, x3)
+    if sink is not None:
+        import torch.distributed as dist
+        # every rank acts on the job-wide maximum: the parameter statistics are identical anyway, the input / head-gradient
+        # column spreads (and the conditioning flag, which depends on the batch) are rank-local data
+        dist.all_reduce(st.out, op=dist.ReduceOp.MAX, group=sink.group)
+        st.exchanges += 1
     st.host.copy_(st.out, non_blocking=True)
     st.out[2:3].zero_()
     st.out[4:].zero_()
-    st.event.record()
+    if st.event is not None:
+        st.event.record()
     st.pending = True
-    st.launched_at = st.calls
+    st.launched_at = st.dp_calls if sink is not None else st.calls
     st.checks += 1
 
 
 def _consume(mod, st: _State, epoch: int) -> None:
     a, w, xi, go = int(st.host[0]), int(st.host[1]), int(st.host[3]), int(st.host[4])
     st.last, st.io_last, st.pending, st.epoch = (a, w), (xi, go), False, epoch
-    now = a > ACT_SPREAD_MAX or w > W_SPREAD_MAX or xi > IO_SPREAD_MAX or go > IO_SPREAD_MAX
-    if now and not st.tripped:
+    st.trip_param = st.trip_param or a > ACT_SPREAD_MAX or w > W_SPREAD_MAX      # sticky within a parameter epoch
+    st.trip_io = xi > IO_SPREAD_MAX or go > IO_SPREAD_MAX                        # a sampled check of THIS batch: re-evaluated
+    now = st.trip_param or st.trip_io
+    if now and not st.warned:
+        st.warned = True
         warnings.warn("videopose3d_amd: intra-tensor dynamic range outside the split-fp16 format's lossless window "
                       "(per-channel BatchNorm bound spread 2^%d, limit 2^%d; weight-row spread 2^%d, limit 2^%d; input / head-gradient "
                       "column spread 2^%d / 2^%d, limit 2^%d): this model now runs on the exact-fp32 engine (math='f32' kernels) "
-                      "until its parameters are re-loaded"
+                      "until its parameters are re-loaded (parameter statistics) or a later measured batch is inside the limit again "
+                      "(input / head-gradient columns)"
                       % (a, ACT_SPREAD_MAX, w, W_SPREAD_MAX, xi, go, IO_SPREAD_MAX), RuntimeWarning, stacklevel=3)
-    st.tripped = st.tripped or now                   # sticky within a parameter epoch (tick clears it on a re-load)
+    st.tripped = now
     k = int(st.host[2])
     st.gram_last = k
     if k >= GRAM_KAPPA_LOG2_MAX and not st.gram_off:
@@ -225,7 +273,7 @@ def tick_replay(mod) -> None:
 
 
 def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
-    if torch.cuda.is_current_stream_capturing():
+    if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
         return                                       # (a captured step is guarded by its replay wrapper: graph.py)
     t0 = time.perf_counter()
     from . import engine, engine_s16
@@ -242,21 +290,42 @@ def _tick(mod, training: bool, b: int, t_in: int, device, x3=None) -> None:
         plan = mod._plan
         t_len = plan.lengths(t_in)
         m_rows = [b * t_len[0]] + [b * t_len[(idx + 1) // 2] for idx in range(1, len(plan.convs))]
-    if st.epoch != epoch:
+    dp = dp_sink(mod)
+    sink = dp if training else None                  # (evaluation calls never take part in a collective: one rank may run them alone)
+    if st.epoch != epoch or (sink is not None and st.dp_epoch != epoch):
         # abrupt change (construction, load_state_dict, .to()): measure NOW, before an engine is chosen for these parameters
-        st.tripped = st.gram_off = False
+        # (data parallel: the first TRAINING call after the change exchanges it -- every rank makes that call at the same step)
+        st.tripped = st.trip_param = st.trip_io = st.gram_off = st.warned = False
         st.out[2:].zero_()
-        _launch(mod, st, m_rows, x3)
-        st.event.synchronize()
+        _launch(mod, st, m_rows, x3, sink)
+        if st.event is not None:
+            st.event.synchronize()
         st.sync_checks += 1
         _consume(mod, st, epoch)
-        st.calls = 0                                 # the first periodic measurement follows the first forward (its kappa)
+        if sink is not None:
+            st.dp_epoch = epoch
+        st.calls = st.dp_calls = 0                   # the first periodic measurement follows the first forward (its kappa)
+        st.launched_at = 0
         return                                       # (not in tick_us: a one-off that waits for the device and loads the kernels)
+    if dp is not None and sink is None:
+        return                                       # an evaluation call of a data-parallel model: the training calls' decisions stand
+    if sink is not None:
+        # rank-consistent cadence: training calls only, consumption at a FIXED distance behind the launch (waiting for the copy
+        # if need be: eight steps behind, a host that runs ahead of the GPU has nothing to wait for)
+        st.dp_calls += 1
+        if st.pending and st.dp_calls - st.launched_at == CONSUME_AFTER:
+            if st.event is not None:
+                st.event.synchronize()
+            _consume(mod, st, epoch)
+        if not st.trip_param and not st.pending and st.dp_calls % CHECK_EVERY == 1:
+            _launch(mod, st, m_rows, x3, sink)
+        st.tick_us += (time.perf_counter() - t0) * 1e6
+        return
     st.calls += 1
     behind = st.calls - st.launched_at
     every = max(1, min(CONSUME_AFTER, CHECK_EVERY // 2))
-    if st.pending and behind > 0 and behind % every == 0 and st.event.query():
+    if st.pending and behind > 0 and behind % every == 0 and (st.event is None or st.event.query()):
         _consume(mod, st, epoch)
-    if not st.tripped and not st.pending and st.calls % CHECK_EVERY == 1:
+    if not st.trip_param and not st.pending and st.calls % CHECK_EVERY == 1:
         _launch(mod, st, m_rows, x3)
     st.tick_us += (time.perf_counter() - t0) * 1e6
