@@ -372,13 +372,21 @@ def _backward_train_f32(mod, saved, gout3: torch.Tensor, need_dx: bool):
     return grads + [d_sw, d_sb], dx
 
 
-# Below this much forward conv work per call the step is bound by launch latency, not by the matrix pipes, and the
-# split-fp16 engine's extra producers / bound kernels cost more than its GEMMs save (measured on MI355X,
-# tools/small_modes.py: arc 3,3,3,3,3 training crosses over between B = 64 [23 GFLOP: 1.83 vs 2.15 ms] and B = 128
-# [45 GFLOP: 2.50 vs 2.15 ms], B = 2 evaluation between 485 and 742 input frames [27 / 44 GFLOP]; arc 3,3,3 stays on
-# the fp32 kernels up to B = 1024 [36 GFLOP: 1.58 vs 1.91 ms]).  VP3D_S16_MIN_GFLOP overrides both (0 = always).
+# Below this much forward conv work per call the step is bound by launch latency / the host, not by the matrix pipes, and the
+# split-fp16 engine's extra producers / bound kernels cost more than its GEMMs save.  Re-derived in round 6 on MI355X
+# (tools/s16_threshold.py, profiles/r06_s16_threshold.txt: both engines forced, run.py's own loop shape) -- the round-1 values
+# (40 / 35 GFLOP) dated from a slower split-fp16 engine and sent run.py's own default configuration (-arc 3,3,3 -b 1024,
+# reference common/arguments.py:37,45: 36.4 GFLOP) to the fp32 kernels:
+#   training, f16x3 / f32 step time:  arc 3,3,3      B = 512 / 768 / 1024  (18 / 27 / 36 GFLOP)   1.08 / 0.96 / 0.99
+#                                     arc 3,3,3,3    B = 128 / 192 / 256   (15 / 22 / 29 GFLOP)   1.14 / 0.99 / 0.79
+#                                     arc 3,3,3,3,3  B =  64 / 128 / 192   (23 / 45 / 68 GFLOP)   1.19 / 0.98 / 0.65
+#   (below ~20 GFLOP both engines sit on their host floors, 1.0 ms for ~60 launches against 1.45 ms for ~80; the three opt-in
+#    edits of INTEGRATION.md 3b or a hipGraph replay move run.py's default to 1.08 / 0.89 ms against 1.43 on the fp32 kernels)
+#   evaluation (B = 2, one sequence + mirrored copy): arc 3,3,3,3,3  T_out = 243 / 400 (27 / 38 GFLOP)  1.16 / 0.67,
+#                                                      arc 3,3,3      T_out = 243 / 1000 (9 / 35 GFLOP)  1.05 / 0.76
+# -> 25 GFLOP (training) / 30 GFLOP (evaluation).  VP3D_S16_MIN_GFLOP overrides both (0 = always).
 _min_gf = os.environ.get("VP3D_S16_MIN_GFLOP")
-S16_MIN_FORWARD_FLOPS = {True: float(_min_gf or 40.0) * 1e9, False: float(_min_gf or 35.0) * 1e9}   # [training]
+S16_MIN_FORWARD_FLOPS = {True: float(_min_gf or 25.0) * 1e9, False: float(_min_gf or 30.0) * 1e9}   # [training]
 
 
 def use_s16(mod, t_in: int, training: bool, need_dx: bool = False, batch: Optional[int] = None) -> bool:
