@@ -335,110 +335,6 @@ int vp3d_prologue_b_s16(vp3d_stream_t stream, const vp3d_rowmap* map, const floa
                         const float* const* w, const int32_t* taps, int32_t c_out, int32_t c_in, const float* w_bounds,
                         void* const* wf, void* const* wd);
 
-/* ---- the small-M tail of the strided training stack as one persistent launch per direction (vp3d_tail_s16.hip) ----------
- * Replaces, for the trailing blocks of TemporalModelOptimized1f whose convs produce few rows (B * T_out of a few thousand
- * at most), the reference's
- *     res = x[:, :, shift + fw//2 :: fw];  x = drop(relu(bn(conv(x))));  x = res + drop(relu(bn(conv_1x1(x))))
- * (common/model.py:190-194) and its autograd backward: conv (S16 MFMA tiles x K-slices), BatchNorm batch statistics +
- * running update, normalisation + ReLU + dropout (+ residual) of ALL those layers are ONE kernel whose co-resident
- * workgroups hand over through grid barriers -- "each conv is a fused conv + BN + ReLU + dropout kernel" in the literal sense.
- * Layers come in blocks: layers[2j] = the strided conv (taps 3, stride 3 -- or 1 --, windows tile the input, res_start -1),
- * layers[2j+1] = the 1x1 conv with the block's residual (res_start = the residual tap: rows taps*m + res_start of the
- * block input).  All convs are C x C, C % 64 == 0; layers[l-1].M == layers[l].M * layers[l].taps.  Every tensor is
- * caller-owned; S16 tensors carry 32-slot bounds (vp3d_s16).  `sync` = vp3d_tail_sync_bytes() of scratch (zeroed by the call). */
-typedef struct vp3d_tail_fwd_layer {
-  int64_t M;                    /* output rows of this conv */
-  int32_t taps;                 /* 1 or 3 (stride == taps) */
-  int32_t res_start;            /* odd layers: residual tap; even layers: -1 */
-  const void* wf;               /* S16 forward pack [C][taps*C] (vp3d_pack_weight_s16) */
-  const float* w_bound;
-  const float* gamma;           /* BatchNorm affine, running statistics (any of the three may be NULL) */
-  const float* beta;
-  float* running_mean;
-  float* running_var;
-  int64_t* num_batches_tracked;
-  float* y;                     /* out: fp32 conv output [M][C] (what backward needs) */
-  float* coef;                  /* out: [4][C] scale, shift, batch mean, 1/sqrt(var + eps) */
-  void* a;                      /* out: S16 activation rows [M][C] under the exponent of *a_bound */
-  const float* a_bound;         /* in: guaranteed bound of the activation (vp3d_act_bounds_multi) */
-  float* a_f32;                 /* out (may be NULL): the activation as plain fp32 */
-  void* a_t;                    /* out (may be NULL): transposed S16 copy [(tap*C + c)][ld_at] for the next conv's wgrad */
-  int64_t ld_at;
-  int32_t taps_at;
-  uint8_t* act_bits;            /* out (may be NULL): activation bits (vp3d_bn_act_fwd_s16's layout) */
-  const vp3d_dropout* drop;     /* may be NULL */
-  int32_t splits;               /* K-slices of the conv GEMM; 0 = planned */
-} vp3d_tail_fwd_layer;
-
-typedef struct vp3d_tail_fwd {
-  int32_t n_layers;             /* 2, 4, 6 or 8 */
-  int32_t C;
-  const vp3d_tail_fwd_layer* layers;
-  const void* x0;               /* S16 rows [layers[0].M * layers[0].taps][C]: the first block's input */
-  const float* x0_bound;
-  float* part;                  /* workspace, part_floats >= vp3d_tail_workspace's fwd_floats */
-  int64_t part_floats;
-  float eps, momentum;
-  const float* momentum_dev;    /* may be NULL: device float read instead of `momentum` (hipGraph replays) */
-  void* sync;
-  void* trace;                  /* may be NULL: 128 uint64 -- [0] = number of stamps, [1..] = 100 MHz wall clock of workgroup 0
-                                   at kernel start, after every grid barrier and at its end (phase timing, tools/tail_trace.py) */
-} vp3d_tail_fwd;
-
-typedef struct vp3d_tail_bwd_layer {
-  int64_t M;
-  int32_t taps;
-  int32_t res_start;
-  const void* wd;               /* S16 dgrad pack [taps*C][C] */
-  const float* w_bound;
-  const float* y;               /* the forward's conv output, coefficients and activation bits */
-  const float* coef;
-  const uint8_t* act_bits;
-  const void* x_t;              /* transposed S16 input of this conv [(taps*C)][ld_xt], ld_xt = roundup(M, 64) */
-  int64_t ld_xt;
-  const float* x_bound;
-  float* go;                    /* fp32 [M][C]: LAST layer: in (gradient wrt the tail's output); others: out (assembled) */
-  float* go_bound;              /* 32 slots: LAST layer: in (max|go|, vp3d_amax); others: zeroed, measured by the call */
-  void* dy;                     /* out: S16 rows [M][C] and transposed [C][ld_dyt] (ld_dyt = roundup(M, 64)) */
-  void* dy_t;
-  int64_t ld_dyt;
-  float* dy_bound;              /* 32 slots, zeroed */
-  float* dgamma;                /* out */
-  float* dbeta;
-  float* dw;                    /* out: [C][C][taps] (reference layout) */
-  int32_t splits_d, splits_w;   /* 0 = planned */
-} vp3d_tail_bwd_layer;
-
-typedef struct vp3d_tail_bwd {
-  int32_t n_layers;
-  int32_t C;
-  const vp3d_tail_bwd_layer* layers;
-  float p;                      /* dropout probability of the forward (the bits hold the decisions) */
-  float* dpart;                 /* workspaces (vp3d_tail_workspace) */
-  int64_t dpart_floats;
-  float* wpart;
-  int64_t wpart_floats;
-  float* dx0;                   /* out: fp32 [layers[0].M * layers[0].taps][C], gradient wrt the first block's input rows */
-  float* dx0_bound;             /* 32 slots, zeroed: max|dx0| */
-  void* sync;
-  void* trace;                  /* may be NULL: as in vp3d_tail_fwd */
-} vp3d_tail_bwd;
-
-int vp3d_tail_fwd_s16(vp3d_stream_t stream, const vp3d_tail_fwd* desc);
-int vp3d_tail_bwd_s16(vp3d_stream_t stream, const vp3d_tail_bwd* desc);
-/* workspace floats for a tail of n_layers layers (M[l], taps[l]) as the two calls plan their K-slices; needs a GPU */
-int vp3d_tail_workspace(int32_t C, int32_t n_layers, const int64_t* M, const int32_t* taps, int64_t* fwd_floats,
-                        int64_t* dpart_floats, int64_t* wpart_floats);
-/* most layers a tail may hold (8 = 4 blocks) */
-int vp3d_tail_max_layers(void);
-/* bytes of the `sync` scratch of the two calls (zeroed by them; word 0 = error flag: non-zero after a call whose grid barrier
- * timed out -- its results are then invalid) */
-int vp3d_tail_sync_bytes(void);
-/* 1 when the tail's grid barrier does its cache write-back / invalidate once per XCD (a probe launch found workgroup b on
- * XCD b % 8 on the current device), 0 when every workgroup fences (fallback; VP3D_TAIL_FLAT_BARRIER=1 forces it); valid
- * after the first tail call or vp3d_tail_workspace on the device */
-int vp3d_tail_barrier_grouped(void);
-
 /* Workspace of a vp3d_tconv_nt_s16 launch in configuration (cfg, splits): floats (0: none) and int32 tickets (0: none). */
 /* 1 when the library was built with -DVP3D_BUILD_EXPERIMENTS (the measured-and-not-adopted S16 GEMM instances: stream-K
  * 120 / 122, register-pipelined 10 / 13 / 21 / 23, 256x128 / 128x256 pairs 24 / 25, four-wave 256x256 26, hybrid pair 30);

@@ -698,22 +698,6 @@ def test_engines_agree_on_random_configurations():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_engines_agree_on_random_configurations_through_the_persistent_tail():
-    """The same sweep (other seed, 40 cases) with VP3D_TAIL=1: every strided configuration whose blocks qualify runs them in
-    the persistent tail kernels (csrc/vp3d_tail_s16.hip), still against the exact-fp32 engine's per-layer launches."""
-    import os
-    import subprocess
-    import sys
-    from videopose3d_amd import _lib
-    if not _lib.lib().vp3d_has_experiments():
-        pytest.skip("library built without VP3D_BUILD_EXPERIMENTS: no persistent tail")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "40", "11"], capture_output=True, text=True,
-                       cwd=root, timeout=600, env=dict(os.environ, VP3D_TAIL="1"))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "tail launches: 0 " not in r.stdout, "the sweep never reached the persistent tail"
-
-
 @pytest.mark.parametrize("joints,c,arc", [(17, 128, [3, 3, 3]), (15, 64, [3, 3, 3, 3]), (17, 256, [3, 1, 3])])
 def test_fused_prologue_is_bit_identical(joints, c, arc, monkeypatch):
     """The two-launch prologue (vp3d_prologue_a_s16: every maximum + the activation bounds; vp3d_prologue_b_s16: input staging +

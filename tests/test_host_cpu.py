@@ -430,9 +430,9 @@ def test_s16_engine_rejects_gather_form_training_beyond_the_kernel_row_limit():
     assert engine_s16.supported(s, 27, True, batch=65535 * 64)
 
 
-def test_tail_structs_have_the_layout_of_the_header(tmp_path):
-    """The ctypes mirrors of vp3d_tail_fwd / vp3d_tail_bwd (+ their per-layer structs) against include/vp3d.h compiled by the C
-    compiler: size and the offset of EVERY field (a silently shifted pointer would be read as garbage by the kernels)."""
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors of the ABI's argument structs against include/vp3d.h compiled by the C compiler: size and the offset
+    of EVERY field (a silently shifted pointer would be read as garbage by the kernels)."""
     import shutil
     import subprocess
     import ctypes as C
@@ -440,9 +440,7 @@ def test_tail_structs_have_the_layout_of_the_header(tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pairs = [("vp3d_tail_fwd_layer", _lib.TailFwdLayer), ("vp3d_tail_fwd", _lib.TailFwd), ("vp3d_tail_bwd_layer", _lib.TailBwdLayer),
-             ("vp3d_tail_bwd", _lib.TailBwd), ("vp3d_dropout", _lib.Dropout), ("vp3d_rowmap", _lib.RowMap),
-             ("vp3d_s16", _lib.S16Opts), ("vp3d_s16_red", _lib.S16Red)]
+    pairs = [("vp3d_dropout", _lib.Dropout), ("vp3d_rowmap", _lib.RowMap), ("vp3d_s16", _lib.S16Opts), ("vp3d_s16_red", _lib.S16Red)]
     lines = ['#include "vp3d.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in pairs:
         lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
@@ -471,34 +469,6 @@ def test_fused_bn_backward_sums_selection_rules():
     assert not S.red_supported(27648, 1024, 1024, 128)         # strips are 256 channels wide
     assert not S.red_supported(27648, 1000, 1024, 1000)
     assert engine_s16.FUSE_BN_RED_DEFAULT == "auto" and engine_s16.FUSE_BN_RED_MIN_ROWS == 16384
-
-
-def test_persistent_tail_selection_rules(monkeypatch):
-    """engine_s16.tail_from (which trailing blocks run in the persistent tail kernels when VP3D_TAIL=1): whole blocks of the
-    strided class whose windows tile, B * T_out <= 3072 rows, C % 64 == 0, one BatchNorm momentum, no synchronised BatchNorm;
-    off by default."""
-    from videopose3d_amd import engine_s16, ops_s16
-    m = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3, 3, 3], channels=1024)
-    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0                    # opt-in
-    monkeypatch.setenv("VP3D_TAIL", "1")
-    if not _lib.lib().vp3d_has_experiments():
-        # the default library is built without the persistent tail (an experiment since round 4): nothing is ever selected
-        assert ops_s16.tail_max_layers() == 0
-        assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0
-        monkeypatch.setattr(ops_s16, "tail_max_layers", lambda: 8)     # the selection rules of an experiments build
-    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 5                    # blocks 3 and 4: 3072 and 1024 rows
-    assert engine_s16.tail_from(m, m._plan, 243, 200, None, True) == 3                     # 200 * 27 rows are too many, 200 * 9 fit
-    assert engine_s16.tail_from(m, m._plan, 243, 64, None, True) == 1                      # 64 * 27 = 1728 rows: all four blocks = the 8 layers a tail may hold
-    assert engine_s16.tail_from(m, m._plan, 243, 8192, None, True) == 0                    # 8192 rows in the last block already
-    assert engine_s16.tail_from(m, m._plan, 243, 1024, object(), True) == 0                # synchronised BatchNorm
-    m.layers_bn[7].momentum = 0.5
-    assert engine_s16.tail_from(m, m._plan, 243, 1024, None, True) == 0                    # per-layer momenta
-    c = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], causal=True, channels=128)
-    assert engine_s16.tail_from(c, c._plan, 27, 16, None, True) == 1                       # every block, causal residual tap
-    d = V.TemporalModel(17, 2, 17, [3, 3, 3], channels=128)
-    assert engine_s16.tail_from(d, d._plan, 27, 16, None, True) == 0                       # dilated class: windows do not tile
-    n = V.TemporalModelOptimized1f(17, 2, 17, [3, 3, 3], channels=96)
-    assert engine_s16.tail_from(n, n._plan, 27, 16, None, True) == 0                       # C % 64 != 0
 
 
 def test_build_is_gated_by_a_content_hash_not_by_mtimes(tmp_path, monkeypatch):

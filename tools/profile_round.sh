@@ -14,11 +14,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-eval --no-f32 --math $MATH"
+BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-eval --no-f32 --no-sweep --math $MATH"
 VP3D_BENCH_GRAPH=0 rocprofv3 --kernel-trace --stats -d "$OUT" -o kt -- $BENCH > "$OUT/kt.log" 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH"; python "$R/tools/prof_summary.py" "$OUT/kt_results.db" 40; } \
     > "$OUT/${TAG}_bench_train_kernel_trace_stats.txt" 2>&1
-FULL="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-f32 --math $MATH"
+FULL="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rocm-ref --no-f32 --no-sweep --math $MATH"
 VP3D_BENCH_GRAPH=0 rocprofv3 --kernel-trace --stats -d "$OUT" -o ktfull -- $FULL > "$OUT/ktfull.log" 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- $FULL"; python "$R/tools/prof_summary.py" "$OUT/ktfull_results.db" 40; } \
     > "$OUT/${TAG}_bench_full_kernel_trace_stats.txt" 2>&1

@@ -24,7 +24,7 @@ N_STEPS, N_KEEP = 6, 3
 
 def run(log_path, math):
     os.environ["VP3D_OVERLAP"] = "0"
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as bench.py: the package no longer sets it at import (round 6)
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as bench.py: the package no longer sets it at import (round 6)
     import torch
     import videopose3d_amd as V
     from videopose3d_amd import dp, ops, loss as vloss

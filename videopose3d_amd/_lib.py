@@ -76,34 +76,6 @@ class Adam(C.Structure):
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("amsgrad", C.c_int32)]
 
 
-class TailFwdLayer(C.Structure):               # include/vp3d.h: vp3d_tail_fwd_layer
-    _fields_ = [("M", C.c_int64), ("taps", C.c_int32), ("res_start", C.c_int32), ("wf", C.c_void_p), ("w_bound", C.c_void_p),
-                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("num_batches_tracked", C.c_void_p), ("y", C.c_void_p), ("coef", C.c_void_p), ("a", C.c_void_p),
-                ("a_bound", C.c_void_p), ("a_f32", C.c_void_p), ("a_t", C.c_void_p), ("ld_at", C.c_int64),
-                ("taps_at", C.c_int32), ("act_bits", C.c_void_p), ("drop", C.POINTER(Dropout)), ("splits", C.c_int32)]
-
-
-class TailFwd(C.Structure):                    # vp3d_tail_fwd
-    _fields_ = [("n_layers", C.c_int32), ("C", C.c_int32), ("layers", C.POINTER(TailFwdLayer)), ("x0", C.c_void_p),
-                ("x0_bound", C.c_void_p), ("part", C.c_void_p), ("part_floats", C.c_int64), ("eps", C.c_float),
-                ("momentum", C.c_float), ("momentum_dev", C.c_void_p), ("sync", C.c_void_p), ("trace", C.c_void_p)]
-
-
-class TailBwdLayer(C.Structure):               # vp3d_tail_bwd_layer
-    _fields_ = [("M", C.c_int64), ("taps", C.c_int32), ("res_start", C.c_int32), ("wd", C.c_void_p), ("w_bound", C.c_void_p),
-                ("y", C.c_void_p), ("coef", C.c_void_p), ("act_bits", C.c_void_p), ("x_t", C.c_void_p), ("ld_xt", C.c_int64),
-                ("x_bound", C.c_void_p), ("go", C.c_void_p), ("go_bound", C.c_void_p), ("dy", C.c_void_p), ("dy_t", C.c_void_p),
-                ("ld_dyt", C.c_int64), ("dy_bound", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("dw", C.c_void_p), ("splits_d", C.c_int32), ("splits_w", C.c_int32)]
-
-
-class TailBwd(C.Structure):                    # vp3d_tail_bwd
-    _fields_ = [("n_layers", C.c_int32), ("C", C.c_int32), ("layers", C.POINTER(TailBwdLayer)), ("p", C.c_float),
-                ("dpart", C.c_void_p), ("dpart_floats", C.c_int64), ("wpart", C.c_void_p), ("wpart_floats", C.c_int64),
-                ("dx0", C.c_void_p), ("dx0_bound", C.c_void_p), ("sync", C.c_void_p), ("trace", C.c_void_p)]
-
-
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P = C.POINTER
 
@@ -129,12 +101,6 @@ SIGNATURES = {
                                       _P(_i32), _f32, _vp]),
     "vp3d_prologue_b_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp,
                                       _vp, _vp, _i32, _P(_vp), _P(_i32), _i32, _i32, _vp, _P(_vp), _P(_vp)]),
-    "vp3d_tail_fwd_s16": (C.c_int, [_vp, _P(TailFwd)]),
-    "vp3d_tail_bwd_s16": (C.c_int, [_vp, _P(TailBwd)]),
-    "vp3d_tail_workspace": (C.c_int, [_i32, _i32, _P(_i64), _P(_i32), _P(_i64), _P(_i64), _P(_i64)]),
-    "vp3d_tail_max_layers": (C.c_int, []),
-    "vp3d_tail_sync_bytes": (C.c_int, []),
-    "vp3d_tail_barrier_grouped": (C.c_int, []),
     "vp3d_has_experiments": (C.c_int, []),
     "vp3d_nt_s16_workspace": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _i32, _P(_i64), _P(_i32)]),
     "vp3d_tconv_nt_s16": (C.c_int, [_vp, _P(RowMap), _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _P(Epilogue), _vp,

@@ -5,7 +5,7 @@ configurations: narrower models, synchronised BatchNorm, dilated convs, ...).  T
 path bit-for-bit (or to summation order) against its alternative on the same model; the A/B tools under tools/ flip them to time
 both.  They used to be VP3D_* environment variables read at call time (rounds 2-4); the settled ones moved here in round 5 so that
 the environment surface of the package is what a user may actually want to set (README: VP3D_MATH, VP3D_RANGE_GUARD,
-VP3D_OVERLAP, VP3D_S16_MIN_GFLOP, VP3D_FUSE_BN_RED, VP3D_GRAPH_PIECEWISE, VP3D_RCCL_CHANNELS, VP3D_TAIL).
+VP3D_OVERLAP, VP3D_S16_MIN_GFLOP, VP3D_FUSE_BN_RED, VP3D_GRAPH_PIECEWISE, VP3D_RCCL_CHANNELS, VP3D_DEV_KERNARG).
 
     from videopose3d_amd._switches import SW;  monkeypatch.setitem(SW, "wgrad_rows", False)
 """

@@ -377,39 +377,6 @@ int vp3d_expand_bwd_p_s16(vp3d_stream_t stream, int64_t M, int32_t C, int32_t kp
                                  *nparts, partials, gram_partials);
 }
 
-// The persistent small-M tail (vp3d_tail_s16.hip) was measured SLOWER than the per-layer launches it replaces at every
-// benchmark shape (+0.3 ms per cfg3 step; in the launch-bound regime it only ties with the fp32 engine that
-// engine.use_s16 picks there anyway): since round 4 it is an experiment -- compiled only with -DVP3D_BUILD_EXPERIMENTS
-// (VP3D_BUILD_EXPERIMENTS=1 python __graft_entry__.py); the default library exports the entry points as refusals.
-#ifdef VP3D_BUILD_EXPERIMENTS
-int vp3d_tail_fwd_s16(vp3d_stream_t stream, const vp3d_tail_fwd* desc) { return launch_tail_fwd((hipStream_t)stream, desc); }
-int vp3d_tail_bwd_s16(vp3d_stream_t stream, const vp3d_tail_bwd* desc) { return launch_tail_bwd((hipStream_t)stream, desc); }
-int vp3d_tail_workspace(int32_t C, int32_t n_layers, const int64_t* M, const int32_t* taps, int64_t* fwd_floats,
-                        int64_t* dpart_floats, int64_t* wpart_floats) {
-  VP3D_REQUIRE(C > 0 && n_layers > 0 && n_layers <= tail_max_layers() && M && taps && fwd_floats && dpart_floats && wpart_floats,
-               "tail_workspace: bad argument");
-  return tail_workspace(C, n_layers, M, taps, fwd_floats, dpart_floats, wpart_floats);
-}
-int vp3d_tail_max_layers(void) { return tail_max_layers(); }
-int vp3d_tail_sync_bytes(void) { return tail_sync_bytes(); }
-int vp3d_tail_barrier_grouped(void) { return tail_barrier_grouped(); }
-#else
-int vp3d_tail_fwd_s16(vp3d_stream_t, const vp3d_tail_fwd*) {
-  VP3D_REQUIRE(false, "tail_fwd_s16: the persistent tail is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)");
-  return VP3D_OK;
-}
-int vp3d_tail_bwd_s16(vp3d_stream_t, const vp3d_tail_bwd*) {
-  VP3D_REQUIRE(false, "tail_bwd_s16: the persistent tail is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)");
-  return VP3D_OK;
-}
-int vp3d_tail_workspace(int32_t, int32_t, const int64_t*, const int32_t*, int64_t*, int64_t*, int64_t*) {
-  VP3D_REQUIRE(false, "tail_workspace: the persistent tail is an experiment this library was built without (-DVP3D_BUILD_EXPERIMENTS)");
-  return VP3D_OK;
-}
-int vp3d_tail_max_layers(void) { return 0; }          /* no layer may go into a tail: engine_s16.tail_from() -> 0 */
-int vp3d_tail_sync_bytes(void) { return 4; }
-int vp3d_tail_barrier_grouped(void) { return 0; }
-#endif
 
 
 int vp3d_has_experiments(void) { return nt_s16_has_experiments(); }

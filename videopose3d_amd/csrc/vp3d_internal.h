@@ -164,14 +164,6 @@ int launch_nt_s16(hipStream_t s, const RowsGemmArgs& a, int cfg, int splits, flo
                   bool raw_partials, int32_t* tickets = nullptr);
 void nt_s16_workspace(int M, int N, int K, int cfg, int splits, int raw, int64_t* ws_floats, int32_t* tickets);
 int nt_s16_has_experiments();
-// persistent small-M tail (vp3d_tail_s16.hip)
-int launch_tail_fwd(hipStream_t s, const vp3d_tail_fwd* d);
-int launch_tail_bwd(hipStream_t s, const vp3d_tail_bwd* d);
-int tail_workspace(int32_t C, int32_t n_layers, const int64_t* M, const int32_t* taps, int64_t* fwd_floats, int64_t* dpart_floats,
-                   int64_t* wpart_floats);
-int tail_max_layers();
-int tail_sync_bytes();
-int tail_barrier_grouped();
 // expand layer, forward (vp3d_expand_s16.hip): statistics pass (stat_sum != nullptr) or activation pass (out != nullptr)
 int launch_expand_fwd_s16(hipStream_t s, int64_t M, int32_t N, int32_t kpad, const float* x, const float* x_bound,
                           const float* w, const float* w_bound, float* stat_sum, float* stat_m2, const float* scale,

@@ -190,42 +190,6 @@ def expand_shortcut_column(plan: StackPlan, sync) -> int:
 # its tail) costs what the 17-30 us pass it replaces does (tools/red_bench.py)
 FUSE_BN_RED_DEFAULT = "auto"
 FUSE_BN_RED_MIN_ROWS = 16384
-TAIL_MAX_ROWS = 3072     # B * T_out up to which a block runs in the persistent tail
-
-
-def tail_from(mod, plan: StackPlan, t_in0: int, batch: int, sync, save: bool) -> int:
-    """Index (in plan.convs) of the first conv of the persistent tail (csrc/vp3d_tail_s16.hip: the trailing blocks whose
-    convs produce at most TAIL_MAX_ROWS rows run as ONE launch per direction), or 0 when there is none.  The tail takes whole
-    blocks of the strided class whose windows tile (reshape GEMMs), 3-tap or 1-tap convs, C % 64 == 0, per-replica BatchNorm
-    with one momentum for all layers; at most vp3d_tail_max_layers() layers.
-    AN EXPERIMENT since round 4 (library built with VP3D_BUILD_EXPERIMENTS=1, then VP3D_TAIL=1): measured on MI355X at the
-    benchmark shapes the persistent kernels are correct and ~0.35 ms per step SLOWER than the per-layer launches they replace
-    (the hardware queue already pipelines those ~90 small kernels; 25 grid barriers of ~8 us and cold L2s after
-    each cost more than the launches they remove); the default library refuses the entry points (tail_max_layers() == 0)."""
-    if os.environ.get("VP3D_TAIL", "0") != "1" or sync is not None or plan.n_blocks < 1 or S.tail_max_layers() == 0:
-        return 0
-    bns = engine._bns(mod)
-    t_len = plan.lengths(t_in0)
-    first = 0
-    max_layers = S.tail_max_layers()
-    for i in reversed(range(plan.n_blocks)):
-        i1, i2 = 1 + 2 * i, 2 + 2 * i
-        sp1, sp2 = plan.convs[i1], plan.convs[i2]
-        t_blk_in, t_blk_out = t_len[i], t_len[i + 1]
-        rows = batch * t_blk_out
-        ok = (rows <= TAIL_MAX_ROWS and sp1.taps in (1, 3) and sp2.taps == 1 and _tiles(sp1, t_blk_in) and
-              sp1.c_in == sp1.c_out == sp2.c_in == sp2.c_out and sp1.c_out % 64 == 0 and
-              plan.res[i].step == sp1.taps and 0 <= plan.res[i].start < sp1.taps and
-              (2 * plan.n_blocks + 1 - i1) <= max_layers and rows * sp1.taps * sp1.c_in * 4 < 2 ** 31)
-        for bn in (bns[i1], bns[i2]):
-            ok = ok and bn.momentum is not None and bn.momentum == bns[i1].momentum and bn.eps == bns[i1].eps
-            ok = ok and bn.track_running_stats == bns[i1].track_running_stats
-        if not ok:
-            break
-        first = i1
-    if first and bns[first].momentum != bns[-1].momentum:
-        return 0
-    return first
 
 
 def _packs(ws, specs, bounds, want_dgrad: bool):
@@ -269,12 +233,9 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
 
     # expand conv: im2row staging (fp32, 128-wide rows) -> S16 rows + transposed copy
     use_bits = save and SW["act_bits"]
-    # the trailing small-M blocks as ONE persistent launch per direction (tail_from); backward reads activation bits
-    tail0 = tail_from(mod, plan, x3.shape[1], b, sync, save) if (use_bits or not save) else 0
     one_col = expand_shortcut_column(plan, sync) if (use_bits and not need_dx) else -1
     fuse_expand = (SW["expand_fused"] and sync is None and not need_dx and
-                   (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1], x3.shape[0]) and
-                   not (tail0 == 1 and save))           # (a tail that starts at conv 1 reads the expand output's transposed copy)
+                   (one_col >= 0 or not save) and next_is_not_tcopy(plan, x3.shape[1], x3.shape[0]))
     kpad = expand_kpad(plan.convs[0])
     assert kpad, "the S16 path stages the expand conv through im2row"
     t_in0 = x3.shape[1]
@@ -316,11 +277,6 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
         sp = plan.convs[idx]
         tiling = sp.taps == 1 or _tiles(sp, t_in_of[idx])
         wform[idx] = ("rows" if wgrad_from_rows(sp.c_out, sp.c_in, b * t_in_of[idx]) else "tcopy") if tiling else "gather"
-
-    # (tail0: the trailing small-M blocks run as one persistent launch; its convs read transposed copies of their inputs for
-    # the weight gradients, the first of which the last per-layer producer writes)
-    for idx in range(tail0, n_layers if tail0 else 0):
-        wform[idx] = "tcopy"
 
     def next_taps(idx):
         """taps of the conv that consumes the activation of layer idx when its wgrad reduces over the producer-written
@@ -380,7 +336,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     h_prev = None          # S16 block input (residual source)
     a = x_rows
     a_t = x_t
-    for idx in range(tail0 if tail0 else n_layers):
+    for idx in range(n_layers):
         spec = spec0 if idx == 0 else plan.convs[idx]
         if idx >= 1 and packs_pending is not None:     # the first consumer of the C x C packs: wait for the second stream
             engine.join_side_now(*packs_pending)
@@ -454,61 +410,10 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     if packs_pending is not None:
         engine.join_side_now(*packs_pending)
         packs_pending = None
-    if tail0:
-        h_last = _tail_forward(mod, plan, tail0, a, a_t, packs, bounds, bits_all, bits_at, m_all, seed, offset, p, save, saved)
     out = engine._shrink(mod, h_last)
     if not save:
         return out, None
-    return out, dict(layers=saved, h_last=h_last, wts=ops.pack_weight(mod.shrink.weight.detach()), bounds=bounds, tail0=tail0)
-
-
-def _tail_forward(mod, plan: StackPlan, tail0: int, x0: S.S16, x0_t, packs, bounds, bits_all, bits_at, m_all, seed, offset, p,
-                  save: bool, saved):
-    """Layers tail0 .. n_layers-1 in one persistent launch (S.tail_fwd); appends their _Saved entries; returns the fp32 stack
-    output (the shrink conv's input)."""
-    convs, bns = engine._convs(mod), engine._bns(mod)
-    n_layers = len(plan.convs)
-    b, _, c = x0.data.shape
-    dev = x0.data.device
-    layers, prev_a, prev_at = [], x0, x0_t
-    h_last = None
-    drops = []
-    for idx in range(tail0, n_layers):
-        spec = plan.convs[idx]
-        m_rows = m_all[idx]
-        if m_rows <= 1:                # same failure as torch.nn.functional.batch_norm in training mode (ops.bn_finalize)
-            raise ValueError("Expected more than 1 value per channel when training, got input size [%d, %d]" % (m_rows, c))
-        t_out = m_rows // b
-        last = idx == n_layers - 1
-        bn = bns[idx]
-        track = bn.track_running_stats and bn.running_mean is not None
-        y = torch.empty((b, t_out, c), dtype=torch.float32, device=dev)
-        coef = torch.empty((4, c), dtype=torch.float32, device=dev)
-        a = torch.empty((b, t_out, c), dtype=torch.float32, device=dev)
-        a_f32 = torch.empty((b, t_out, c), dtype=torch.float32, device=dev) if last else None
-        taps_at = plan.convs[idx + 1].taps if not last else 0
-        a_t = (torch.empty((taps_at * c, S.t_pitch(m_rows, taps_at)), dtype=torch.float32, device=dev)
-               if (save and not last) else None)
-        bits = None
-        if bits_all is not None:
-            bits = bits_all[bits_at:bits_at + m_rows * c // 8]
-            bits_at += bits.numel()
-        drop = ops.make_dropout(p, seed, offset, idx, mod._dropout_counter_ptr())
-        drops.append(drop)
-        layers.append(dict(M=m_rows, taps=spec.taps, res_start=plan.res[idx // 2 - 1].start if idx % 2 == 0 else -1,
-                           wf=packs[idx][0], gamma=bn.weight, beta=bn.bias,
-                           running_mean=bn.running_mean if track else None, running_var=bn.running_var if track else None,
-                           nbt=bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None,
-                           y=y, coef=coef, a=a, a_bound=bounds[idx], a_f32=a_f32, a_t=a_t, taps_at=taps_at, bits=bits, drop=drop))
-        if save:
-            sv = _Saved(prev_at, y, coef, drop, packs[idx][1], prev_a.data.shape[1], 0, bits, x_rows=prev_a)
-            sv.wform = "tcopy"
-            saved.append(sv)
-        prev_a, prev_at = S.S16(a, bounds[idx]), (S.S16(a_t, bounds[idx]) if a_t is not None else None)
-        if last:
-            h_last = a_f32
-    S.tail_fwd(c, x0, layers, float(bns[tail0].eps), float(bns[tail0].momentum), mod._momentum_dev_ptr())
-    return h_last
+    return out, dict(layers=saved, h_last=h_last, wts=ops.pack_weight(mod.shrink.weight.detach()), bounds=bounds)
 
 
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
@@ -707,33 +612,7 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
                     family="tconv_dgrad", red=red_for(up, bb * t_o, taps * c_in, c_out, dy), mix=True)
         return dx
 
-    # the trailing small-M blocks: one persistent launch (S.tail_bwd) instead of ~10 launches per block on two streams
-    tail0 = saved.get("tail0", 0)
     n_head = plan.n_blocks
-    if tail0:
-        n_head = (tail0 - 1) // 2
-        tl = []
-        for idx in range(tail0, n_layers):
-            s_, spec = L[idx], plan.convs[idx]
-            m_rows = s_.y.shape[0] * s_.y.shape[1]
-            c = spec.c_out
-            o_w, o_g, o_bt = view(convs[idx].weight), view(bns[idx].weight), view(bns[idx].bias)
-            if o_g is None or o_bt is None:
-                o_g = o_bt = None
-            dgb = torch.empty((2, c), dtype=torch.float32, device=dev) if o_g is None else None
-            dgam, dbet = (dgb[0], dgb[1]) if o_g is None else (o_g, o_bt)
-            dw = o_w if o_w is not None else torch.empty((c, spec.c_in, spec.taps), dtype=torch.float32, device=dev)
-            grads[3 * idx], grads[3 * idx + 1], grads[3 * idx + 2] = sunk(dw, o_w), sunk(dgam, o_g), sunk(dbet, o_bt)
-            tl.append(dict(M=m_rows, taps=spec.taps, res_start=plan.res[idx // 2 - 1].start if idx % 2 == 0 else -1,
-                           wd=s_.wd, y=s_.y, coef=s_.coef, bits=s_.bits, x_t=s_.x_t,
-                           go=dh if idx == last else torch.empty_like(s_.y), go_bound=bounds[idx],
-                           dy=torch.empty_like(s_.y), dy_t=torch.empty((c, S.t_pitch(m_rows)), dtype=torch.float32, device=dev),
-                           dy_bound=bounds[n_layers + idx], dgamma=dgam, dbeta=dbet, dw=dw))
-        dx0 = torch.empty((b, L[tail0].t_in, plan.convs[tail0].c_in), dtype=torch.float32, device=dev)
-        S.tail_bwd(plan.convs[tail0].c_out, p if L[tail0].drop is not None else 0.0, tl, dx0, bounds[tail0 - 1])
-        dh = dx0
-        for _ in range(plan.n_blocks - n_head):
-            group_done(on_side=False)
     for i in reversed(range(n_head)):
         i1, i2 = 1 + 2 * i, 2 + 2 * i
         dy2, dy2_t = act_bwd(i2, dh)

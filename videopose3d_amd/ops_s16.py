@@ -864,142 +864,3 @@ def prologue_b(x: torch.Tensor, spec: ConvSpec, kpad: int, one_col: int, x_bound
           "vp3d_prologue_b_s16")
     packs = [(S16(wf, w_bounds[i]), S16(wd, w_bounds[i]) if wd is not None else None) for i, (wf, wd) in enumerate(zip(wfs, wds))]
     return S16(rows, x_bound), (S16(tt, x_bound) if tt is not None else None), w0_packed, S16(w0_s16, w0_bound), packs
-
-
-# --------------------------------------------------------------------------------------------------------
-# persistent small-M tail (vp3d_tail_fwd_s16 / vp3d_tail_bwd_s16: csrc/vp3d_tail_s16.hip)
-# --------------------------------------------------------------------------------------------------------
-_tail_ws_cache = {}
-_tail_sync_pool = {}
-TAIL_CALLS = {"fwd": 0, "bwd": 0}        # launches of the persistent kernels in this process (the tests assert on it)
-TAIL_TRACE = {"fwd": None, "bwd": None}  # set to a uint64[128] device tensor each: workgroup 0's phase time stamps (tools/tail_trace.py)
-
-
-def tail_max_layers() -> int:
-    return int(_lib.lib().vp3d_tail_max_layers())
-
-
-def tail_workspace(c: int, rows, taps) -> Tuple[int, int, int]:
-    """(forward, dgrad, wgrad) workspace floats of a tail with the given per-layer (rows, taps), as the launchers plan it."""
-    key = (torch.cuda.current_device(), c, tuple(rows), tuple(taps))
-    hit = _tail_ws_cache.get(key)
-    if hit is None:
-        n = len(rows)
-        f, d, w = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        check(_lib.lib().vp3d_tail_workspace(c, n, (C.c_int64 * n)(*rows), (C.c_int32 * n)(*taps), C.byref(f), C.byref(d),
-                                             C.byref(w)), "vp3d_tail_workspace")
-        hit = _tail_ws_cache[key] = (f.value, d.value, w.value)
-    return hit
-
-
-def _tail_sync(device) -> torch.Tensor:
-    """Barrier state (word 0 = error flag) of the persistent kernels, one per (device, stream): launches on a stream are ordered and
-    every call zeroes the pair itself."""
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
-    t = _tail_sync_pool.get(key)
-    if t is None:
-        t = _tail_sync_pool[key] = torch.zeros(_lib.lib().vp3d_tail_sync_bytes() // 4, dtype=torch.int32, device=device)
-    return t
-
-
-def tail_error(device) -> int:
-    """(synchronises) non-zero when a grid barrier of the last tail launch on the current stream timed out."""
-    return int(_tail_sync(device)[0].item())
-
-
-_tail_flag_host = {}
-
-
-def _tail_watch(device):
-    """Time-outs must not pass silently: after every launch the error flag is copied (stream-ordered, non-blocking) into a
-    pinned host word, and before every launch the word of the EARLIER launches is looked at -- no synchronisation, at most a
-    step of delay.  A time-out means some workgroup was never resident (another process on the GPU, a grid larger than the
-    occupancy): the results of that launch are invalid."""
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
-    h = _tail_flag_host.get(key)
-    if h is None:
-        h = _tail_flag_host[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
-    elif int(h[0]) != 0:
-        h[0] = 0
-        raise _lib.Vp3dError("a grid barrier of an earlier persistent-tail launch timed out (VP3D_TAIL=1): its results were invalid; "
-                             "run with VP3D_TAIL=0 (the default per-layer launches)")
-    return h
-
-
-def tail_fwd(c: int, x0: S16, layers, eps: float, momentum: float, momentum_dev: Optional[int] = None):
-    """Forward of the tail's layers in one launch.  layers: list of dicts with
-         M, taps, res_start, wf (S16), gamma, beta, running_mean, running_var, nbt (tensors or None), y, coef, a (tensors),
-         a_bound (tensor), a_f32, a_t (tensors or None), taps_at, bits (tensor or None), drop (_lib.Dropout or None)
-    The tensors are written in place; nothing is returned."""
-    n = len(layers)
-    dev = x0.data.device
-    fwd_floats, _, _ = tail_workspace(c, [L["M"] for L in layers], [L["taps"] for L in layers])
-    part = torch.empty(max(fwd_floats, 4), dtype=torch.float32, device=dev)
-    arr = (_lib.TailFwdLayer * n)()
-    flops = nbytes = 0.0
-    for i, L in enumerate(layers):
-        u = arr[i]
-        u.M, u.taps, u.res_start = L["M"], L["taps"], L["res_start"]
-        u.wf, u.w_bound = L["wf"].data.data_ptr(), L["wf"].bound_ptr()
-        u.gamma, u.beta = L["gamma"].data_ptr(), L["beta"].data_ptr()
-        u.running_mean, u.running_var, u.num_batches_tracked = ops._p(L["running_mean"]), ops._p(L["running_var"]), ops._p(L["nbt"])
-        u.y, u.coef, u.a, u.a_bound = L["y"].data_ptr(), L["coef"].data_ptr(), L["a"].data_ptr(), L["a_bound"].data_ptr()
-        u.a_f32 = ops._p(L.get("a_f32"))
-        at = L.get("a_t")
-        u.a_t, u.ld_at, u.taps_at = ops._p(at), (at.shape[1] if at is not None else 0), (L.get("taps_at") or 1)
-        u.act_bits = ops._p(L.get("bits"))
-        u.drop = C.pointer(L["drop"]) if L.get("drop") is not None else None
-        u.splits = int(L.get("splits") or 0)
-        flops += 2.0 * L["M"] * c * L["taps"] * c
-        nbytes += 4.0 * (L["M"] * c * (L["taps"] + 3) + c * c * L["taps"])
-    d = _lib.TailFwd()
-    d.n_layers, d.C, d.layers = n, c, arr
-    d.x0, d.x0_bound = x0.data.data_ptr(), x0.bound_ptr()
-    d.part, d.part_floats = part.data_ptr(), part.numel()
-    d.eps, d.momentum, d.momentum_dev = float(eps), float(momentum), momentum_dev
-    d.sync = _tail_sync(dev).data_ptr()
-    d.trace = ops._p(TAIL_TRACE["fwd"])
-    TAIL_CALLS["fwd"] += 1
-    watch = _tail_watch(dev)
-    ops._timed_call("tconv_fwd", flops, _lib.lib().vp3d_tail_fwd_s16, ops._stream(), C.byref(d), nbytes=nbytes,
-                    shape=(layers[0]["M"], c, layers[0]["taps"] * c, "tail", n, 1))
-    if not torch.cuda.is_current_stream_capturing():
-        watch.copy_(_tail_sync(dev)[:1], non_blocking=True)
-
-
-def tail_bwd(c: int, p: float, layers, dx0: torch.Tensor, dx0_bound: torch.Tensor):
-    """Backward of the tail's layers in one launch.  layers: list of dicts with
-         M, taps, res_start, wd (S16), y, coef, bits, x_t (S16), go, go_bound, dy, dy_t, dy_bound, dgamma, dbeta, dw (tensors)
-    (go / go_bound of the LAST layer are inputs); dx0 [rows0, C] and dx0_bound (zeroed) receive the gradient wrt the tail's
-    input rows and its maximum."""
-    n = len(layers)
-    dev = dx0.device
-    _, d_floats, w_floats = tail_workspace(c, [L["M"] for L in layers], [L["taps"] for L in layers])
-    dpart = torch.empty(max(d_floats, 4), dtype=torch.float32, device=dev)
-    wpart = torch.empty(max(w_floats, 4), dtype=torch.float32, device=dev)
-    arr = (_lib.TailBwdLayer * n)()
-    flops = nbytes = 0.0
-    for i, L in enumerate(layers):
-        u = arr[i]
-        u.M, u.taps, u.res_start = L["M"], L["taps"], L["res_start"]
-        u.wd, u.w_bound = L["wd"].data.data_ptr(), L["wd"].bound_ptr()
-        u.y, u.coef, u.act_bits = L["y"].data_ptr(), L["coef"].data_ptr(), L["bits"].data_ptr()
-        u.x_t, u.ld_xt, u.x_bound = L["x_t"].data.data_ptr(), L["x_t"].data.shape[1], L["x_t"].bound_ptr()
-        u.go, u.go_bound = L["go"].data_ptr(), L["go_bound"].data_ptr()
-        u.dy, u.dy_t, u.ld_dyt, u.dy_bound = L["dy"].data_ptr(), L["dy_t"].data_ptr(), L["dy_t"].shape[1], L["dy_bound"].data_ptr()
-        u.dgamma, u.dbeta, u.dw = L["dgamma"].data_ptr(), L["dbeta"].data_ptr(), L["dw"].data_ptr()
-        u.splits_d, u.splits_w = int(L.get("splits_d") or 0), int(L.get("splits_w") or 0)
-        flops += 4.0 * L["M"] * c * L["taps"] * c
-        nbytes += 4.0 * (L["M"] * c * (2 * L["taps"] + 6) + 2 * c * c * L["taps"])
-    d = _lib.TailBwd()
-    d.n_layers, d.C, d.layers, d.p = n, c, arr, float(p)
-    d.dpart, d.dpart_floats, d.wpart, d.wpart_floats = dpart.data_ptr(), dpart.numel(), wpart.data_ptr(), wpart.numel()
-    d.dx0, d.dx0_bound = dx0.data_ptr(), dx0_bound.data_ptr()
-    d.sync = _tail_sync(dev).data_ptr()
-    d.trace = ops._p(TAIL_TRACE["bwd"])
-    TAIL_CALLS["bwd"] += 1
-    watch = _tail_watch(dev)
-    ops._timed_call("tconv_dgrad", flops, _lib.lib().vp3d_tail_bwd_s16, ops._stream(), C.byref(d), nbytes=nbytes,
-                    shape=(layers[0]["M"], layers[0]["taps"] * c, c, "tail", n, 1))
-    if not torch.cuda.is_current_stream_capturing():
-        watch.copy_(_tail_sync(dev)[:1], non_blocking=True)
