@@ -641,8 +641,10 @@ int vp3d_tta_fold(vp3d_stream_t stream, int64_t n_frames, int32_t n_joints, int3
  *   loss[0]  = (1/n_pts) * sum_i w_i * || pred_i - target_i ||_2          (rows of `dim` floats; w NULL = 1)
  *   grad[i]  = w_i * (pred_i - target_i) / (||.||_2 * n_pts)               (d loss / d pred; 0 where the norm is 0;
  *                                                                           grad may be NULL: loss only)
- * ws: workspace of vp3d_mpjpe_ws_bytes(n_pts) bytes, 8-byte aligned (0 bytes / NULL up to 65,536 points).
- * Deterministic (no atomics; fp64 combine). */
+ * ws: workspace of vp3d_mpjpe_ws_bytes(n_pts) bytes, 8-byte aligned (0 bytes / NULL up to 256 points); its FIRST 8 BYTES hold
+ * the ticket of the one-launch block fold and must be zero on entry -- the call leaves them zero, so a workspace that was
+ * zeroed once serves every later call on the same stream.
+ * Deterministic (the blocks' fp64 partials are folded in block order by the block that arrives last; no float atomics). */
 int64_t vp3d_mpjpe_ws_bytes(int64_t n_pts);
 int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pred, const float* target,
                const float* w, float* loss, float* grad, void* ws);

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-GEMM_NAMES = ("k_nt_s16", "k_tn_s16", "k_rows_gemm", "k_red_gemm", "k_expand_fwd_s16", "k_expand_bwd_p_s16")
+GEMM_NAMES = ("k_nt_s16", "k_tn_s16", "k_rows_gemm", "k_red_gemm", "k_expand_fwd_s16", "k_expand_bwd_p_s16", "k_head_fwd", "k_head_bwd")
 STREAM_NAMES = ("k_bn_act_fwd_s16", "k_bn_bwd_apply_s16", "k_bn_bwd_reduce_bits", "k_bn_act_fwd", "k_bn_bwd_apply", "k_bn_bwd_reduce")
 N_STEPS, N_KEEP = 6, 3
 

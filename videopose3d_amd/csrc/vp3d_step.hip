@@ -99,14 +99,21 @@ __global__ void __launch_bounds__(256) k_tta_fold(int64_t T, int J, int D, const
 // mpjpe / weighted_mpjpe: loss = mean_i w_i * ||p_i - t_i||_2 ; grad_i = w_i * (p_i - t_i) / (||.|| * n)
 // Deterministic: per-thread serial sums, fixed-shape LDS tree, fp64 combine of the block partials.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LOSS_THREADS = 1024;
+constexpr int LOSS_THREADS = 256;
+constexpr int LOSS_MAX_BLOCKS = 1024;
 
+// One point per thread and pass (a block of 256 threads, up to LOSS_MAX_BLOCKS blocks): the gradient of a point needs nothing
+// but the point, so it is written at once; the value is the sum of the blocks' fp64 partials, folded IN BLOCK ORDER by the block
+// that draws the last ticket (round 6: the single 1024-thread block of rounds 2-5 walked 17 points per thread through dependent
+// scalar loads -- 15 us on the dependent chain between the head's forward and backward; this form takes ~5).
+// ws: [0] = ticket (int32 in the first 8 bytes: zero on entry, zero again on exit), [1 ..] = the partials.
 template <int DIM>
 __global__ void __launch_bounds__(LOSS_THREADS) k_mpjpe(int64_t n, int dim, const float* __restrict__ p,
                                                         const float* __restrict__ t, const float* __restrict__ w,
-                                                        float inv_n, float* __restrict__ grad, double* __restrict__ part,
+                                                        float inv_n, float* __restrict__ grad, double* __restrict__ ws,
                                                         float* __restrict__ loss) {
   __shared__ double red[LOSS_THREADS / 64];
+  __shared__ int last_flag;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int d = DIM > 0 ? DIM : dim;
@@ -126,8 +133,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_mpjpe(int64_t n, int dim, cons
       for (int c = 0; c < d; ++c) grad[i * d + c] = df[c] * k;
     }
   }
-  // fixed-shape reduction: xor butterfly inside each wave, then the 16 wave sums in order (one barrier instead of the
-  // ten of a 1024-wide LDS tree: the kernel is pure latency)
+  // fixed-shape reduction: xor butterfly inside each wave, then the wave sums in order
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -135,16 +141,24 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_mpjpe(int64_t n, int dim, cons
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < LOSS_THREADS / 64; ++i) tot += red[i];
-    if (gridDim.x == 1) loss[0] = (float)(tot * (double)inv_n);
-    else part[blockIdx.x] = tot;
-  }
-}
-
-__global__ void k_mpjpe_finish(int nparts, const double* __restrict__ part, float inv_n, float* loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += part[i];
-    loss[0] = (float)(s * (double)inv_n);
+    if (gridDim.x == 1) {
+      loss[0] = (float)(tot * (double)inv_n);
+      last_flag = 0;
+    } else {
+      // publish the partial past this XCD's L2, draw the ticket; the last arriver acquires and folds in block order
+      __hip_atomic_store(ws + 1 + blockIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int* ticket = reinterpret_cast<int*>(ws);
+      const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = tk == (int)gridDim.x - 1 ? 1 : 0;
+      if (last_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double sum = 0.0;
+        for (int i = 0; i < (int)gridDim.x; ++i)
+          sum += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        loss[0] = (float)(sum * (double)inv_n);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero for the next launch
+      }
+    }
   }
 }
 
@@ -268,18 +282,21 @@ int vp3d_tta_fold(vp3d_stream_t stream, int64_t n_frames, int32_t n_joints, int3
   return check_launch("tta_fold");
 }
 
+static int mpjpe_blocks(int64_t n_pts) { return grid_for(n_pts, LOSS_THREADS, LOSS_MAX_BLOCKS); }
+
 int64_t vp3d_mpjpe_ws_bytes(int64_t n_pts) {
-  if (n_pts <= (int64_t)LOSS_THREADS * 64) return 0;
-  return (int64_t)grid_for(n_pts, LOSS_THREADS * 8, 256) * (int64_t)sizeof(double);
+  const int blocks = mpjpe_blocks(n_pts);
+  return blocks <= 1 ? 0 : (int64_t)(1 + blocks) * (int64_t)sizeof(double);
 }
 
 int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pred, const float* target,
                const float* w, float* loss, float* grad, void* ws) {
   VP3D_REQUIRE(n_pts > 0 && dim > 0 && dim <= 8 && pred && target && loss, "mpjpe: bad argument (n=%lld dim=%d)",
                (long long)n_pts, dim);
-  const int blocks = n_pts <= (int64_t)LOSS_THREADS * 64 ? 1 : grid_for(n_pts, LOSS_THREADS * 8, 256);
+  const int blocks = mpjpe_blocks(n_pts);
   VP3D_REQUIRE(blocks == 1 || (ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0),
-               "mpjpe: %lld points need an 8-byte aligned workspace of vp3d_mpjpe_ws_bytes()", (long long)n_pts);
+               "mpjpe: %lld points need an 8-byte aligned workspace of vp3d_mpjpe_ws_bytes() whose first 8 bytes are zero",
+               (long long)n_pts);
   const float inv_n = (float)(1.0 / (double)n_pts);
   double* part = reinterpret_cast<double*>(ws);
   if (dim == 3)
@@ -291,10 +308,7 @@ int vp3d_mpjpe(vp3d_stream_t stream, int64_t n_pts, int32_t dim, const float* pr
   else
     VP3D_LAUNCH((k_mpjpe<0>), dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n_pts, dim, pred, target,
                        w, inv_n, grad, part, loss);
-  int rc = check_launch("mpjpe");
-  if (rc != VP3D_OK || blocks == 1) return rc;
-  VP3D_LAUNCH(k_mpjpe_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, blocks, part, inv_n, loss);
-  return check_launch("mpjpe_finish");
+  return check_launch("mpjpe");
 }
 
 int vp3d_adam_step(vp3d_stream_t stream, int64_t n, float* param, const float* grad, float* exp_avg,

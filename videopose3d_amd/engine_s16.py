@@ -224,7 +224,10 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     mod._stats_epoch += 1
     dev = x3.device
     n_layers = len(plan.convs)
-    bounds = S.new_bounds(2 * n_layers + 1, dev)   # [0,n): activations, [n,2n): weights, 2n: input
+    # [0,n): activations, [n,2n): weights, 2n: input; with `save` also the backward's 2n bounds ([0,n): go of layer i, [n,2n): dy
+    # of layer i) -- one zero-fill launch in the forward instead of a second one at the head of the backward's dependent chain
+    bounds_all = S.new_bounds(2 * n_layers + 1 + (2 * n_layers if save else 0), dev)
+    bounds = bounds_all[:2 * n_layers + 1]
     saved: List[_Saved] = []
     b = x3.shape[0]
     sync = mod.__dict__.get("_vp3d_sync_bn")         # dp.SyncBatchNorm: statistics (and their bounds) over the global batch
@@ -413,7 +416,7 @@ def forward_train(mod, x3: torch.Tensor, save: bool, need_dx: bool = False):
     out = engine._shrink(mod, h_last)
     if not save:
         return out, None
-    return out, dict(layers=saved, h_last=h_last, wts=ops.pack_weight(mod.shrink.weight.detach()), bounds=bounds)
+    return out, dict(layers=saved, h_last=h_last, wts=ops.pack_weight(mod.shrink.weight.detach()), bounds=bounds, bwd_bounds=bounds_all[2 * n_layers + 1:])
 
 
 def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
@@ -428,7 +431,9 @@ def backward_train(mod, saved, gout3: torch.Tensor, need_dx: bool):
     sink = mod.__dict__.get("_vp3d_grad_sink")
     convs, bns = engine._convs(mod), engine._bns(mod)
     n_layers = len(L)
-    bounds = S.new_bounds(2 * n_layers, dev)   # [0,n): go of layer i, [n,2n): dy of layer i
+    bounds = saved.pop("bwd_bounds", None)         # [0,n): go of layer i, [n,2n): dy of layer i (zeroed by the forward)
+    if bounds is None or bounds.shape[0] != 2 * n_layers:
+        bounds = S.new_bounds(2 * n_layers, dev)   # (a second backward through the same graph is refused upstream; be safe)
 
     def view(prm):
         return sink.view_for(prm) if sink is not None else None

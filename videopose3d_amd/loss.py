@@ -15,6 +15,19 @@ from ._lib import check
 from .ops import _chk, _p, _stream
 
 
+_ws_pool = {}
+
+
+def _workspace(device, n_doubles: int) -> torch.Tensor:
+    """The fold's workspace (ticket + per-block partials), one per (device, stream): zeroed ONCE -- the kernel leaves its ticket
+    zero, launches on one stream are ordered."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    t = _ws_pool.get(key)
+    if t is None or t.numel() < n_doubles:
+        t = _ws_pool[key] = torch.zeros(max(n_doubles, 1100), dtype=torch.float64, device=device)
+    return t
+
+
 def _mpjpe_call(pred, target, w, need_grad):
     _chk(pred, "predicted")
     _chk(target, "target")
@@ -24,7 +37,7 @@ def _mpjpe_call(pred, target, w, need_grad):
     loss = torch.empty((), dtype=torch.float32, device=pred.device)
     grad = torch.empty_like(pred) if need_grad else None
     ws_bytes = L.vp3d_mpjpe_ws_bytes(n)
-    ws = torch.empty((ws_bytes // 8,), dtype=torch.float64, device=pred.device) if ws_bytes else None
+    ws = _workspace(pred.device, ws_bytes // 8) if ws_bytes else None
     with torch.cuda.device(pred.device):
         check(L.vp3d_mpjpe(_stream(), n, dim, pred.data_ptr(), target.data_ptr(), _p(w), loss.data_ptr(), _p(grad),
                            _p(ws)), "vp3d_mpjpe")
