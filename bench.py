@@ -170,15 +170,15 @@ def _latest(*names):
     return os.path.join(ROOT, "profiles", names[-1])
 
 
-PMC_JSON = {"f32": _latest("r05f32_pmc_traffic.json", "r04f32_pmc_traffic.json"),
-            "f16x3": _latest("r05_pmc_traffic.json", "r04_pmc_traffic.json")}
+PMC_JSON = {"f32": _latest("r06f32_pmc_traffic.json", "r05f32_pmc_traffic.json", "r04f32_pmc_traffic.json"),
+            "f16x3": _latest("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")}
 FAMILY_KERNELS = {"f32": {"tconv_fwd": "k_rows_gemm<true,", "tconv_dgrad": "k_rows_gemm<false,", "tconv_wgrad": "k_red_gemm<"},
                   # one kernel serves all three GEMM forms of the split-fp16 path (all are "NT")
                   "f16x3": {"tconv_fwd": "k_nt_s16<", "tconv_dgrad": "k_nt_s16<", "tconv_wgrad": "k_nt_s16<"}}
 
 
-STEP_TABLE_JSON = {"f16x3": _latest("r05_step_table.json", "r04_step_table.json"),
-                   "f32": _latest("r05f32_step_table.json", "r04f32_step_table.json")}
+STEP_TABLE_JSON = {"f16x3": _latest("r06_step_table.json", "r05_step_table.json", "r04_step_table.json"),
+                   "f32": _latest("r06f32_step_table.json", "r05f32_step_table.json", "r04f32_step_table.json")}
 
 
 def pmc_traffic(family, math):
