@@ -127,6 +127,110 @@ __global__ void __launch_bounds__(C22::NT, 2) k_loop(const float* __restrict__ A
   out[(int64_t)blockIdx.x * C::NT + tid] = s;
 }
 
+// ---- round 6: the K loop of a CONSUMER-SIDE fused BatchNorm + ReLU + dropout (north_star: "each dilated conv is a fused
+// conv+BN+ReLU+dropout kernel"; review item 8): the A operand is not an S16 activation that a producer pass wrote, but the RAW
+// fp32 conv output y of the previous layer, and the consumer forms a = keep * relu(y * scale_k + shift_k) itself, per K-tile,
+// in registers -- global_load (32 B of y + 1 byte of stored activation bits per (row, 8-channel group)) -> fma / max / select
+// -> hi / lo split -> two ds_write_b128 into the same swizzled LDS image the LDS-DMA path writes.  B stays on LDS-DMA.
+// Register double buffer: the raw loads of K-tile it + 1 are issued behind the barrier of iteration `it` and converted
+// behind its MFMAs.  What the pass-free forward of the 27,648-row 1x1 conv would run its K loop at.
+__global__ void __launch_bounds__(C22::NT, 2) k_loop_fused(const float* __restrict__ Y, const float* __restrict__ B, const uint8_t* __restrict__ bits,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, float* out,
+                                                           int M, int N, int K, int n_tiles) {
+  using C = C22;
+  constexpr int RB = C::RB, CB = C::CB, BM = C::BM, BN = C::BN, PB = C::PB, BK = C::BKE, ROWB = C::ROWB, RPP = C::RPP;
+  constexpr int CPR = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / C::WN, wn = w % C::WN;
+  const int h = lane >> 5, cl = lane & 31;
+  const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = K / BK;
+  f32x16 acc[RB][CB];
+  for (int i = 0; i < RB; ++i)
+    for (int j = 0; j < CB; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)N * K * 4), 0x00020000);
+  int b_cur[PB];
+  for (int i = 0; i < PB; ++i) {
+    const int r = (w * PB + i) * RPP + lane / CPR, chunk = (lane & (CPR - 1)) ^ C::swz(r);
+    b_cur[i] = ((n0 + r) * K + chunk * 4) * 4;
+  }
+  // A items of this thread: (row, group) = (idx >> 2, idx & 3) for idx = tid and tid + 512: 4 threads cover a row's 128 bytes
+  const int row0 = tid >> 2, g = tid & 3, row1 = row0 + 128;
+  const float* y0 = Y + (int64_t)(m0 + row0) * K + g * 8;
+  const float* y1 = Y + (int64_t)(m0 + row1) * K + g * 8;
+  const uint8_t* q0 = bits + ((int64_t)(m0 + row0) * K + g * 8) / 8;
+  const uint8_t* q1 = bits + ((int64_t)(m0 + row1) * K + g * 8) / 8;
+  const int lds0 = row0 * ROWB, lds1 = row1 * ROWB;
+  const int ch0 = ((2 * g) ^ C::swz(row0)) * 16, cl0 = ((2 * g + 1) ^ C::swz(row0)) * 16;
+  const int ch1 = ((2 * g) ^ C::swz(row1)) * 16, cl1 = ((2 * g + 1) ^ C::swz(row1)) * 16;
+  f32x4 raw[4];
+  uint32_t rb[2];
+  auto load_raw = [&](int kt) {
+    raw[0] = *reinterpret_cast<const f32x4*>(y0 + kt * BK);
+    raw[1] = *reinterpret_cast<const f32x4*>(y0 + kt * BK + 4);
+    raw[2] = *reinterpret_cast<const f32x4*>(y1 + kt * BK);
+    raw[3] = *reinterpret_cast<const f32x4*>(y1 + kt * BK + 4);
+    rb[0] = q0[kt * (BK / 8)];
+    rb[1] = q1[kt * (BK / 8)];
+  };
+  auto convert_store = [&](int kt, int stage) {
+    char* sA = smem + stage * C::STAGE_B;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + kt * BK + g * 8), s1 = *reinterpret_cast<const f32x4*>(scale + kt * BK + g * 8 + 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + kt * BK + g * 8), t1 = *reinterpret_cast<const f32x4*>(shift + kt * BK + g * 8 + 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = e < 4 ? raw[2 * u][e] : raw[2 * u + 1][e - 4];
+        const float z = fmaf(yy, e < 4 ? s0[e] : s1[e - 4], e < 4 ? t0[e] : t1[e - 4]);
+        v[e] = (z > 0.f && ((rb[u] >> e) & 1u)) ? z * 1.3333334f : 0.f;
+      }
+      f16x8 hi, lo;
+      s16_split8(v, 0.125f, hi, lo);
+      *reinterpret_cast<f16x8*>(sA + (u ? lds1 : lds0) + (u ? ch1 : ch0)) = hi;
+      *reinterpret_cast<f16x8*>(sA + (u ? lds1 : lds0) + (u ? cl1 : cl0)) = lo;
+    }
+  };
+  auto issue_b = [&](int stage) {
+    char* sB = smem + stage * C::STAGE_B + C::A_B;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) blds16(rsB, b_cur[i], sB + (w * PB + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_cur[i] += BK * 4;
+  };
+  const int sw = C::swz(cl);
+  const int off0 = ((2 * (0 + h)) ^ sw) * 16, off1 = ((2 * (2 + h)) ^ sw) * 16;
+  const int a_row = (wm * RB * 32 + cl) * ROWB, b_row = (wn * CB * 32 + cl) * ROWB;
+  load_raw(0);
+  issue_b(0);
+  convert_store(0, 0);
+  int st_c = 0, st_i = 1;
+  for (int it = 0; it < nkt; ++it) {
+    wait_vmcnt<0>();
+    __syncthreads();                                   // (drains lgkmcnt as well: the A image written behind the previous MFMAs)
+    const int nx = it + 1 < nkt ? it + 1 : it;
+    load_raw(nx);
+    issue_b(st_i);
+    const char* sA = smem + st_c * C::STAGE_B + a_row;
+    const char* sB = smem + st_c * C::STAGE_B + C::A_B + b_row;
+    compute_tile<RB, CB, 2, ROWB>(sA, sB, acc, off0, off1);
+    convert_store(nx, st_i);
+    st_c ^= 1;
+    st_i ^= 1;
+  }
+  wait_vmcnt<0>();
+  float s = 0.f;
+  for (int i = 0; i < RB; ++i)
+    for (int j = 0; j < CB; ++j)
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[(int64_t)blockIdx.x * C::NT + tid] = s;
+}
+
 // ---- round 4: the 224 x 256 tile (verdict item 3): 27,648 rows = 123.4 row tiles -> 124 x 4 = 496 tiles = 1.94 rounds of 256
 // CUs (432 tiles of 256 x 256 = 1.69 rounds cost 2).  Same 8 waves in the same 2 x 4 grid: wave row 0 keeps its 4 row blocks
 // (rows 0..127), wave row 1 has 3 (rows 128..223) -- wave w runs on SIMD w % 4, so every SIMD hosts one wave of each kind and
@@ -239,6 +343,45 @@ int main() {
     }
     printf("ABL %d  %-28s %.3f ms   %.0f TFLOP/s algorithmic (%.0f executed)   %.2f us per K-tile\n", abl, names[abl], best,
            2.0 * M * N * K / best / 1e9, 6.0 * M * N * K / best / 1e9, best * 1e3 / 2 / (K / 32));
+  }
+  {
+    // round 6: A through registers with the fused BatchNorm + ReLU + dropout (stored bits), K = 1024 and K = 3072
+    uint8_t* bits;
+    float *sc, *sh;
+    hipMalloc(&bits, (size_t)M * K / 8);
+    hipMemset(bits, 0xB7, (size_t)M * K / 8);
+    hipMalloc(&sc, K * 4);
+    hipMalloc(&sh, K * 4);
+    float* Y;                                          // the raw conv output: real fp32 values (the MFMA power draw depends on the data)
+    hipMalloc(&Y, (size_t)M * K * 4);
+    {
+      std::vector<float> hy((size_t)M * K);
+      for (auto& v : hy) v = (rand() % 2001 - 1000) / 1000.0f;
+      hipMemcpy(Y, hy.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
+    }
+    std::vector<float> hs(K, 1.0f), ht(K, 0.05f);
+    hipMemcpy(sc, hs.data(), K * 4, hipMemcpyHostToDevice);
+    hipMemcpy(sh, ht.data(), K * 4, hipMemcpyHostToDevice);
+    for (int kk : {3072, 1024}) {
+      float best = 1e9f, best0 = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_loop_fused, dim3(tiles), dim3(C22::NT), 0, 0, Y, B, bits, sc, sh, out, M, N, kk, N / 256);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_loop<0>, dim3(tiles), dim3(C22::NT), 0, 0, A, B, out, M, N, kk, N / 256);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best0) best0 = ms;
+      }
+      printf("K = %4d  fused A producer (fp32 y + bits -> BN + ReLU + dropout -> split -> LDS) %.3f ms  %.0f TFLOP/s   |  library loop %.3f ms  %.0f TFLOP/s   (x %.2f)\n",
+             kk, best, 2.0 * M * N * kk / best / 1e9, best0, 2.0 * M * N * kk / best0 / 1e9, best / best0);
+    }
   }
   {
     // the 224 x 256 tile on the same two full rounds: 128 x 4 = 512 tiles over 28,672 rows (operands re-used: A is 32,768 rows)
