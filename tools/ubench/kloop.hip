@@ -384,6 +384,25 @@ int main() {
     }
   }
   {
+    // round 6: the per-tile FIXED cost of the library loop (workgroup start, row setup, first DMA latency, drain; the ubench has
+    // no epilogue): T(K, rounds) = launch + rounds * (K / 32 * t + X)
+    for (int kk : {64, 1024, 3072})
+      for (int rounds : {1, 2}) {
+        const int mm = rounds * 64 * 256;               // rounds * 64 m-tiles x 4 n-tiles = rounds * 256 tiles
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+          hipEventRecord(e0);
+          hipLaunchKernelGGL(k_loop<0>, dim3(rounds * 256), dim3(C22::NT), 0, 0, A, B, out, mm, N, kk, N / 256);
+          hipEventRecord(e1);
+          hipEventSynchronize(e1);
+          float ms;
+          hipEventElapsedTime(&ms, e0, e1);
+          if (rep && ms < best) best = ms;
+        }
+        printf("fixed-cost probe  K = %4d  rounds = %d: %8.1f us   (%.1f us per round)\n", kk, rounds, best * 1e3, best * 1e3 / rounds);
+      }
+  }
+  {
     // the 224 x 256 tile on the same two full rounds: 128 x 4 = 512 tiles over 28,672 rows (operands re-used: A is 32,768 rows)
     const int M2 = 224 * 128;
     float best = 1e9f;
