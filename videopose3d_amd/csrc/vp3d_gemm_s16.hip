@@ -28,6 +28,18 @@ namespace {
 
 using namespace mma;
 
+// -DVP3D_TRACE (tools/gemm_trace.py, never in the shipped library): thread 0 of every workgroup of k_nt_s16 leaves the 100-MHz
+// wall clock at its phase boundaries in g_trace[workgroup][8] -- where a tile's time goes between workgroup start and exit
+#ifdef VP3D_TRACE
+__device__ unsigned long long* g_trace = nullptr;
+#define VP3D_TR(k)                                                                                         \
+  do {                                                                                                     \
+    if (g_trace != nullptr && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();    \
+  } while (0)
+#else
+#define VP3D_TR(k) do { } while (0)
+#endif
+
 // position in the launch order -> tile.  Workgroup id b runs on XCD b % 8 (round-robin dispatch), and every XCD has its
 // own L2, so XCD x gets a CONTIGUOUS eighth [x*per_xcd, (x+1)*per_xcd) of a linear tile order in which consecutive tiles
 // form compact patches: column blocks of up to 8 tiles, inside a block m-tile by m-tile (the ~32-64 tiles an XCD runs at
@@ -77,6 +89,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / C::WN, wn = w % C::WN;
   const int h = lane >> 5, cl = lane & 31;
+  VP3D_TR(0);
 
   const int nkt_all = p.K / BK;
   // ---- work of this workgroup: one (tile, K range) segment, or (stream-K workgroups) a run of them ------------------------
@@ -227,6 +240,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     // NSTAGE-deep ring, NSTAGE-1 tiles in flight: iteration `it` waits for ITS tile only (counted vmcnt: the newer
     // tiles stay in flight across the barrier), then refills the stage everyone left at the end of iteration it-1
 #pragma unroll
+    VP3D_TR(1);
     for (int ps = 0; ps < NSTAGE - 1; ++ps) issue(ps, ps < nkt);
     // (MIX: one specialised loop per wave row -- both pass the same barriers; a branch INSIDE the loop made hipcc spill)
     auto main_loop = [&](auto rbw_c) {
@@ -284,12 +298,17 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
     if (it < nkt) body(it, fr[0], fr[1]);
   }
+  VP3D_TR(2);
   wait_vmcnt<0>();                                   // the trailing zero-page DMAs must not land in the staging below
+  VP3D_TR(3);
 
   // ---- epilogue -------------------------------------------------------------------------------------------
   const bool partial = p.splits > 1;
   const Epi& e = p.epi;
   {
+    // (round 6: these bound loads -- ~1 us of dependent L2 round trips per tile with the matrix pipe idle, tools/gemm_trace.py --
+    //  were hoisted in front of the K loop and carried in scalar registers: no change of the step or of the eval forward in
+    //  three alternating-process pairs each, one spilled VGPR: reverted, profiles/r06_gemm_tile_trace.txt)
     int ex = 0;
     if (e.bound_a != nullptr) ex += s16_exp_of(e.bound_a);
     if (e.bound_b != nullptr) ex += s16_exp_of(e.bound_b);
@@ -430,6 +449,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     }
   }
 
+  VP3D_TR(4);
   if (!partial && e.no_out) return;                  // statistics-only launch (workgroup-uniform)
   __syncthreads();                                   // every wave is done reading the operand ring
   // Each wave stages one 32-row block of its sub-tile at a time through its own [32][CB*32] fp32 LDS region and
@@ -674,6 +694,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       }
       epi_stage_sync();
     }
+    VP3D_TR(5);
     // ---- tile column sums: row lanes of the wave (shuffles), the WM waves of a column (LDS), one partial row per tile ----
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1)
@@ -728,6 +749,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       red_flag = last;
     }
     __syncthreads();
+    VP3D_TR(6);
     if (!red_flag) return;
     {
       const int col4 = (tid % LW) * 4, rg = tid / LW;
@@ -916,6 +938,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
     epi_stage_sync();
   }
   }
+  VP3D_TR(5);
   if (!partial && e.amax_out != nullptr) {             // max|stored value| of the whole launch (S16 exponent of the result)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -929,6 +952,7 @@ __global__ void __launch_bounds__(C::NT, (C::NW * C::OCC) / 4) k_nt_s16(const Ro
       s16_atomic_bound(e.amax_out, m);
     }
   }
+  VP3D_TR(6);
   };   // run_segment
 
   if constexpr (!SK) {
@@ -1836,4 +1860,15 @@ int launch_amax(hipStream_t s, int64_t n, const float* src, float* bound, float 
   return check_launch("amax");
 }
 
+#ifdef VP3D_TRACE
+int set_trace(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 }  // namespace vp3d
+
+#ifdef VP3D_TRACE
+extern "C" int vp3d_debug_trace(void* p) { return vp3d::set_trace(p); }
+#endif
